@@ -1,0 +1,681 @@
+// ORACLE (test infrastructure, NOT product code).
+// CPU restatement of the reference's AIR layer for the G1 path: limb-polynomial utilities, the
+// bigint-mod-p gadgets, flags / pulses / range-check lookups, the G1 add/double gadget, and the two
+// tables G1Stark (plumbing config, 2^9..2^10 rows) and G1ExpStark (2^16 rows).  Every function cites
+// the reference file:line it follows.  Constraint EMISSION ORDER is part of the result (Horner in
+// alpha) and is kept exactly, including the duplicated eval_flags call (g1/exp.rs:462,467).
+#pragma once
+#include "stark.hpp"
+#include "bn254.hpp"
+#include <array>
+
+namespace orc {
+
+static const int N_LIMBS = 16;         // src/constants.rs:1-2
+static const int LIMB_BITS = 16;
+static const int NUM_INPUT_LIMBS = 8;  // src/utils/flags.rs:41-42
+static const int INPUT_LIMB_BITS = 32;
+static const int NUM_FLAGS_COLS = 14;  // flags.rs:30
+static const int64_t AUX_COEFF_ABS_MAX = 1 << 29;  // modular.rs:29
+
+template <class P> static inline P cst(u64 v) { return P(GF(v)); }
+template <class P, size_t N> using Arr = std::array<P, N>;
+
+// ---- src/modular/pol_utils.rs -------------------------------------------------------------------
+template <class T> static inline Arr<T, 31> pol_mul_wide(const Arr<T, 16>& a, const Arr<T, 16>& b) {  // :221
+  Arr<T, 31> r; for (auto& x : r) x = T();
+  for (int i = 0; i < 16; i++) for (int j = 0; j < 16; j++) r[i + j] = r[i + j] + a[i] * b[j];
+  return r;
+}
+template <class T> static inline Arr<T, 32> pol_mul_wide2(const Arr<T, 17>& a, const Arr<T, 16>& b) {  // :274
+  Arr<T, 32> r; for (auto& x : r) x = T();
+  for (int i = 0; i < 17; i++) for (int j = 0; j < 16; j++) r[i + j] = r[i + j] + a[i] * b[j];
+  return r;
+}
+template <class T> static inline Arr<T, 31> pol_add(const Arr<T, 16>& a, const Arr<T, 16>& b) {  // :47
+  Arr<T, 31> r; for (auto& x : r) x = T();
+  for (int i = 0; i < 16; i++) r[i] = a[i] + b[i];
+  return r;
+}
+template <class T> static inline Arr<T, 31> pol_sub(const Arr<T, 16>& a, const Arr<T, 16>& b) {  // :131
+  Arr<T, 31> r; for (auto& x : r) x = T();
+  for (int i = 0; i < 16; i++) r[i] = a[i] - b[i];
+  return r;
+}
+template <class T, size_t N> static inline Arr<T, N> pol_sub_normal(const Arr<T, N>& a, const Arr<T, N>& b) {  // :142
+  Arr<T, N> r; for (size_t i = 0; i < N; i++) r[i] = a[i] - b[i]; return r;
+}
+template <class T, size_t N> static inline Arr<T, N> pol_mul_scalar(const Arr<T, N>& a, T c) {  // :235
+  Arr<T, N> r; for (size_t i = 0; i < N; i++) r[i] = c * a[i]; return r;
+}
+template <class T> static inline Arr<T, 31> widen(const Arr<T, 16>& a) {
+  Arr<T, 31> r; for (auto& x : r) x = T(); for (int i = 0; i < 16; i++) r[i] = a[i]; return r;
+}
+// pol_adjoin_root :348  -- (x - root) * a(x)
+template <class T> static inline Arr<T, 32> pol_adjoin_root(const Arr<T, 32>& a, T root) {
+  Arr<T, 32> r;
+  r[0] = (T() - root) * a[0];
+  for (int d = 1; d < 32; d++) r[d] = a[d - 1] - root * a[d];
+  return r;
+}
+
+static inline const Arr<int64_t, 16>& bn254_modulus_limbs() {  // modular.rs:298-309
+  static const Arr<int64_t, 16> m = u256_to_limbs16(BN254_P);
+  return m;
+}
+template <class P> static inline Arr<P, 16> bn254_modulus_p() {
+  Arr<P, 16> r; const auto& m = bn254_modulus_limbs();
+  for (int i = 0; i < 16; i++) r[i] = cst<P>((u64)m[i]);
+  return r;
+}
+
+// ---- src/modular/modular.rs, modular_zero.rs, addcy.rs --------------------------------------------
+template <class T> struct ModulusAux {      // modular.rs:31-36
+  Arr<T, 16> out_aux_red; Arr<T, 17> quot_abs; Arr<T, 31> aux_input_lo, aux_input_hi;
+};
+template <class T> struct ModulusAuxZero {  // modular_zero.rs:27-31
+  Arr<T, 17> quot_abs; Arr<T, 31> aux_input_lo, aux_input_hi;
+};
+
+// addcy.rs:16-58
+template <class P>
+static inline void eval_addcy(Consumer<P>& yc, P filter, const Arr<P, 16>& x, const Arr<P, 16>& y, const Arr<P, 16>& z, const Arr<P, 16>& given_cy) {
+  P overflow = cst<P>(1ULL << LIMB_BITS);
+  P overflow_inv = cst<P>(18446462594437939201ULL);  // addcy.rs:13
+  P cy = P();
+  for (int i = 0; i < 16; i++) {
+    P t = cy + x[i] + y[i] - z[i];
+    yc.constraint(filter * t * (overflow - t));
+    cy = t * overflow_inv;
+  }
+  yc.constraint(filter * given_cy[0] * (given_cy[0] - cst<P>(1)));
+  yc.constraint(filter * (cy - given_cy[0]));
+  for (int i = 1; i < 16; i++) yc.constraint(filter * given_cy[i]);
+}
+
+template <class P>
+static inline Arr<P, 32> aux_adjoined(const Arr<P, 31>& lo, const Arr<P, 31>& hi) {
+  P base = cst<P>(1ULL << LIMB_BITS), offset = cst<P>((u64)AUX_COEFF_ABS_MAX);
+  Arr<P, 32> aux_poly; aux_poly[31] = P();
+  for (int i = 0; i < 31; i++) aux_poly[i] = (lo[i] - offset) + base * hi[i];
+  return pol_adjoin_root(aux_poly, base);
+}
+// modular.rs:102-153
+template <class P>
+static inline Arr<P, 32> modular_constr_poly(Consumer<P>& yc, P filter, const Arr<P, 16>& modulus, const Arr<P, 16>& output, P quot_sign, const ModulusAux<P>& aux) {
+  Arr<P, 16> is_less_than; for (auto& x : is_less_than) x = P(); is_less_than[0] = cst<P>(1);
+  eval_addcy(yc, filter, modulus, aux.out_aux_red, output, is_less_than);
+  yc.constraint(filter * (quot_sign * quot_sign - cst<P>(1)));
+  Arr<P, 17> quot; for (int i = 0; i < 17; i++) quot[i] = quot_sign * aux.quot_abs[i];
+  Arr<P, 32> constr = pol_mul_wide2(quot, modulus);
+  for (int i = 0; i < 16; i++) constr[i] = constr[i] + output[i];
+  Arr<P, 32> adj = aux_adjoined(aux.aux_input_lo, aux.aux_input_hi);
+  for (int i = 0; i < 32; i++) constr[i] = constr[i] + adj[i];
+  return constr;
+}
+// modular.rs:215-230
+template <class P>
+static inline void eval_modular_op(Consumer<P>& yc, P filter, const Arr<P, 16>& modulus, const Arr<P, 31>& input, const Arr<P, 16>& output, P quot_sign, const ModulusAux<P>& aux) {
+  Arr<P, 32> c = modular_constr_poly(yc, filter, modulus, output, quot_sign, aux);
+  for (int i = 0; i < 31; i++) c[i] = c[i] - input[i];
+  for (int i = 0; i < 32; i++) yc.constraint(filter * c[i]);
+}
+// modular_zero.rs:82-120
+template <class P>
+static inline void eval_modular_zero(Consumer<P>& yc, P filter, const Arr<P, 16>& modulus, const Arr<P, 31>& input, P quot_sign, const ModulusAuxZero<P>& aux) {
+  yc.constraint(filter * (quot_sign * quot_sign - cst<P>(1)));
+  Arr<P, 17> quot; for (int i = 0; i < 17; i++) quot[i] = quot_sign * aux.quot_abs[i];
+  Arr<P, 32> c = pol_mul_wide2(quot, modulus);
+  Arr<P, 32> adj = aux_adjoined(aux.aux_input_lo, aux.aux_input_hi);
+  for (int i = 0; i < 32; i++) c[i] = c[i] + adj[i];
+  for (int i = 0; i < 31; i++) c[i] = c[i] - input[i];
+  for (int i = 0; i < 32; i++) yc.constraint(filter * c[i]);
+}
+
+// Witness side.  Common core of generate_modular_op (modular.rs:38-100) and generate_modular_zero
+// (modular_zero.rs:33-80): given P(x) (31 signed coeffs), out = P(beta) mod p, quot, aux.
+struct ModWitness {
+  Arr<int64_t, 16> output, out_aux_red;
+  int quot_sign;  // +1 / -1
+  Arr<int64_t, 17> quot_abs;
+  Arr<int64_t, 31> aux_lo, aux_hi;
+};
+static inline ModWitness generate_modular_witness(const Arr<int64_t, 31>& pol_input, bool zero_mode) {
+  const auto& ml = bn254_modulus_limbs();
+  // input mod p by Horner in Fq
+  Fq acc = fq_from_u64(0), b16 = fq_from_u64(65536);
+  for (int i = 30; i >= 0; i--) {
+    acc = fq_mul(acc, b16);
+    int64_t c = pol_input[i];
+    if (c >= 0) acc = fq_add(acc, fq_from_u64((uint64_t)c)); else acc = fq_sub(acc, fq_from_u64((uint64_t)(-c)));
+  }
+  U256 out = fq_to_u256(acc);
+  if (zero_mode) assert(out.is_zero());  // modular_zero.rs:39
+  // quot = (input - output) / p, exact: multiply by p^-1 mod 2^320
+  I320 in = i320_zero();
+  for (int i = 0; i < 31; i++) i320_add_shifted_i64(in, pol_input[i], 16 * i);
+  I320 diff = i320_sub_u256(in, out);
+  I320 q = i320_mul(diff, bn254_p_inv_320());
+  ModWitness w;
+  w.quot_sign = q.neg() ? -1 : 1;
+  I320 qa = q.neg() ? i320_neg(q) : q;
+  for (int i = 0; i < 17; i++) w.quot_abs[i] = (int64_t)((qa.l[i / 4] >> (16 * (i % 4))) & 0xffff);
+  // |quot| must fit 17 limbs (bigint_to_columns assert, utils.rs:152)
+  for (int i = 17; i < 20; i++) assert(((qa.l[i / 4] >> (16 * (i % 4))) & 0xffff) == 0);
+  w.output = u256_to_limbs16(out);
+  {
+    // out_aux_red = 2^256 - p + output  (modular.rs:62)
+    U256 t; u256_sub(t, out, BN254_P);  // wraps mod 2^256
+    w.out_aux_red = u256_to_limbs16(t);
+    assert(u256_cmp(out, BN254_P) < 0);
+  }
+  // constr_poly = input - output - quot*m ; aux = constr/(x - beta)   (modular.rs:65-72)
+  int64_t constr[32];
+  for (int i = 0; i < 31; i++) constr[i] = pol_input[i];
+  constr[31] = 0;
+  if (!zero_mode) for (int i = 0; i < 16; i++) constr[i] -= w.output[i];
+  for (int i = 0; i < 17; i++) for (int j = 0; j < 16; j++) constr[i + j] -= (int64_t)w.quot_sign * w.quot_abs[i] * ml[j];
+  int64_t aux[32];
+  aux[0] = -(constr[0] >> LIMB_BITS);  // pol_remove_root_2exp, pol_utils.rs:390
+  for (int d = 1; d < 31; d++) aux[d] = (aux[d - 1] - constr[d]) >> LIMB_BITS;
+  aux[31] = 0;
+  for (int i = 0; i < 32; i++) { aux[i] += AUX_COEFF_ABS_MAX; assert(aux[i] >= 0 && aux[i] <= 2 * AUX_COEFF_ABS_MAX); }
+  for (int i = 0; i < 31; i++) { w.aux_lo[i] = aux[i] & 0xffff; w.aux_hi[i] = (aux[i] >> LIMB_BITS) & 0xffff; }
+  return w;
+}
+
+// ---- src/curves/g1/muladd.rs -----------------------------------------------------------------------
+template <class T> struct G1Output {  // :49-59 ; column layout :79-94 (320 columns)
+  Arr<T, 16> lambda, new_x, new_y;
+  ModulusAuxZero<T> aux_zero; ModulusAux<T> aux_x, aux_y;
+  T quot_sign_zero, quot_sign_x, quot_sign_y;
+};
+static const int G1_OUTPUT_COLS = 20 * N_LIMBS;
+
+template <class T> static inline Arr<T, 16> read16(const T* lv, int& cur) { Arr<T, 16> r; for (int i = 0; i < 16; i++) r[i] = lv[cur + i]; cur += 16; return r; }
+template <class T, size_t N> static inline Arr<T, N> readn(const T* lv, int& cur) { Arr<T, N> r; for (size_t i = 0; i < N; i++) r[i] = lv[cur + i]; cur += (int)N; return r; }
+template <class T> static inline G1Output<T> read_g1_output(const T* lv, int& cur) {  // :102-122
+  G1Output<T> o;
+  o.lambda = read16(lv, cur); o.new_x = read16(lv, cur); o.new_y = read16(lv, cur);
+  o.aux_zero.quot_abs = readn<T, 17>(lv, cur); o.aux_zero.aux_input_lo = readn<T, 31>(lv, cur); o.aux_zero.aux_input_hi = readn<T, 31>(lv, cur);
+  for (ModulusAux<T>* a : {&o.aux_x, &o.aux_y}) {
+    a->out_aux_red = read16(lv, cur); a->quot_abs = readn<T, 17>(lv, cur); a->aux_input_lo = readn<T, 31>(lv, cur); a->aux_input_hi = readn<T, 31>(lv, cur);
+  }
+  o.quot_sign_zero = lv[cur++]; o.quot_sign_x = lv[cur++]; o.quot_sign_y = lv[cur++];
+  return o;
+}
+// eval_g1_add :179-230
+template <class P>
+static inline void eval_g1_add(Consumer<P>& yc, P filter, const Arr<P, 16>& a_x, const Arr<P, 16>& a_y, const Arr<P, 16>& b_x, const Arr<P, 16>& b_y, const G1Output<P>& o) {
+  Arr<P, 16> modulus = bn254_modulus_p<P>();
+  Arr<P, 16> delta_x = pol_sub_normal(b_x, a_x);
+  Arr<P, 31> delta_y = pol_sub(b_y, a_y);
+  Arr<P, 31> zero_pol = pol_sub_normal(pol_mul_wide(o.lambda, delta_x), delta_y);
+  eval_modular_zero(yc, filter, modulus, zero_pol, o.quot_sign_zero, o.aux_zero);
+  Arr<P, 31> new_x_input = pol_sub_normal(pol_mul_wide(o.lambda, o.lambda), pol_add(a_x, b_x));
+  eval_modular_op(yc, filter, modulus, new_x_input, o.new_x, o.quot_sign_x, o.aux_x);
+  Arr<P, 16> x1_minus_new_x = pol_sub_normal(a_x, o.new_x);
+  Arr<P, 31> new_y_input = pol_sub_normal(pol_mul_wide(o.lambda, x1_minus_new_x), widen(a_y));
+  eval_modular_op(yc, filter, modulus, new_y_input, o.new_y, o.quot_sign_y, o.aux_y);
+}
+// eval_g1_double :291-342
+template <class P>
+static inline void eval_g1_double(Consumer<P>& yc, P filter, const Arr<P, 16>& x, const Arr<P, 16>& y, const G1Output<P>& o) {
+  Arr<P, 16> modulus = bn254_modulus_p<P>();
+  Arr<P, 31> lambda_y_double = pol_mul_scalar(pol_mul_wide(o.lambda, y), cst<P>(2));
+  Arr<P, 31> x_sq_triple = pol_mul_scalar(pol_mul_wide(x, x), cst<P>(3));
+  Arr<P, 31> zero_pol = pol_sub_normal(lambda_y_double, x_sq_triple);
+  eval_modular_zero(yc, filter, modulus, zero_pol, o.quot_sign_zero, o.aux_zero);
+  Arr<P, 31> new_x_input = pol_sub_normal(pol_mul_wide(o.lambda, o.lambda), pol_add(x, x));
+  eval_modular_op(yc, filter, modulus, new_x_input, o.new_x, o.quot_sign_x, o.aux_x);
+  Arr<P, 16> x1_minus_new_x = pol_sub_normal(x, o.new_x);
+  Arr<P, 31> new_y_input = pol_sub_normal(pol_mul_wide(o.lambda, x1_minus_new_x), widen(y));
+  eval_modular_op(yc, filter, modulus, new_y_input, o.new_y, o.quot_sign_y, o.aux_y);
+}
+
+// Witness for one add / double (generate_g1_add :124-177, generate_g1_double :409-460).
+// Writes the 320 G1Output columns as canonical field values.
+static inline void write_mod_aux(GF* lv, int& cur, const ModWitness& w, bool with_out_aux_red) {
+  if (with_out_aux_red) for (int i = 0; i < 16; i++) lv[cur++] = GF((u64)w.out_aux_red[i]);
+  for (int i = 0; i < 17; i++) lv[cur++] = GF((u64)w.quot_abs[i]);
+  for (int i = 0; i < 31; i++) lv[cur++] = GF((u64)w.aux_lo[i]);
+  for (int i = 0; i < 31; i++) lv[cur++] = GF((u64)w.aux_hi[i]);
+}
+static inline void write_g1_output_default(GF* lv) {  // G1Output::default :61-75
+  for (int i = 0; i < G1_OUTPUT_COLS - 3; i++) lv[i] = GF();
+  for (int i = G1_OUTPUT_COLS - 3; i < G1_OUTPUT_COLS; i++) lv[i] = GF::one();
+}
+static inline Arr<int64_t, 31> i64_mul_wide(const Arr<int64_t, 16>& a, const Arr<int64_t, 16>& b) { return pol_mul_wide<int64_t>(a, b); }
+
+// Returns (new_x, new_y); `is_double` selects the formula.  Writes lv[0..320).
+static inline void generate_g1_op(bool is_double, const U256& ax, const U256& ay, const U256& bx, const U256& by, GF* lv, U256& nx, U256& ny) {
+  Fq x1 = fq_from_u256(ax), y1 = fq_from_u256(ay);
+  Fq lambda;
+  if (is_double) {
+    Fq x2 = fq_mul(x1, x1);
+    Fq num = fq_add(fq_add(x2, x2), x2);
+    Fq den = fq_add(y1, y1);
+    assert(!den.m.is_zero());
+    lambda = fq_mul(num, fq_inv(den));
+  } else {
+    Fq x2 = fq_from_u256(bx), y2 = fq_from_u256(by);
+    Fq den = fq_sub(x2, x1);
+    assert(!den.m.is_zero());
+    lambda = fq_mul(fq_sub(y2, y1), fq_inv(den));
+  }
+  Arr<int64_t, 16> l = u256_to_limbs16(fq_to_u256(lambda));
+  Arr<int64_t, 16> axl = u256_to_limbs16(ax), ayl = u256_to_limbs16(ay);
+  Arr<int64_t, 16> bxl = is_double ? axl : u256_to_limbs16(bx), byl = is_double ? ayl : u256_to_limbs16(by);
+  Arr<int64_t, 31> zero_pol;
+  if (is_double) {
+    zero_pol = pol_sub_normal(pol_mul_scalar(i64_mul_wide(l, ayl), (int64_t)2), pol_mul_scalar(i64_mul_wide(axl, axl), (int64_t)3));
+  } else {
+    zero_pol = pol_sub_normal(i64_mul_wide(l, pol_sub_normal(bxl, axl)), pol_sub(byl, ayl));
+  }
+  ModWitness wz = generate_modular_witness(zero_pol, true);
+  Arr<int64_t, 31> new_x_input = pol_sub_normal(i64_mul_wide(l, l), pol_add(axl, bxl));
+  ModWitness wx = generate_modular_witness(new_x_input, false);
+  Arr<int64_t, 31> new_y_input = pol_sub_normal(i64_mul_wide(l, pol_sub_normal(axl, wx.output)), widen(ayl));
+  ModWitness wy = generate_modular_witness(new_y_input, false);
+  int cur = 0;
+  for (int i = 0; i < 16; i++) lv[cur++] = GF((u64)l[i]);
+  for (int i = 0; i < 16; i++) lv[cur++] = GF((u64)wx.output[i]);
+  for (int i = 0; i < 16; i++) lv[cur++] = GF((u64)wy.output[i]);
+  write_mod_aux(lv, cur, wz, false);
+  write_mod_aux(lv, cur, wx, true);
+  write_mod_aux(lv, cur, wy, true);
+  lv[cur++] = GF::from_i64(wz.quot_sign); lv[cur++] = GF::from_i64(wx.quot_sign); lv[cur++] = GF::from_i64(wy.quot_sign);
+  assert(cur == G1_OUTPUT_COLS);
+  nx = limbs16_to_u256(wx.output.data()); ny = limbs16_to_u256(wy.output.data());
+}
+
+// ---- src/utils/flags.rs -------------------------------------------------------------------------------
+static inline void generate_flags_first_row(GF* lv, int s, const uint32_t* limbs) {  // :46-75
+  uint32_t first_bit = limbs[0] & 1, rest = limbs[0] >> 1;
+  lv[s] = GF(); lv[s + 1] = GF(); lv[s + 2] = GF(); lv[s + 3] = GF::one();
+  lv[s + 4] = GF(first_bit); lv[s + 5] = GF(first_bit);
+  lv[s + 6] = GF(rest);
+  for (int i = 1; i < NUM_INPUT_LIMBS; i++) lv[s + 6 + i] = GF(limbs[i]);
+}
+static inline void generate_flags_next_row(const GF* lv, GF* nv, size_t cur_row, int s) {  // :77-134
+  int a = s + 2, b = s + 3, fb = s + 4, bit = s + 5, sl = s + 6, el = sl + NUM_INPUT_LIMBS;
+  nv[a] = GF::one() - lv[a];
+  nv[b] = GF::one() - lv[b];
+  size_t num_rows = 2 * INPUT_LIMB_BITS * NUM_INPUT_LIMBS;
+  nv[s] = cur_row == num_rows - 2 ? GF::one() : GF();
+  nv[s + 1] = (cur_row % (2 * INPUT_LIMB_BITS) == 2 * INPUT_LIMB_BITS - 3) ? GF::one() : GF();
+  if (lv[a] == GF::one()) {
+    u64 fl = lv[sl].v; u64 nb = fl & 1;
+    nv[bit] = GF(nb); nv[sl] = GF(fl >> 1);
+  } else { nv[bit] = lv[bit]; nv[sl] = lv[sl]; }
+  if (lv[s + 1] == GF::one()) {
+    for (int c = sl + 1; c < el; c++) nv[c - 1] = lv[c];
+    nv[el - 1] = GF();
+  } else {
+    for (int c = sl + 1; c < el; c++) nv[c] = lv[c];
+  }
+  nv[fb] = nv[bit] * nv[b];
+}
+template <class P>
+static inline void eval_flags(Consumer<P>& yc, const P* lv, const P* nv, int s) {  // :136-195
+  int fin = s, rot = s + 1, a = s + 2, b = s + 3, fb = s + 4, bitc = s + 5, sl = s + 6, el = sl + NUM_INPUT_LIMBS;
+  P one = cst<P>(1);
+  yc.constraint_first_row(lv[a]);
+  yc.constraint_first_row(lv[b] - one);
+  P bit = lv[bitc];
+  yc.constraint(bit * bit - bit);
+  yc.constraint(bit * lv[b] - lv[fb]);
+  yc.constraint(lv[rot] * lv[a]);
+  yc.constraint(lv[fin] * lv[rot]);
+  yc.constraint_transition(lv[a] + nv[a] - one);
+  yc.constraint_transition(lv[b] + nv[b] - one);
+  P first_limb = lv[sl], next_first_limb = nv[sl], next_bit = nv[bitc];
+  P is_split = lv[a], is_final = lv[fin], is_not_final = one - is_final;
+  yc.constraint_transition(is_not_final * is_split * (first_limb - cst<P>(2) * next_first_limb - next_bit));
+  P is_not_split = one - is_split, is_rotate = lv[rot];
+  P is_not_rotate_nor_final = one - is_rotate - is_final;
+  yc.constraint_transition(is_not_split * (next_bit - bit));
+  yc.constraint_transition(is_not_rotate_nor_final * is_not_split * (first_limb - next_first_limb));
+  for (int c = sl + 1; c < el; c++) yc.constraint_transition(is_rotate * (nv[c - 1] - lv[c]));
+  yc.constraint_transition(is_rotate * nv[el - 1]);
+  for (int c = sl + 1; c < el; c++) yc.constraint_transition(is_not_rotate_nor_final * (nv[c] - lv[c]));
+}
+
+// ---- src/utils/pulse.rs ---------------------------------------------------------------------------------
+static inline int get_witness_col(int start, int i) { return start + 1 + 2 * i; }  // :14
+static inline int get_pulse_col(int start, int i) { return start + 1 + 2 * i + 1; }  // :10
+static inline void generate_pulse(std::vector<std::vector<GF>>& cols, const std::vector<size_t>& positions) {  // :20-43
+  size_t rows = cols[0].size();
+  std::vector<GF> counter(rows);
+  for (size_t i = 0; i < rows; i++) counter[i] = GF((u64)i);
+  cols.push_back(counter);
+  size_t base = cols.size();
+  cols.resize(base + 2 * positions.size());
+#pragma omp parallel for schedule(dynamic, 4)
+  for (size_t k = 0; k < positions.size(); k++) {
+    size_t pos = positions[k];
+    std::vector<GF> diff(rows), inv(rows);
+    for (size_t i = 0; i < rows; i++) diff[i] = i == pos ? GF::one() : counter[i] - GF((u64)pos);
+    gf_batch_inv(diff.data(), inv.data(), rows);
+    inv[pos] = GF();
+    std::vector<GF> pulse(rows, GF());
+    pulse[pos] = GF::one();
+    cols[base + 2 * k].swap(inv);
+    cols[base + 2 * k + 1].swap(pulse);
+  }
+}
+template <class P>
+static inline void eval_pulse(Consumer<P>& yc, const P* lv, const P* nv, int start, const std::vector<size_t>& positions) {  // :45-63
+  P counter = lv[start], one = cst<P>(1);
+  yc.constraint_first_row(counter);
+  yc.constraint_transition(nv[start] - counter - one);
+  for (size_t i = 0; i < positions.size(); i++) {
+    P cmp = counter - cst<P>((u64)positions[i]);
+    P witness = lv[get_witness_col(start, (int)i)], pulse = lv[get_pulse_col(start, (int)i)];
+    yc.constraint(cmp * witness + pulse - one);
+    yc.constraint(cmp * pulse);
+  }
+}
+static inline void generate_periodic_pulse_witness(std::vector<std::vector<GF>>& cols, size_t pulse_col, size_t period, size_t first_pulse) {  // :100-144
+  size_t rows = cols[0].size();
+  std::vector<GF> counter(rows), diff(rows), wit(rows);
+  size_t c = period - first_pulse - 1;
+  for (size_t i = 0; i < rows; i++) {
+    counter[i] = GF((u64)c);
+    assert((c == period - 1) == (cols[pulse_col][i] == GF::one()));
+    diff[i] = c == period - 1 ? GF::one() : GF((u64)c) - GF((u64)(period - 1));
+    c = (c + 1) % period;
+  }
+  gf_batch_inv(diff.data(), wit.data(), rows);
+  for (size_t i = 0; i < rows; i++) if (counter[i] == GF((u64)(period - 1))) wit[i] = GF();
+  cols.push_back(counter); cols.push_back(wit);
+}
+template <class P>
+static inline void eval_periodic_pulse(Consumer<P>& yc, const P* lv, const P* nv, int pulse_col, int start, size_t period, size_t first_pulse) {  // :146-170
+  P counter = lv[start], witness = lv[start + 1], is_reset = lv[pulse_col], next_counter = nv[start], one = cst<P>(1);
+  yc.constraint_first_row(counter - cst<P>((u64)(period - first_pulse - 1)));
+  yc.constraint_transition((one - is_reset) * (next_counter - counter - one));
+  yc.constraint_transition(is_reset * next_counter);
+  P delta = counter - cst<P>((u64)(period - 1));
+  yc.constraint(delta * witness + is_reset - one);
+  yc.constraint(delta * is_reset);
+}
+
+// ---- src/utils/lookup.rs, range_check.rs ----------------------------------------------------------------------
+template <class P>
+static inline void eval_lookups(Consumer<P>& yc, const P* lv, const P* nv, int col_in, int col_tab) {  // lookup.rs:13-34
+  P diff_input_prev = nv[col_in] - lv[col_in];
+  P diff_input_table = nv[col_in] - nv[col_tab];
+  yc.constraint(diff_input_prev * diff_input_table);
+  yc.constraint_last_row(diff_input_table);
+}
+static inline void permuted_cols(const std::vector<GF>& inputs, const std::vector<GF>& table, std::vector<GF>& sorted_inputs, std::vector<GF>& permuted_table) {  // lookup.rs:60-111
+  size_t n = inputs.size();
+  sorted_inputs = inputs;
+  std::sort(sorted_inputs.begin(), sorted_inputs.end(), [](GF a, GF b) { return a.v < b.v; });
+  std::vector<GF> sorted_table = table;
+  std::sort(sorted_table.begin(), sorted_table.end(), [](GF a, GF b) { return a.v < b.v; });
+  std::vector<size_t> unused_inds; std::vector<GF> unused_vals;
+  permuted_table.assign(n, GF());
+  size_t i = 0, j = 0;
+  while (j < n && i < n) {
+    u64 iv = sorted_inputs[i].v, tv = sorted_table[j].v;
+    if (iv > tv) { unused_vals.push_back(sorted_table[j]); j++; }
+    else if (iv < tv) {
+      if (!unused_vals.empty()) { permuted_table[i] = unused_vals.back(); unused_vals.pop_back(); }
+      else unused_inds.push_back(i);
+      i++;
+    } else { permuted_table[i] = sorted_table[j]; i++; j++; }
+  }
+  for (size_t k = j; k < n; k++) unused_vals.push_back(sorted_table[k]);
+  for (size_t k = i; k < n; k++) unused_inds.push_back(k);
+  assert(unused_inds.size() == unused_vals.size());
+  for (size_t k = 0; k < unused_inds.size(); k++) permuted_table[unused_inds[k]] = unused_vals[k];
+}
+static inline std::vector<GF> range_table(size_t rows, u64 range_max) {
+  std::vector<GF> t(rows);
+  for (size_t i = 0; i < rows; i++) t[i] = GF(i < range_max ? (u64)i : range_max - 1);
+  return t;
+}
+static inline void generate_u16_range_check(size_t t0, size_t t1, std::vector<std::vector<GF>>& cols) {  // range_check.rs:20-47
+  size_t rows = cols[0].size();
+  assert(rows >= 65536);  // :26
+  std::vector<GF> table = range_table(rows, 65536);
+  cols.push_back(table);
+  size_t base = cols.size();
+  cols.resize(base + 2 * (t1 - t0));
+#pragma omp parallel for schedule(dynamic, 4)
+  for (size_t k = t0; k < t1; k++) {
+    for (auto& x : cols[k]) { assert(x.v < 65536); (void)x; }
+    permuted_cols(cols[k], table, cols[base + 2 * (k - t0)], cols[base + 2 * (k - t0) + 1]);
+  }
+}
+template <class P>
+static inline void eval_u16_range_check(Consumer<P>& yc, const P* lv, const P* nv, int start, size_t ntargets) {  // :49-68
+  for (int i = start + 1; i < start + 1 + 2 * (int)ntargets; i += 2) eval_lookups(yc, lv, nv, i, i + 1);
+  P cur = lv[start], next = nv[start];
+  yc.constraint_first_row(cur);
+  P incr = next - cur;
+  yc.constraint_transition(incr * incr - incr);
+  yc.constraint_last_row(cur - cst<P>(65535));
+}
+static inline void generate_split_u16_range_check(size_t t0, size_t t1, std::vector<std::vector<GF>>& cols) {  // :116-160
+  size_t rows = cols[0].size();
+  assert(rows >= 256);
+  std::vector<GF> table = range_table(rows, 256);
+  cols.push_back(table);
+  size_t base = cols.size();
+  cols.resize(base + 6 * (t1 - t0));
+#pragma omp parallel for schedule(dynamic, 4)
+  for (size_t k = t0; k < t1; k++) {
+    std::vector<GF> lo(rows), hi(rows);
+    for (size_t i = 0; i < rows; i++) { u64 v = cols[k][i].v; assert(v < 65536); lo[i] = GF(v & 0xff); hi[i] = GF(v >> 8); }
+    size_t o = base + 6 * (k - t0);
+    permuted_cols(lo, table, cols[o + 1], cols[o + 2]);
+    permuted_cols(hi, table, cols[o + 4], cols[o + 5]);
+    cols[o].swap(lo); cols[o + 3].swap(hi);
+  }
+}
+template <class P>
+static inline void eval_split_u16_range_check(Consumer<P>& yc, const P* lv, const P* nv, int main_col, size_t t0, size_t t1) {  // :162-192
+  for (size_t i = 0; i < t1 - t0; i++) {
+    P lo = lv[main_col + 1 + 6 * i], hi = lv[main_col + 4 + 6 * i];
+    yc.constraint(lv[t0 + i] - (lo + hi * cst<P>(256)));
+  }
+  for (int i = main_col + 1; i < main_col + 1 + 6 * (int)(t1 - t0); i += 6) {
+    eval_lookups(yc, lv, nv, i + 1, i + 2);
+    eval_lookups(yc, lv, nv, i + 4, i + 5);
+  }
+  P cur = lv[main_col], next = nv[main_col];
+  yc.constraint_first_row(cur);
+  P incr = next - cur;
+  yc.constraint_transition(incr * incr - incr);
+  yc.constraint_last_row(cur - cst<P>(255));
+}
+
+// ---- tables ---------------------------------------------------------------------------------------------------------
+template <class Derived>
+struct AirBase : Air {
+  void eval(const GF* lv, const GF* nv, const GF* pi, Consumer<GF>& c) const override { static_cast<const Derived*>(this)->template eval_t<GF>(lv, nv, pi, c); }
+  void eval(const Ext* lv, const Ext* nv, const Ext* pi, Consumer<Ext>& c) const override { static_cast<const Derived*>(this)->template eval_t<Ext>(lv, nv, pi, c); }
+};
+
+// G1Stark: src/curves/g1/muladd.rs:462-624 (single add rows, split range check).
+struct G1OpAir : AirBase<G1OpAir> {
+  static const int MAIN_COLS = 24 * N_LIMBS + 2;
+  static const int START_RC = 4 * N_LIMBS, NUM_RC = 20 * N_LIMBS - 4, END_RC = START_RC + NUM_RC;
+  size_t num_columns() const override { return MAIN_COLS + 1 + 6 * NUM_RC; }
+  size_t num_public_inputs() const override { return 0; }
+  std::vector<std::pair<size_t, size_t>> permutation_pairs() const override {  // range_check.rs:228-246
+    std::vector<std::pair<size_t, size_t>> p;
+    for (size_t i = MAIN_COLS + 1; i < (size_t)MAIN_COLS + 1 + 6 * NUM_RC; i += 6) {
+      p.push_back({MAIN_COLS, i + 2}); p.push_back({MAIN_COLS, i + 5});
+      p.push_back({i, i + 1}); p.push_back({i + 3, i + 4});
+    }
+    return p;
+  }
+  template <class P> void eval_t(const P* lv, const P* nv, const P*, Consumer<P>& yc) const {  // :550-582
+    eval_split_u16_range_check(yc, lv, nv, MAIN_COLS, START_RC, END_RC);
+    int cur = 0;
+    auto a_x = read16(lv, cur), a_y = read16(lv, cur), b_x = read16(lv, cur), b_y = read16(lv, cur);
+    G1Output<P> o = read_g1_output(lv, cur);
+    P is_add = lv[cur++], is_double = lv[cur++];
+    eval_g1_add(yc, is_add, a_x, a_y, b_x, b_y, o);
+    eval_g1_double(yc, is_double, a_x, a_y, o);
+  }
+  // generate_trace :481-546 with caller-provided point pairs (the reference draws them at random).
+  std::vector<std::vector<GF>> generate_trace(const std::vector<G1Affine>& a, const std::vector<G1Affine>& b) const {
+    size_t rows = a.size();
+    std::vector<std::vector<GF>> cols(MAIN_COLS, std::vector<GF>(rows));
+#pragma omp parallel for schedule(static)
+    for (size_t r = 0; r < rows; r++) {
+      GF lv[MAIN_COLS];
+      auto put = [&](int off, const U256& v) { auto l = u256_to_limbs16(v); for (int i = 0; i < 16; i++) lv[off + i] = GF((u64)l[i]); };
+      put(0, a[r].x); put(16, a[r].y); put(32, b[r].x); put(48, b[r].y);
+      U256 nx, ny;
+      generate_g1_op(false, a[r].x, a[r].y, b[r].x, b[r].y, lv + 64, nx, ny);
+      lv[MAIN_COLS - 2] = GF::one(); lv[MAIN_COLS - 1] = GF();
+      for (int c = 0; c < MAIN_COLS; c++) cols[c][r] = lv[c];
+    }
+    generate_split_u16_range_check(START_RC, END_RC, cols);
+    return cols;
+  }
+};
+
+// G1ExpStark: src/curves/g1/exp.rs.
+struct G1ExpIONative { G1Affine x, offset; uint32_t exp_val[NUM_INPUT_LIMBS]; G1Affine output; };  // :109-114
+struct G1ExpAir : AirBase<G1ExpAir> {
+  size_t num_io;
+  // constants(num_io) :6-34
+  int start_flags_col, num_main_cols, start_periodic_pulse_col, start_io_pulses_col, start_lookups_col, num_range_check_cols;
+  size_t ncols, npi;
+  std::vector<size_t> pulse_positions;  // get_pulse_positions :153-163
+  explicit G1ExpAir(size_t n) : num_io(n) {
+    start_flags_col = 24 * N_LIMBS;
+    num_main_cols = start_flags_col + NUM_FLAGS_COLS;
+    start_periodic_pulse_col = num_main_cols;
+    start_io_pulses_col = start_periodic_pulse_col + 2;
+    start_lookups_col = start_io_pulses_col + 1 + 4 * (int)num_io;
+    num_range_check_cols = 24 * N_LIMBS - 3;
+    ncols = start_lookups_col + 1 + 2 * num_range_check_cols;
+    npi = 7 * NUM_INPUT_LIMBS * num_io;
+    size_t rpb = 2 * INPUT_LIMB_BITS * NUM_INPUT_LIMBS;
+    for (size_t i = 0; i < num_io; i++) { pulse_positions.push_back(i * rpb); pulse_positions.push_back(i * rpb + rpb - 1); }
+  }
+  size_t num_columns() const override { return ncols; }
+  size_t num_public_inputs() const override { return npi; }
+  std::vector<std::pair<size_t, size_t>> permutation_pairs() const override {  // range_check.rs:96-113
+    std::vector<std::pair<size_t, size_t>> p;
+    for (int i = 0; i < num_range_check_cols; i++) {
+      p.push_back({(size_t)start_lookups_col, (size_t)start_lookups_col + 1 + 2 * i + 1});
+      p.push_back({(size_t)i, (size_t)start_lookups_col + 1 + 2 * i});
+    }
+    return p;
+  }
+  template <class P> static Arr<P, 8> u16_to_u32(const Arr<P, 16>& x) {  // utils.rs:56-64
+    Arr<P, 8> r; P base = cst<P>(1ULL << 16);
+    for (int i = 0; i < 8; i++) r[i] = x[2 * i] + base * x[2 * i + 1];
+    return r;
+  }
+  template <class P> void eval_t(const P* lv, const P* nv, const P* pi, Consumer<P>& yc) const {  // :331-495
+    int is_final_col = start_flags_col, is_double_col = start_flags_col + 2, is_add_col = start_flags_col + 4, start_limbs_col = start_flags_col + 6;
+    P one = cst<P>(1);
+    int cur = 0;
+    auto a_x = read16(lv, cur), a_y = read16(lv, cur), b_x = read16(lv, cur), b_y = read16(lv, cur);
+    G1Output<P> output = read_g1_output(lv, cur);
+    P is_add = lv[is_add_col], is_double = lv[is_double_col], is_final = lv[is_final_col];
+    P is_not_final = one - is_final;
+    // is_final == sum of output pulses  :359-365
+    P sum_is_output = P();
+    for (size_t i = 1; i < 2 * num_io; i += 2) sum_is_output = sum_is_output + lv[get_pulse_col(start_io_pulses_col, (int)i)];
+    yc.constraint(is_final - sum_is_output);
+    // public inputs :368-392
+    {
+      Arr<P, 8> x_x = u16_to_u32(a_x), x_y = u16_to_u32(a_y), bx32 = u16_to_u32(b_x), by32 = u16_to_u32(b_y);
+      Arr<P, 8> limbs; for (int k = 0; k < 8; k++) limbs[k] = lv[start_limbs_col + k];
+      limbs[0] = limbs[0] * cst<P>(2) + is_add;
+      size_t pc = 0;
+      for (size_t i = 0; i < 2 * num_io; i += 2) {
+        const P* io = pi + pc; pc += 56;  // x.x x.y off.x off.y exp_val out.x out.y  (read_g1_exp_io :137-151)
+        P is_in = lv[get_pulse_col(start_io_pulses_col, (int)i)], is_out = lv[get_pulse_col(start_io_pulses_col, (int)i + 1)];
+        for (int k = 0; k < 8; k++) yc.constraint(is_in * (io[k] - x_x[k]));
+        for (int k = 0; k < 8; k++) yc.constraint(is_in * (io[8 + k] - x_y[k]));
+        for (int k = 0; k < 8; k++) yc.constraint(is_in * (io[16 + k] - bx32[k]));
+        for (int k = 0; k < 8; k++) yc.constraint(is_in * (io[24 + k] - by32[k]));
+        for (int k = 0; k < 8; k++) yc.constraint(is_out * (io[40 + k] - bx32[k]));
+        for (int k = 0; k < 8; k++) yc.constraint(is_out * (io[48 + k] - by32[k]));
+        for (int k = 0; k < 8; k++) yc.constraint(is_in * (io[32 + k] - limbs[k]));
+      }
+    }
+    // transitions :395-461
+    cur = 0;
+    auto n_a_x = read16(nv, cur), n_a_y = read16(nv, cur), n_b_x = read16(nv, cur), n_b_y = read16(nv, cur);
+    auto eqt = [&](P filter, const Arr<P, 16>& x, const Arr<P, 16>& y) { for (int i = 0; i < 16; i++) yc.constraint_transition(filter * (x[i] - y[i])); };
+    P fd = is_not_final * is_double;
+    eqt(fd, n_a_x, output.new_x); eqt(fd, n_a_y, output.new_y); eqt(fd, n_b_x, b_x); eqt(fd, n_b_y, b_y);
+    P fa = is_not_final * is_add;
+    eqt(fa, n_a_x, a_x); eqt(fa, n_a_y, a_y); eqt(fa, n_b_x, output.new_x); eqt(fa, n_b_y, output.new_y);
+    P fn = is_not_final * (one - is_double - is_add);
+    eqt(fn, n_a_x, a_x); eqt(fn, n_a_y, a_y); eqt(fn, n_b_x, b_x); eqt(fn, n_b_y, b_y);
+    eval_flags(yc, lv, nv, start_flags_col);                       // :462
+    eval_g1_add(yc, is_add, a_x, a_y, b_x, b_y, output);           // :463
+    eval_g1_double(yc, is_double, a_x, a_y, output);               // :464
+    eval_flags(yc, lv, nv, start_flags_col);                       // :467 (duplicate, kept)
+    eval_periodic_pulse(yc, lv, nv, start_flags_col + 1, start_periodic_pulse_col, 2 * INPUT_LIMB_BITS, 2 * INPUT_LIMB_BITS - 2);
+    eval_pulse(yc, lv, nv, start_io_pulses_col, pulse_positions);
+    eval_u16_range_check(yc, lv, nv, start_lookups_col, (size_t)num_range_check_cols);
+  }
+  // generate_trace_for_one_block :255-288 -> writes 512 rows of num_main_cols into `rows`
+  void generate_block(const G1ExpIONative& in, std::vector<std::vector<GF>>& cols, size_t row0, G1Affine& out) const {
+    size_t num_rows = 2 * INPUT_LIMB_BITS * NUM_INPUT_LIMBS;
+    std::vector<GF> lv(num_main_cols, GF()), nvv(num_main_cols, GF());
+    int sf = start_flags_col;
+    auto put = [&](GF* r, int off, const U256& v) { auto l = u256_to_limbs16(v); for (int i = 0; i < 16; i++) r[off + i] = GF((u64)l[i]); };
+    generate_flags_first_row(lv.data(), sf, in.exp_val);
+    U256 ax = in.x.x, ay = in.x.y, bx = in.offset.x, by = in.offset.y, nx, ny;
+    // generate_g1_exp_first_row :165-191
+    put(lv.data(), 0, ax); put(lv.data(), 16, ay); put(lv.data(), 32, bx); put(lv.data(), 48, by);
+    if (lv[sf + 4] == GF::one()) generate_g1_op(false, ax, ay, bx, by, lv.data() + 64, nx, ny); else write_g1_output_default(lv.data() + 64);
+    for (int c = 0; c < num_main_cols; c++) cols[c][row0] = lv[c];
+    for (size_t i = 0; i + 1 < num_rows; i++) {
+      std::fill(nvv.begin(), nvv.end(), GF());
+      generate_flags_next_row(lv.data(), nvv.data(), i, sf);
+      // generate_g1_exp_next_row :193-230
+      if (lv[sf + 2] == GF::one()) { ax = nx; ay = ny; }
+      else if (lv[sf + 4] == GF::one()) { bx = nx; by = ny; }
+      put(nvv.data(), 0, ax); put(nvv.data(), 16, ay); put(nvv.data(), 32, bx); put(nvv.data(), 48, by);
+      if (nvv[sf + 2] == GF::one()) generate_g1_op(true, ax, ay, ax, ay, nvv.data() + 64, nx, ny);
+      else if (nvv[sf + 4] == GF::one()) generate_g1_op(false, ax, ay, bx, by, nvv.data() + 64, nx, ny);
+      else write_g1_output_default(nvv.data() + 64);
+      for (int c = 0; c < num_main_cols; c++) cols[c][row0 + i + 1] = nvv[c];
+      lv.swap(nvv);
+    }
+    out.x = bx; out.y = by;  // b at the last row (:273-281)
+  }
+  // generate_trace :290-318 ; fills `outputs` with x*s+offset per instance.
+  std::vector<std::vector<GF>> generate_trace(std::vector<G1ExpIONative>& inputs) const {
+    assert(inputs.size() == num_io);
+    size_t rpb = 2 * INPUT_LIMB_BITS * NUM_INPUT_LIMBS, rows = rpb * num_io;
+    std::vector<std::vector<GF>> cols(num_main_cols, std::vector<GF>(rows));
+#pragma omp parallel for schedule(dynamic, 1)
+    for (size_t k = 0; k < num_io; k++) generate_block(inputs[k], cols, k * rpb, inputs[k].output);
+    generate_periodic_pulse_witness(cols, start_flags_col + 1, 2 * INPUT_LIMB_BITS, 2 * INPUT_LIMB_BITS - 2);
+    generate_pulse(cols, pulse_positions);
+    generate_u16_range_check(0, (size_t)num_range_check_cols, cols);
+    assert(cols.size() == ncols);
+    return cols;
+  }
+  // generate_public_inputs :320-327 ; g1_exp_io_to_columns :124-135 ; fq_to_u32_columns utils.rs:24
+  std::vector<GF> generate_public_inputs(const std::vector<G1ExpIONative>& inputs) const {
+    std::vector<GF> pi;
+    auto put = [&](const U256& v) { for (int i = 0; i < 8; i++) pi.push_back(GF((v.l[i / 2] >> (32 * (i % 2))) & 0xffffffffULL)); };
+    for (auto& in : inputs) {
+      put(in.x.x); put(in.x.y); put(in.offset.x); put(in.offset.y);
+      for (int i = 0; i < 8; i++) pi.push_back(GF(in.exp_val[i]));
+      put(in.output.x); put(in.output.y);
+    }
+    return pi;
+  }
+};
+
+}  // namespace orc

@@ -1,0 +1,214 @@
+"""ctypes binding of the CPU oracle (oracle/_build/liboracle.so) -- TEST INFRASTRUCTURE ONLY.
+
+Also holds small pure-Python BN254 helpers (Python ints) used to make inputs and to cross-check the
+oracle's witness arithmetic independently.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB_PATH = os.path.join(ORACLE_DIR, "_build", "liboracle.so")
+
+GL_P = 0xFFFFFFFF00000001
+BN_P = 21888242871839275222246405745257275088696311157297823662689037894645226208583
+BN_R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+
+AIR_G1_OP = 1
+AIR_G1_EXP = 2
+
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        L = C.CDLL(LIB_PATH)
+        u64p = C.POINTER(C.c_uint64)
+        L.orc_gf_mul.restype = C.c_uint64
+        L.orc_gf_mul.argtypes = [C.c_uint64, C.c_uint64]
+        L.orc_gf_inv.restype = C.c_uint64
+        L.orc_gf_inv.argtypes = [C.c_uint64]
+        for f in ("orc_air_num_columns", "orc_air_num_public_inputs", "orc_air_num_permutation_zs"):
+            getattr(L, f).restype = C.c_size_t
+            getattr(L, f).argtypes = [C.c_int, C.c_size_t]
+        L.orc_prove.restype = C.c_int
+        L.orc_prove.argtypes = [C.c_int, C.c_size_t, C.c_void_p, C.c_uint, C.c_void_p, C.c_size_t,
+                                C.POINTER(u64p), C.POINTER(C.c_size_t), C.POINTER(C.c_double)]
+        L.orc_verify.restype = C.c_int
+        L.orc_verify.argtypes = [C.c_int, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_char_p)]
+        L.orc_free.argtypes = [C.c_void_p]
+        L.orc_commit_values.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_hash_no_pad.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+        L.orc_challenger_probe.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        L.orc_ifft.argtypes = [C.c_void_p, C.c_size_t]
+        L.orc_coset_lde.argtypes = [C.c_void_p, C.c_size_t, C.c_uint, C.c_void_p]
+        L.orc_g1exp_generate_trace.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        L.orc_g1op_generate_trace.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+        L.orc_permuted_cols.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        L.orc_eval_constraints.argtypes = [C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                           C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+# ---------------------------------------------------------------- Poseidon / field
+def poseidon_permute(state):
+    a = np.array(state, dtype=np.uint64)
+    lib().orc_poseidon_permute(ptr(a))
+    return [int(x) for x in a]
+
+
+def round_constants():
+    a = np.zeros(360, dtype=np.uint64)
+    lib().orc_poseidon_round_constants(ptr(a))
+    return [int(x) for x in a]
+
+
+def hash_no_pad(vals):
+    a = np.array(vals, dtype=np.uint64)
+    out = np.zeros(4, dtype=np.uint64)
+    lib().orc_hash_no_pad(ptr(a), len(a), ptr(out))
+    return [int(x) for x in out]
+
+
+def commit_values(cols, rate_bits=1, cap_height=4, want_coeffs=False, want_lde=False):
+    cols = np.ascontiguousarray(cols, dtype=np.uint64)
+    ncols, n = cols.shape
+    cap = np.zeros((1 << cap_height, 4), dtype=np.uint64)
+    coeffs = np.zeros_like(cols) if want_coeffs else None
+    lde = np.zeros((ncols, n << rate_bits), dtype=np.uint64) if want_lde else None
+    lib().orc_commit_values(ptr(cols), ncols, n, rate_bits, cap_height, ptr(cap),
+                            ptr(coeffs) if want_coeffs else None, ptr(lde) if want_lde else None)
+    return cap, coeffs, lde
+
+
+# ---------------------------------------------------------------- BN254 in Python ints
+def g1_add(p, q):
+    if p is None:
+        return q
+    if q is None:
+        return p
+    (x1, y1), (x2, y2) = p, q
+    if x1 == x2:
+        if (y1 + y2) % BN_P == 0:
+            return None
+        lam = 3 * x1 * x1 * pow(2 * y1, -1, BN_P) % BN_P
+    else:
+        lam = (y2 - y1) * pow(x2 - x1, -1, BN_P) % BN_P
+    x3 = (lam * lam - x1 - x2) % BN_P
+    y3 = (lam * (x1 - x3) - y1) % BN_P
+    return (x3, y3)
+
+
+def g1_mul(p, k):
+    r = None
+    while k:
+        if k & 1:
+            r = g1_add(r, p)
+        p = g1_add(p, p)
+        k >>= 1
+    return r
+
+
+def g1_random(rng):
+    """Random affine G1 point: random x until x^3+3 is a square (p = 3 mod 4)."""
+    while True:
+        x = int(rng.integers(0, 1 << 62)) * (1 << 192) + int(rng.integers(0, 1 << 62)) * (1 << 128) \
+            + int(rng.integers(0, 1 << 62)) * (1 << 64) + int(rng.integers(0, 1 << 62))
+        x %= BN_P
+        rhs = (x * x * x + 3) % BN_P
+        y = pow(rhs, (BN_P + 1) // 4, BN_P)
+        if y * y % BN_P == rhs:
+            if int(rng.integers(0, 2)):
+                y = BN_P - y
+            return (x, y)
+
+
+def u32_limbs(v, n=8):
+    return [(v >> (32 * i)) & 0xFFFFFFFF for i in range(n)]
+
+
+def g1exp_inputs(num_io, seed):
+    """Mirror of src/curves/g1/exp.rs:794-809: random x, offset, exp_val = 8 uniform u32 limbs."""
+    rng = np.random.default_rng(seed)
+    ios = np.zeros((num_io, 40), dtype=np.uint32)
+    native = []
+    for k in range(num_io):
+        x = g1_random(rng)
+        off = g1_random(rng)
+        exp = [int(v) for v in rng.integers(0, 1 << 32, size=8, dtype=np.uint64)]
+        ios[k, 0:8] = u32_limbs(x[0]); ios[k, 8:16] = u32_limbs(x[1])
+        ios[k, 16:24] = u32_limbs(off[0]); ios[k, 24:32] = u32_limbs(off[1])
+        ios[k, 32:40] = exp
+        native.append((x, off, sum(e << (32 * i) for i, e in enumerate(exp))))
+    return ios, native
+
+
+def g1op_inputs(rows, seed):
+    rng = np.random.default_rng(seed)
+    pts = np.zeros((rows, 32), dtype=np.uint32)
+    native = []
+    for r in range(rows):
+        a = g1_random(rng); b = g1_random(rng)
+        pts[r, 0:8] = u32_limbs(a[0]); pts[r, 8:16] = u32_limbs(a[1])
+        pts[r, 16:24] = u32_limbs(b[0]); pts[r, 24:32] = u32_limbs(b[1])
+        native.append((a, b))
+    return pts, native
+
+
+def g1exp_trace(ios):
+    num_io = ios.shape[0]
+    L = lib()
+    ncols = L.orc_air_num_columns(AIR_G1_EXP, num_io)
+    npi = L.orc_air_num_public_inputs(AIR_G1_EXP, num_io)
+    trace = np.zeros((ncols, 512 * num_io), dtype=np.uint64)
+    pi = np.zeros(npi, dtype=np.uint64)
+    ios = np.ascontiguousarray(ios, dtype=np.uint32)
+    L.orc_g1exp_generate_trace(ptr(ios), num_io, ptr(trace), ptr(pi))
+    return trace, pi
+
+
+def g1op_trace(pts):
+    rows = pts.shape[0]
+    L = lib()
+    ncols = L.orc_air_num_columns(AIR_G1_OP, 0)
+    trace = np.zeros((ncols, rows), dtype=np.uint64)
+    pts = np.ascontiguousarray(pts, dtype=np.uint32)
+    L.orc_g1op_generate_trace(ptr(pts), rows, ptr(trace))
+    return trace
+
+
+def prove(kind, num_io, trace, pi):
+    trace = np.ascontiguousarray(trace, dtype=np.uint64)
+    pi = np.ascontiguousarray(pi, dtype=np.uint64)
+    n = trace.shape[1]
+    degree_bits = n.bit_length() - 1
+    out = C.POINTER(C.c_uint64)()
+    nw = C.c_size_t()
+    secs = C.c_double()
+    rc = lib().orc_prove(kind, num_io, ptr(trace), degree_bits, ptr(pi), len(pi), C.byref(out), C.byref(nw), C.byref(secs))
+    if rc != 0:
+        raise RuntimeError(f"orc_prove failed rc={rc}")
+    words = np.ctypeslib.as_array(out, shape=(nw.value,)).copy()
+    lib().orc_free(out)
+    return words, secs.value
+
+
+def verify(kind, num_io, words):
+    words = np.ascontiguousarray(words, dtype=np.uint64)
+    why = C.c_char_p()
+    rc = lib().orc_verify(kind, num_io, ptr(words), len(words), C.byref(why))
+    return rc, (why.value or b"").decode()
