@@ -1,0 +1,143 @@
+/*
+ * sbn.h -- C ABI of the MI355X-native Starky/BN254 prover path (libsbn254.so).
+ *
+ * Drop-in boundary for the reference's prove()/verify_stark_proof() calls on the G1 tables:
+ *   reference call sites   src/curves/g1/exp.rs:811-826      (G1ExpStark: trace, pi, prove, verify)
+ *                          src/curves/g1/muladd.rs:666-678   (G1Stark)
+ *                          src/curves/g1/circuit.rs:187-201  (G1ExpStarkyProofGenerator::run_once)
+ *   reference signatures   starky 0.1.1 `prove::<F,C,S,D>(stark, &config, trace_poly_values,
+ *                          public_inputs, &mut timing)` and `verify_stark_proof(stark, proof, &config)`
+ *                          (un-vendored dependency, Cargo.toml:21).
+ *
+ * Because the AIR's `eval_packed_generic` is generic Rust that cannot cross a C ABI, a table is
+ * named by (kind, num_io) and its constraint code lives natively behind this boundary.
+ *
+ * Conventions: plain pointers and sizes, no exceptions; 0 = success, negative = sbn_status error.
+ * All field elements are canonical Goldilocks u64 (< 2^64 - 2^32 + 1), little-endian.
+ * Trace wire format = the reference's Vec<PolynomialValues<F>>: COLUMN-MAJOR [num_columns][N]
+ * (src/curves/g1/exp.rs:314-317).  Public inputs: flat [num_public_inputs] (exp.rs:320-327).
+ *
+ * Proof byte layout ("canonical proof words", LE u64 each; the reference never serialises a proof,
+ * so this layout is defined here and shared with the test oracle):
+ *   header[12] = { magic "SNBPROV1", degree_bits, n_trace_cols, n_perm_zs, n_quotient_polys,
+ *                  n_public_inputs, cap_height, rate_bits, n_fri_layers, arity_bits,
+ *                  final_poly_len, n_queries }
+ *   trace_cap[2^cap_height][4], permutation_zs_cap[..][4] (iff n_perm_zs>0), quotient_polys_cap[..][4]
+ *   openings: local_values[n_trace_cols][2], next_values[..][2], permutation_zs[n_perm_zs][2],
+ *             permutation_zs_next[..][2], quotient_polys[n_quotient_polys][2]     (ext elem = c0,c1)
+ *   fri commit_phase_merkle_caps[n_fri_layers][2^cap_height][4]
+ *   per query (n_queries): per initial oracle (trace, [perm_zs], quotient): leaf row values, then
+ *             siblings[lde_bits-cap_height][4]; per FRI layer: evals[2^arity_bits][2], siblings[..][4]
+ *   final_poly[final_poly_len][2], pow_witness, public_inputs[n_public_inputs]
+ */
+#ifndef SBN_H
+#define SBN_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum sbn_status {
+  SBN_OK = 0,
+  SBN_ERR_BAD_ARG = -1,       /* null pointer, unknown air kind, size mismatch */
+  SBN_ERR_NON_CANONICAL = -2, /* a field element >= p was supplied */
+  SBN_ERR_NO_DEVICE = -3,     /* no HIP device / HIP runtime failure at init */
+  SBN_ERR_HIP = -4,           /* a HIP call failed (message via sbn_last_error) */
+  SBN_ERR_MALFORMED_PROOF = -5,
+  SBN_ERR_VERIFY_FAILED = -6, /* proof rejected (reason via sbn_last_error) */
+  SBN_ERR_UNSUPPORTED = -7,   /* e.g. G1_EXP with fewer than 2^16 rows (range_check.rs:26) */
+  SBN_ERR_WITNESS = -8        /* trace generation hit a degenerate case (x1==x2 in an affine add) */
+} sbn_status;
+
+/* Table kinds.  G1_OP = reference `G1Stark` (src/curves/g1/muladd.rs:462-624);
+ * G1_EXP = reference `G1ExpStark` (src/curves/g1/exp.rs:232-742). */
+typedef enum sbn_air_kind { SBN_AIR_G1_OP = 1, SBN_AIR_G1_EXP = 2 } sbn_air_kind;
+
+typedef struct sbn_air_desc {
+  int32_t kind;    /* sbn_air_kind */
+  uint32_t num_io; /* G1_EXP: number of scalar-mult instances (rows = 512*num_io); G1_OP: ignored */
+} sbn_air_desc;
+
+/* Mirrors starky `StarkConfig` + plonky2 `FriConfig` (reference: stark.config() ->
+ * StarkConfig::standard_fast_config, src/curves/g1/exp.rs:250-253). */
+typedef struct sbn_config {
+  uint32_t security_bits;      /* 100 */
+  uint32_t num_challenges;     /* 2   */
+  uint32_t rate_bits;          /* 1   */
+  uint32_t cap_height;         /* 4   */
+  uint32_t proof_of_work_bits; /* 16  */
+  uint32_t fri_arity_bits;     /* 4   (FriReductionStrategy::ConstantArityBits(4, 5)) */
+  uint32_t fri_final_poly_bits;/* 5   */
+  uint32_t num_query_rounds;   /* 84  */
+} sbn_config;
+
+typedef struct sbn_prover sbn_prover; /* device context: buffers sized for one (air, degree_bits) */
+typedef struct sbn_proof sbn_proof;   /* host-side proof object (canonical words) */
+
+/* Library / device ------------------------------------------------------------------------------ */
+const char* sbn_version(void);
+const char* sbn_last_error(void);                    /* thread-local message of the last failure */
+int sbn_device_count(void);
+int sbn_set_device(int device);                      /* device used by subsequently created provers */
+void sbn_standard_fast_config(sbn_config* out);      /* StarkConfig::standard_fast_config */
+
+/* Table shape (ExpStarkConstants, src/curves/g1/exp.rs:6-34) ----------------------------------- */
+size_t sbn_air_num_columns(const sbn_air_desc* air);
+size_t sbn_air_num_public_inputs(const sbn_air_desc* air);
+size_t sbn_air_num_permutation_zs(const sbn_air_desc* air, const sbn_config* cfg);
+size_t sbn_air_num_constraints(const sbn_air_desc* air); /* AIR constraints per point (no perm checks) */
+
+/* Witness generation (host): replaces G1ExpStark::generate_trace / generate_public_inputs
+ * (src/curves/g1/exp.rs:290-327) and G1Stark::generate_trace (muladd.rs:481-546).
+ * ios: num_io x 40 u32 = x.x[8] x.y[8] offset.x[8] offset.y[8] exp_val[8]  (u32 limbs, LE).
+ * trace_out: column-major [num_columns][512*num_io]; pi_out: [56*num_io]. */
+int sbn_generate_trace_g1_exp(const uint32_t* ios, size_t num_io, uint64_t* trace_out, uint64_t* pi_out);
+/* pts: rows x 32 u32 = a.x[8] a.y[8] b.x[8] b.y[8]; trace_out: [num_columns][rows]. */
+int sbn_generate_trace_g1_op(const uint32_t* pts, size_t rows, uint64_t* trace_out);
+
+/* Prover ---------------------------------------------------------------------------------------- */
+int sbn_prover_create(const sbn_air_desc* air, const sbn_config* cfg, uint32_t degree_bits, sbn_prover** out);
+void sbn_prover_destroy(sbn_prover* p);
+/* Host -> device copy of the trace (PCIe-inclusive path). */
+int sbn_prover_load_trace(sbn_prover* p, const uint64_t* trace_col_major, const uint64_t* public_inputs, size_t n_pi);
+/* Trace already resident in HBM (device pointer, same layout); copied device-to-device. */
+int sbn_prover_load_trace_device(sbn_prover* p, const uint64_t* d_trace_col_major, const uint64_t* public_inputs, size_t n_pi);
+/* prove() on the loaded trace; may be called repeatedly (the loaded trace is preserved). */
+int sbn_prover_prove(sbn_prover* p, sbn_proof** out);
+/* Per-stage device times (ms, HIP events on the prover's stream) of the last prove():
+ * names via sbn_prover_stage_name(i); returns the number of stages written. */
+int sbn_prover_stage_times(const sbn_prover* p, float* ms_out, int cap);
+const char* sbn_prover_stage_name(int i);
+/* Raw device pointer of the loaded trace buffer (for callers that fill it on-device). */
+uint64_t* sbn_prover_trace_device_ptr(sbn_prover* p);
+
+/* One-shot convenience with the reference's argument list:
+ * prove(stark, &config, trace_poly_values, public_inputs) (src/curves/g1/exp.rs:818-825). */
+int sbn_prove(const sbn_air_desc* air, const sbn_config* cfg, const uint64_t* trace_col_major, uint32_t degree_bits,
+              const uint64_t* public_inputs, size_t n_pi, sbn_proof** out);
+
+/* Proof object ---------------------------------------------------------------------------------- */
+size_t sbn_proof_num_words(const sbn_proof* proof);
+const uint64_t* sbn_proof_words(const sbn_proof* proof);
+/* Writes the canonical LE byte stream; returns bytes needed (call with cap=0 to size). */
+size_t sbn_proof_serialize(const sbn_proof* proof, uint8_t* buf, size_t cap);
+uint32_t sbn_proof_degree_bits(const sbn_proof* proof); /* StarkProof::recover_degree_bits, exp.rs:829 */
+void sbn_proof_free(sbn_proof* proof);
+
+/* Verifier: verify_stark_proof(stark, proof, &config) (src/curves/g1/exp.rs:826). */
+int sbn_verify(const sbn_air_desc* air, const sbn_config* cfg, const uint8_t* proof_bytes, size_t len);
+
+/* Building blocks exposed for parity tests and benchmarks (device in/out unless noted) --------- */
+/* PolynomialBatch::from_values on a host column-major matrix: Merkle cap (2^cap_height x 4 words),
+ * optionally coefficients [ncols][n] and LDE [ncols][n<<rate_bits] (natural order) back to host. */
+int sbn_commit_values(const uint64_t* cols, size_t ncols, size_t n, uint32_t rate_bits, uint32_t cap_height,
+                      uint64_t* cap_out, uint64_t* coeffs_out, uint64_t* lde_out);
+/* Poseidon permutation of `count` independent width-12 states on the device (host in/out). */
+int sbn_poseidon_permute_batch(uint64_t* states, size_t count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SBN_H */

@@ -1,0 +1,10 @@
+"""starky-bn254 on MI355X: Python host-side mirror of the reference's prover interface.
+
+Thin ctypes layer over the C ABI in include/sbn.h (libsbn254.so, built in-tree by
+`make -C starky_bn254_amd/csrc`).  There is NO CPU fallback: importing works without a GPU (so the
+symbol table can be checked), but every prove()/commit call fails loudly without a HIP device.
+"""
+from .api import (  # noqa: F401
+    AIR_G1_OP, AIR_G1_EXP, SbnError, StarkConfig, G1Stark, G1ExpStark, Prover, Proof,
+    prove, verify_stark_proof, commit_values, poseidon_permute_batch, lib, lib_path, EXPORTS,
+)

@@ -1,0 +1,285 @@
+"""Host-side mirror of the reference's operator interface for the G1 prover path.
+
+Names follow the reference (src/curves/g1/exp.rs:232-328, :811-826):
+    stark = G1ExpStark(num_io);  config = stark.config()
+    trace = stark.generate_trace(inputs);  pi = stark.generate_public_inputs(inputs)
+    proof = prove(stark, config, trace, pi);  verify_stark_proof(stark, proof, config)
+Errors surface as SbnError (the reference returns anyhow::Result and callers unwrap).
+"""
+import ctypes as C
+import os
+import numpy as np
+
+AIR_G1_OP = 1
+AIR_G1_EXP = 2
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+# every symbol include/sbn.h declares
+EXPORTS = [
+    "sbn_version", "sbn_last_error", "sbn_device_count", "sbn_set_device", "sbn_standard_fast_config",
+    "sbn_air_num_columns", "sbn_air_num_public_inputs", "sbn_air_num_permutation_zs", "sbn_air_num_constraints",
+    "sbn_generate_trace_g1_exp", "sbn_generate_trace_g1_op",
+    "sbn_prover_create", "sbn_prover_destroy", "sbn_prover_load_trace", "sbn_prover_load_trace_device",
+    "sbn_prover_prove", "sbn_prover_stage_times", "sbn_prover_stage_name", "sbn_prover_trace_device_ptr",
+    "sbn_prove", "sbn_proof_num_words", "sbn_proof_words", "sbn_proof_serialize", "sbn_proof_degree_bits",
+    "sbn_proof_free", "sbn_verify", "sbn_commit_values", "sbn_poseidon_permute_batch",
+]
+
+
+class SbnError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"sbn error {code}: {msg}")
+        self.code = code
+
+
+class _AirDesc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("num_io", C.c_uint32)]
+
+
+class _Config(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("security_bits", "num_challenges", "rate_bits", "cap_height",
+                                            "proof_of_work_bits", "fri_arity_bits", "fri_final_poly_bits", "num_query_rounds")]
+
+
+def lib_path():
+    return os.path.join(_HERE, "libsbn254.so")
+
+
+def lib():
+    """Loads libsbn254.so; raises if the HIP extension has not been built (no fallback)."""
+    global _LIB
+    if _LIB is None:
+        p = lib_path()
+        if not os.path.exists(p):
+            raise SbnError(-100, f"{p} is missing: build it with `make -C starky_bn254_amd/csrc` (there is no CPU fallback)")
+        L = C.CDLL(p)
+        vp, sz, u32 = C.c_void_p, C.c_size_t, C.c_uint32
+        L.sbn_version.restype = C.c_char_p
+        L.sbn_last_error.restype = C.c_char_p
+        L.sbn_prover_stage_name.restype = C.c_char_p
+        L.sbn_prover_stage_name.argtypes = [C.c_int]
+        for f in ("sbn_air_num_columns", "sbn_air_num_public_inputs", "sbn_air_num_constraints"):
+            getattr(L, f).restype = sz
+            getattr(L, f).argtypes = [C.POINTER(_AirDesc)]
+        L.sbn_air_num_permutation_zs.restype = sz
+        L.sbn_air_num_permutation_zs.argtypes = [C.POINTER(_AirDesc), C.POINTER(_Config)]
+        L.sbn_standard_fast_config.argtypes = [C.POINTER(_Config)]
+        L.sbn_generate_trace_g1_exp.argtypes = [vp, sz, vp, vp]
+        L.sbn_generate_trace_g1_op.argtypes = [vp, sz, vp]
+        L.sbn_prover_create.argtypes = [C.POINTER(_AirDesc), C.POINTER(_Config), u32, C.POINTER(vp)]
+        L.sbn_prover_destroy.argtypes = [vp]
+        L.sbn_prover_load_trace.argtypes = [vp, vp, vp, sz]
+        L.sbn_prover_load_trace_device.argtypes = [vp, vp, vp, sz]
+        L.sbn_prover_prove.argtypes = [vp, C.POINTER(vp)]
+        L.sbn_prover_stage_times.argtypes = [vp, C.POINTER(C.c_float), C.c_int]
+        L.sbn_prover_trace_device_ptr.restype = vp
+        L.sbn_prover_trace_device_ptr.argtypes = [vp]
+        L.sbn_prove.argtypes = [C.POINTER(_AirDesc), C.POINTER(_Config), vp, u32, vp, sz, C.POINTER(vp)]
+        L.sbn_proof_num_words.restype = sz
+        L.sbn_proof_num_words.argtypes = [vp]
+        L.sbn_proof_words.restype = C.POINTER(C.c_uint64)
+        L.sbn_proof_words.argtypes = [vp]
+        L.sbn_proof_serialize.restype = sz
+        L.sbn_proof_serialize.argtypes = [vp, vp, sz]
+        L.sbn_proof_degree_bits.restype = u32
+        L.sbn_proof_degree_bits.argtypes = [vp]
+        L.sbn_proof_free.argtypes = [vp]
+        L.sbn_verify.argtypes = [C.POINTER(_AirDesc), C.POINTER(_Config), vp, sz]
+        L.sbn_commit_values.argtypes = [vp, sz, sz, u32, u32, vp, vp, vp]
+        L.sbn_poseidon_permute_batch.argtypes = [vp, sz]
+        L.sbn_set_device.argtypes = [C.c_int]
+        _LIB = L
+    return _LIB
+
+
+def _check(rc):
+    if rc != 0:
+        raise SbnError(rc, lib().sbn_last_error().decode())
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class StarkConfig:
+    """starky `StarkConfig` (+ FriConfig); `standard_fast_config()` as in exp.rs:250-253."""
+
+    def __init__(self):
+        self._c = _Config()
+        lib().sbn_standard_fast_config(C.byref(self._c))
+
+    @staticmethod
+    def standard_fast_config(num_columns=None, num_public_inputs=None):
+        return StarkConfig()
+
+    def __getattr__(self, name):
+        return getattr(object.__getattribute__(self, "_c"), name)
+
+
+class _Stark:
+    kind = 0
+
+    def __init__(self, num_io=0):
+        self.num_io = num_io
+        self._d = _AirDesc(self.kind, num_io)
+
+    def config(self):
+        return StarkConfig.standard_fast_config(self.num_columns, self.num_public_inputs)
+
+    @property
+    def num_columns(self):
+        return lib().sbn_air_num_columns(C.byref(self._d))
+
+    @property
+    def num_public_inputs(self):
+        return lib().sbn_air_num_public_inputs(C.byref(self._d))
+
+    def num_permutation_zs(self, config=None):
+        config = config or StarkConfig()
+        return lib().sbn_air_num_permutation_zs(C.byref(self._d), C.byref(config._c))
+
+    @property
+    def num_constraints(self):
+        return lib().sbn_air_num_constraints(C.byref(self._d))
+
+    def constraint_degree(self):
+        return 3
+
+
+class G1Stark(_Stark):
+    """Reference `G1Stark` (src/curves/g1/muladd.rs:462-624): one affine add per row."""
+    kind = AIR_G1_OP
+
+    def __init__(self):
+        super().__init__(0)
+
+    def generate_trace(self, pts):
+        """pts: (rows, 32) uint32 = a.x a.y b.x b.y as 8xu32 LE limbs -> column-major (ncols, rows) uint64."""
+        pts = np.ascontiguousarray(pts, dtype=np.uint32)
+        rows = pts.shape[0]
+        trace = np.zeros((self.num_columns, rows), dtype=np.uint64)
+        _check(lib().sbn_generate_trace_g1_op(_ptr(pts), rows, _ptr(trace)))
+        return trace
+
+
+class G1ExpStark(_Stark):
+    """Reference `G1ExpStark` (src/curves/g1/exp.rs:232-742): 512 rows per scalar multiplication."""
+    kind = AIR_G1_EXP
+
+    def generate_trace_and_public_inputs(self, ios):
+        """ios: (num_io, 40) uint32 = x.x x.y offset.x offset.y exp_val (8xu32 LE limbs each)."""
+        ios = np.ascontiguousarray(ios, dtype=np.uint32)
+        assert ios.shape == (self.num_io, 40)
+        trace = np.zeros((self.num_columns, 512 * self.num_io), dtype=np.uint64)
+        pi = np.zeros(self.num_public_inputs, dtype=np.uint64)
+        _check(lib().sbn_generate_trace_g1_exp(_ptr(ios), self.num_io, _ptr(trace), _ptr(pi)))
+        return trace, pi
+
+    def generate_trace(self, ios):
+        return self.generate_trace_and_public_inputs(ios)[0]
+
+    def generate_public_inputs(self, ios):
+        return self.generate_trace_and_public_inputs(ios)[1]
+
+
+class Proof:
+    """StarkProofWithPublicInputs as canonical proof words (layout: include/sbn.h)."""
+
+    def __init__(self, words, degree_bits):
+        self.words = words
+        self.degree_bits = degree_bits
+
+    def to_bytes(self):
+        return self.words.astype("<u8").tobytes()
+
+    def recover_degree_bits(self, config=None):
+        return self.degree_bits
+
+
+def _take_proof(h):
+    L = lib()
+    n = L.sbn_proof_num_words(h)
+    words = np.ctypeslib.as_array(L.sbn_proof_words(h), shape=(n,)).copy()
+    db = L.sbn_proof_degree_bits(h)
+    L.sbn_proof_free(h)
+    return Proof(words, db)
+
+
+class Prover:
+    """Device context for one (table, degree_bits): buffers stay allocated across proofs."""
+
+    def __init__(self, stark, config, degree_bits):
+        self.stark, self.config = stark, config
+        self._h = C.c_void_p()
+        _check(lib().sbn_prover_create(C.byref(stark._d), C.byref(config._c), degree_bits, C.byref(self._h)))
+
+    def load_trace(self, trace, public_inputs):
+        trace = np.ascontiguousarray(trace, dtype=np.uint64)
+        pi = np.ascontiguousarray(public_inputs, dtype=np.uint64)
+        _check(lib().sbn_prover_load_trace(self._h, _ptr(trace), _ptr(pi), len(pi)))
+
+    def load_trace_device(self, device_ptr, public_inputs):
+        pi = np.ascontiguousarray(public_inputs, dtype=np.uint64)
+        _check(lib().sbn_prover_load_trace_device(self._h, C.c_void_p(device_ptr), _ptr(pi), len(pi)))
+
+    def trace_device_ptr(self):
+        return lib().sbn_prover_trace_device_ptr(self._h)
+
+    def prove(self):
+        h = C.c_void_p()
+        _check(lib().sbn_prover_prove(self._h, C.byref(h)))
+        return _take_proof(h)
+
+    def stage_times(self):
+        buf = (C.c_float * 32)()
+        k = lib().sbn_prover_stage_times(self._h, buf, 32)
+        return {lib().sbn_prover_stage_name(i).decode(): float(buf[i]) for i in range(k)}
+
+    def close(self):
+        if self._h:
+            lib().sbn_prover_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def prove(stark, config, trace_poly_values, public_inputs, timing=None):
+    """starky `prove(stark, &config, trace_poly_values, public_inputs, &mut timing)`."""
+    trace = np.ascontiguousarray(trace_poly_values, dtype=np.uint64)
+    pi = np.ascontiguousarray(public_inputs, dtype=np.uint64)
+    n = trace.shape[1]
+    if trace.shape[0] != stark.num_columns or n & (n - 1):
+        raise SbnError(-1, "trace shape does not match the table")
+    h = C.c_void_p()
+    _check(lib().sbn_prove(C.byref(stark._d), C.byref(config._c), _ptr(trace), n.bit_length() - 1, _ptr(pi), len(pi), C.byref(h)))
+    return _take_proof(h)
+
+
+def verify_stark_proof(stark, proof, config):
+    """starky `verify_stark_proof(stark, proof, &config)`; raises SbnError when rejected."""
+    b = proof.to_bytes() if isinstance(proof, Proof) else bytes(proof)
+    buf = (C.c_uint8 * len(b)).from_buffer_copy(b)
+    _check(lib().sbn_verify(C.byref(stark._d), C.byref(config._c), buf, len(b)))
+
+
+def commit_values(cols, rate_bits=1, cap_height=4, want_coeffs=False, want_lde=False):
+    """PolynomialBatch::from_values on the device -> (cap, coeffs, lde)."""
+    cols = np.ascontiguousarray(cols, dtype=np.uint64)
+    ncols, n = cols.shape
+    cap = np.zeros((1 << cap_height, 4), dtype=np.uint64)
+    coeffs = np.zeros_like(cols) if want_coeffs else None
+    lde = np.zeros((ncols, n << rate_bits), dtype=np.uint64) if want_lde else None
+    _check(lib().sbn_commit_values(_ptr(cols), ncols, n, rate_bits, cap_height, _ptr(cap), _ptr(coeffs), _ptr(lde)))
+    return cap, coeffs, lde
+
+
+def poseidon_permute_batch(states):
+    s = np.ascontiguousarray(states, dtype=np.uint64).copy()
+    _check(lib().sbn_poseidon_permute_batch(_ptr(s), s.shape[0]))
+    return s

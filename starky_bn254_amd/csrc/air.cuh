@@ -1,0 +1,429 @@
+// Constraint evaluators of the reference's G1 tables, templated over the element type P so that
+// the SAME code runs on the device over the base field (quotient evaluation, one thread per LDE
+// point) and on the host over the quadratic extension (verifier at zeta) -- mirroring how the
+// reference reuses `eval_packed_generic` for both (src/curves/g1/exp.rs:331-495).
+//
+// The reference folds constraints one by one into two Horner accumulators (acc = acc*alpha + c,
+// starky ConstraintConsumer).  That is polynomial evaluation in alpha, so any exact regrouping gives
+// the same field element.  Here every gadget computes a LOCAL Horner sum h over its own constraints
+// with the filter factored out, and is merged as acc = acc*alpha^count + filter*h (alpha^k from a
+// per-proof table).  This removes one multiply per constraint, shares the sub-expressions that
+// eval_g1_add and eval_g1_double have in common (3 of 7 limb convolutions, the whole new_y block),
+// evaluates eval_flags once for its two emissions (exp.rs:462,467), and replaces the
+// 56*num_io public-input constraints (exp.rs:368-392) by 4 multiplies per instance.
+//
+// Row values are fetched through an accessor (`row.l(c)` local, `row.n(c)` next): on the device it
+// reads the column-major LDE matrix directly (lanes = consecutive LDE points => coalesced), so the
+// limb convolutions need no per-thread arrays -- operands stream from L1/L2.
+#pragma once
+#include "gl.cuh"
+
+static constexpr int SBN_NCH = 2;              // StarkConfig.num_challenges (standard_fast_config)
+static constexpr int APOW_MAX = 7169;          // alpha^k table length (k <= 56*128)
+static constexpr int G1EXP_MAX_IO = 128;
+
+// BN254 base-field modulus in 16-bit limbs (src/modular/modular.rs:298-309).
+GL_HD u64 bn254_modulus_limb(int j) {
+  constexpr u64 M[16] = {0xfd47, 0xd87c, 0x8c16, 0x3c20, 0xca8d, 0x6871, 0x6a91, 0x9781,
+                         0x585d, 0x8181, 0x45b6, 0xb850, 0xa029, 0xe131, 0x4e72, 0x3064};
+  return M[j];
+}
+
+template <class P>
+struct Cons {
+  P alpha[SBN_NCH];
+  P acc[SBN_NCH];
+  const P* apow[SBN_NCH];  // apow[j][k] = alpha_j^k, k < APOW_MAX
+  P z_last, l_first, l_last;
+  GL_HD void c(P x) {
+#pragma unroll
+    for (int j = 0; j < SBN_NCH; j++) acc[j] = acc[j] * alpha[j] + x;
+  }
+  GL_HD void ct(P x) { c(x * z_last); }
+  GL_HD void cf(P x) { c(x * l_first); }
+  GL_HD void cl(P x) { c(x * l_last); }
+  // acc = acc*alpha^count + filter*h
+  GL_HD void merge(const P* h, P filter, int count) {
+#pragma unroll
+    for (int j = 0; j < SBN_NCH; j++) acc[j] = acc[j] * apow[j][count] + filter * h[j];
+  }
+};
+
+template <class P>
+struct Horner2 {  // local two-challenge Horner sum
+  P h[SBN_NCH];
+  GL_HD void push(const Cons<P>& cs, P x) {
+#pragma unroll
+    for (int j = 0; j < SBN_NCH; j++) h[j] = h[j] * cs.alpha[j] + x;
+  }
+  GL_HD void shift(const Cons<P>& cs, int k) {
+#pragma unroll
+    for (int j = 0; j < SBN_NCH; j++) h[j] = h[j] * cs.apow[j][k];
+  }
+};
+
+// ---- G1 add/double gadget columns (src/curves/g1/muladd.rs:79-94) -----------
+namespace g1c {
+static constexpr int AX = 0, AY = 16, BX = 32, BY = 48, GB = 64;
+static constexpr int LAM = GB + 0, NX = GB + 16, NY = GB + 32;
+static constexpr int Z_QA = GB + 48, Z_LO = GB + 65, Z_HI = GB + 96;
+static constexpr int X_OAR = GB + 127, X_QA = GB + 143, X_LO = GB + 160, X_HI = GB + 191;
+static constexpr int Y_OAR = GB + 222, Y_QA = GB + 238, Y_LO = GB + 255, Y_HI = GB + 286;
+static constexpr int SGN_Z = GB + 317, SGN_X = GB + 318, SGN_Y = GB + 319;
+static constexpr int END = GB + 320;  // 384
+}  // namespace g1c
+
+// eval_packed_generic_addcy (src/modular/addcy.rs:16-58) for `modulus + out_aux_red = output + 2^256`,
+// followed by the quot_sign^2 = 1 constraint (modular.rs:123): 34 constraints, filter factored out.
+template <class P, class Row>
+GL_HD void modop_prefix(const Cons<P>& cs, const Row& row, int oar_col, int out_col, int sign_col, Horner2<P>& h) {
+  const P overflow = lift<P>(65536), overflow_inv = lift<P>(18446462594437939201ULL), one = lift<P>(1);
+  P cy = lift<P>(0);
+  for (int i = 0; i < 16; i++) {
+    P t = cy + lift<P>(bn254_modulus_limb(i)) + row.l(oar_col + i) - row.l(out_col + i);
+    h.push(cs, t * (overflow - t));
+    cy = t * overflow_inv;
+  }
+  h.push(cs, lift<P>(0));  // given_cy[0]*(given_cy[0]-1) with given_cy[0] = 1
+  h.push(cs, cy - one);    // cy == given_cy[0]
+  h.shift(cs, 15);         // given_cy[1..16] = 0
+  P s = row.l(sign_col);
+  h.push(cs, s * s - one);
+}
+
+// Both eval_g1_add (muladd.rs:179-230) and eval_g1_double (:291-342) on the same row.
+// h_add / h_dbl receive the 165-constraint local Horner sums (filters NOT applied).
+template <class P, class Row>
+GL_HD void g1_gadget(const Cons<P>& cs, const Row& row, P* h_add, P* h_dbl) {
+  using namespace g1c;
+  const P one = lift<P>(1), base = lift<P>(65536), off = lift<P>(1ULL << 29);
+  const P two = lift<P>(2), three = lift<P>(3);
+  // modular_zero prefix: quot_sign_zero^2 - 1   (modular_zero.rs:91)
+  Horner2<P> hza, hzd, hxa, hxd, hy;
+  P sz = row.l(SGN_Z), sx = row.l(SGN_X), sy = row.l(SGN_Y);
+#pragma unroll
+  for (int j = 0; j < SBN_NCH; j++) { hza.h[j] = sz * sz - one; hxa.h[j] = lift<P>(0); hy.h[j] = lift<P>(0); }
+  modop_prefix(cs, row, X_OAR, NX, SGN_X, hxa);
+  modop_prefix(cs, row, Y_OAR, NY, SGN_Y, hy);
+  hzd = hza; hxd = hxa;
+  P pz = lift<P>(0), px = lift<P>(0), py = lift<P>(0);  // previous aux coefficient of each gadget
+  for (int k = 0; k < 32; k++) {
+    // limb convolutions, coefficient k (pol_mul_wide, pol_utils.rs:221)
+    P c1 = lift<P>(0), c2 = c1, c3 = c1, c4 = c1, c5 = c1;
+    if (k < 31) {
+      int i0 = k > 15 ? k - 15 : 0, i1 = k < 15 ? k : 15;
+      for (int i = i0; i <= i1; i++) {
+        int j = k - i;
+        P li = row.l(LAM + i), axj = row.l(AX + j);
+        c1 += li * (row.l(BX + j) - axj);
+        c2 += li * row.l(AY + j);
+        c3 += row.l(AX + i) * axj;
+        c4 += li * row.l(LAM + j);
+        c5 += li * (axj - row.l(NX + j));
+      }
+    }
+    // quot(x) * modulus(x), coefficient k (pol_mul_wide2, pol_utils.rs:274); quot = sign*quot_abs
+    P qz = lift<P>(0), qx = qz, qy = qz;
+    {
+      int i0 = k > 15 ? k - 15 : 0, i1 = k < 16 ? k : 16;
+      for (int i = i0; i <= i1; i++) {
+        P m = lift<P>(bn254_modulus_limb(k - i));
+        qz += row.l(Z_QA + i) * m;
+        qx += row.l(X_QA + i) * m;
+        qy += row.l(Y_QA + i) * m;
+      }
+    }
+    // (x - beta) * aux(x), coefficient k (pol_adjoin_root, pol_utils.rs:348); aux_31 = 0
+    P az = lift<P>(0), ax_ = az, ay_ = az;
+    if (k < 31) {
+      az = row.l(Z_LO + k) - off + base * row.l(Z_HI + k);
+      ax_ = row.l(X_LO + k) - off + base * row.l(X_HI + k);
+      ay_ = row.l(Y_LO + k) - off + base * row.l(Y_HI + k);
+    }
+    P adjz = pz - base * az, adjx = px - base * ax_, adjy = py - base * ay_;
+    pz = az; px = ax_; py = ay_;
+    P zk = sz * qz + adjz;
+    P xk = sx * qx + adjx;
+    P yk = sy * qy + adjy - c5;
+    P za = zk - c1, zd = zk - (two * c2 - three * c3);
+    P xa = xk - c4, xd = xa;
+    if (k < 16) {
+      P axk = row.l(AX + k), ayk = row.l(AY + k), bxk = row.l(BX + k), nxk = row.l(NX + k);
+      za = za + (row.l(BY + k) - ayk);  // zero_pol = lambda*dx - dy
+      xa = xa + nxk + (axk + bxk);      // input = lambda^2 - (x1 + x2)
+      xd = xd + nxk + (axk + axk);
+      yk = yk + row.l(NY + k) + ayk;    // input = lambda*(x1 - new_x) - y1
+    }
+    hza.push(cs, za); hzd.push(cs, zd);
+    hxa.push(cs, xa); hxd.push(cs, xd);
+    hy.push(cs, yk);
+  }
+#pragma unroll
+  for (int j = 0; j < SBN_NCH; j++) {
+    P a132 = cs.apow[j][132], a66 = cs.apow[j][66];
+    h_add[j] = hza.h[j] * a132 + hxa.h[j] * a66 + hy.h[j];
+    h_dbl[j] = hzd.h[j] * a132 + hxd.h[j] * a66 + hy.h[j];
+  }
+}
+static constexpr int G1_GADGET_CONSTRAINTS = 165;
+
+// eval_flags (src/utils/flags.rs:136-195): 26 constraints, emitted into a local sum.
+template <class P, class Row>
+GL_HD void flags_block(const Cons<P>& cs, const Row& row, int s, Horner2<P>& h) {
+  const P one = lift<P>(1);
+  const int fin = s, rot = s + 1, a = s + 2, b = s + 3, fb = s + 4, bitc = s + 5, sl = s + 6, el = sl + 8;
+  P la = row.l(a), lb = row.l(b), bit = row.l(bitc), lrot = row.l(rot), lfin = row.l(fin);
+  h.push(cs, la * cs.l_first);
+  h.push(cs, (lb - one) * cs.l_first);
+  h.push(cs, bit * bit - bit);
+  h.push(cs, bit * lb - row.l(fb));
+  h.push(cs, lrot * la);
+  h.push(cs, lfin * lrot);
+  h.push(cs, (la + row.n(a) - one) * cs.z_last);
+  h.push(cs, (lb + row.n(b) - one) * cs.z_last);
+  P first_limb = row.l(sl), next_first_limb = row.n(sl), next_bit = row.n(bitc);
+  P is_not_final = one - lfin, is_not_split = one - la;
+  P nrf = one - lrot - lfin;
+  h.push(cs, is_not_final * la * (first_limb - (next_first_limb + next_first_limb) - next_bit) * cs.z_last);
+  h.push(cs, is_not_split * (next_bit - bit) * cs.z_last);
+  h.push(cs, nrf * is_not_split * (first_limb - next_first_limb) * cs.z_last);
+  for (int c = sl + 1; c < el; c++) h.push(cs, lrot * (row.n(c - 1) - row.l(c)) * cs.z_last);
+  h.push(cs, lrot * row.n(el - 1) * cs.z_last);
+  for (int c = sl + 1; c < el; c++) h.push(cs, nrf * (row.n(c) - row.l(c)) * cs.z_last);
+}
+static constexpr int FLAGS_CONSTRAINTS = 26;
+
+// eval_lookups (src/utils/lookup.rs:13-34).
+template <class P, class Row>
+GL_HD void lookup_pair(Cons<P>& cs, const Row& row, int col_in, int col_tab) {
+  P nin = row.n(col_in);
+  P d_table = nin - row.n(col_tab);
+  cs.c((nin - row.l(col_in)) * d_table);
+  cs.cl(d_table);
+}
+template <class P, class Row>
+GL_HD void range_table_block(Cons<P>& cs, const Row& row, int table_col, u64 range_max_minus_1) {
+  P cur = row.l(table_col), incr = row.n(table_col) - cur;
+  cs.cf(cur);
+  cs.ct(incr * incr - incr);
+  cs.cl(cur - lift<P>(range_max_minus_1));
+}
+
+// ---- G1Stark (src/curves/g1/muladd.rs:462-624) --------------------------------------------------
+struct G1OpShape {
+  static constexpr int MAIN_COLS = 24 * 16 + 2;                 // 386
+  static constexpr int START_RC = 64, NUM_RC = 20 * 16 - 4;     // 316 targets
+  static constexpr int NUM_COLS = MAIN_COLS + 1 + 6 * NUM_RC;   // 2283
+  static constexpr int NUM_PAIRS = 4 * NUM_RC;                  // 1264
+  static constexpr int NUM_CONSTRAINTS = NUM_RC + 4 * NUM_RC + 3 + 2 * 165;
+  // split_u16_range_check_pairs (range_check.rs:228-246)
+  GL_HD static void pair(int z, int& lhs, int& rhs) {
+    int t = z >> 2, w = z & 3, i = MAIN_COLS + 1 + 6 * t;
+    if (w == 0) { lhs = MAIN_COLS; rhs = i + 2; }
+    else if (w == 1) { lhs = MAIN_COLS; rhs = i + 5; }
+    else if (w == 2) { lhs = i; rhs = i + 1; }
+    else { lhs = i + 3; rhs = i + 4; }
+  }
+};
+template <class P, class Row>
+GL_HD void g1op_eval(Cons<P>& cs, const Row& row) {
+  typedef G1OpShape S;
+  // eval_split_u16_range_check (range_check.rs:162-192)
+  const P c256 = lift<P>(256);
+  for (int i = 0; i < S::NUM_RC; i++) {
+    P lo = row.l(S::MAIN_COLS + 1 + 6 * i), hi = row.l(S::MAIN_COLS + 4 + 6 * i);
+    cs.c(row.l(S::START_RC + i) - (lo + hi * c256));
+  }
+  for (int i = S::MAIN_COLS + 1; i < S::MAIN_COLS + 1 + 6 * S::NUM_RC; i += 6) {
+    lookup_pair(cs, row, i + 1, i + 2);
+    lookup_pair(cs, row, i + 4, i + 5);
+  }
+  range_table_block(cs, row, S::MAIN_COLS, 255);
+  P h_add[SBN_NCH], h_dbl[SBN_NCH];
+  g1_gadget(cs, row, h_add, h_dbl);
+  cs.merge(h_add, row.l(S::MAIN_COLS - 2), G1_GADGET_CONSTRAINTS);  // is_add
+  cs.merge(h_dbl, row.l(S::MAIN_COLS - 1), G1_GADGET_CONSTRAINTS);  // is_double
+}
+
+// ---- G1ExpStark (src/curves/g1/exp.rs) ------------------------------------------------------------
+struct G1ExpShape {  // constants(num_io), exp.rs:6-34
+  int num_io, start_flags, num_main, start_periodic, start_io_pulses, start_lookups, num_rc, num_cols, num_pi;
+  GL_HD explicit G1ExpShape(int n) {
+    num_io = n; start_flags = 24 * 16; num_main = start_flags + 14; start_periodic = num_main;
+    start_io_pulses = start_periodic + 2; start_lookups = start_io_pulses + 1 + 4 * n;
+    num_rc = 24 * 16 - 3; num_cols = start_lookups + 1 + 2 * num_rc; num_pi = 56 * n;
+  }
+  GL_HD int num_pairs() const { return 2 * num_rc; }
+  GL_HD int num_constraints() const { return 1 + num_pi + 192 + 26 + 165 + 165 + 26 + 5 + 2 + 4 * num_io + 2 * num_rc + 3; }
+  // u16_range_check_pairs (range_check.rs:96-113)
+  GL_HD void pair(int z, int& lhs, int& rhs) const {
+    if (z & 1) { lhs = z >> 1; rhs = start_lookups + z; }
+    else { lhs = start_lookups; rhs = start_lookups + 2 + z; }
+  }
+  GL_HD int witness_col(int i) const { return start_io_pulses + 1 + 2 * i; }  // pulse.rs:14
+  GL_HD int pulse_col(int i) const { return start_io_pulses + 2 + 2 * i; }    // pulse.rs:10
+};
+
+// Per-proof constants of the regrouped public-input block: for challenge j and instance i,
+//   W = alpha_j^(56*(num_io-1-i)), WA = W * sum_{m in IN} alpha_j^(55-m) pi[i][..], WO likewise for OUT.
+template <class P>
+struct G1ExpPiConsts {
+  P W[SBN_NCH][G1EXP_MAX_IO], WA[SBN_NCH][G1EXP_MAX_IO], WO[SBN_NCH][G1EXP_MAX_IO];
+};
+// Emission slot m (0..55) of one instance's vec_equal calls (exp.rs:381-391) -> public-input index
+// inside the instance's 56 values (g1_exp_io_to_columns order, exp.rs:124-135).
+GL_HD int g1exp_pi_index(int m) { return m < 32 ? m : (m < 48 ? 40 + (m - 32) : 32 + (m - 48)); }
+GL_HD bool g1exp_slot_is_out(int m) { return m >= 32 && m < 48; }
+
+template <class P>
+static inline void g1exp_pi_consts(const G1ExpShape& sh, const P* const apow[SBN_NCH], const P* pi, G1ExpPiConsts<P>& out) {
+  for (int j = 0; j < SBN_NCH; j++)
+    for (int i = 0; i < sh.num_io; i++) {
+      P a = lift<P>(0), o = lift<P>(0);
+      for (int m = 0; m < 56; m++) {
+        P t = apow[j][55 - m] * pi[56 * i + g1exp_pi_index(m)];
+        if (g1exp_slot_is_out(m)) o = o + t; else a = a + t;
+      }
+      P w = apow[j][56 * (sh.num_io - 1 - i)];
+      out.W[j][i] = w; out.WA[j][i] = w * a; out.WO[j][i] = w * o;
+    }
+}
+
+template <class P, class Row>
+GL_HD void g1exp_eval(Cons<P>& cs, const Row& row, const G1ExpShape& sh, const G1ExpPiConsts<P>* pic) {
+  using namespace g1c;
+  const P one = lift<P>(1), base = lift<P>(65536);
+  const int sf = sh.start_flags;
+  P is_final = row.l(sf), is_double = row.l(sf + 2), is_add = row.l(sf + 4);
+  P is_not_final = one - is_final;
+  // [1] is_final - sum(output pulses)                                         exp.rs:359-365
+  // [2] public-input binding, regrouped                                       exp.rs:368-392
+  {
+    P vin[SBN_NCH], vout[SBN_NCH];
+#pragma unroll
+    for (int j = 0; j < SBN_NCH; j++) { vin[j] = lift<P>(0); vout[j] = lift<P>(0); }
+    for (int m = 0; m < 56; m++) {
+      P v;
+      if (m < 48) {
+        int grp = m >> 3, k = m & 7;  // 0:a_x 1:a_y 2:b_x 3:b_y (input pulse) 4:b_x 5:b_y (output pulse)
+        int col = grp == 0 ? AX : grp == 1 ? AY : (grp == 2 || grp == 4) ? BX : BY;
+        v = row.l(col + 2 * k) + base * row.l(col + 2 * k + 1);  // u16_columns_to_u32_columns, utils.rs:56
+      } else {
+        int k = m - 48;
+        v = row.l(sf + 6 + k);
+        if (k == 0) v = v + v + is_add;  // limbs[0]*2 + bit  (exp.rs:389)
+      }
+#pragma unroll
+      for (int j = 0; j < SBN_NCH; j++) {
+        P t = cs.apow[j][55 - m] * v;
+        if (g1exp_slot_is_out(m)) vout[j] = vout[j] + t; else vin[j] = vin[j] + t;
+      }
+    }
+    P sum_out = lift<P>(0);
+    P s_in_wa[SBN_NCH], s_in_w[SBN_NCH], s_out_wo[SBN_NCH], s_out_w[SBN_NCH];
+#pragma unroll
+    for (int j = 0; j < SBN_NCH; j++) { s_in_wa[j] = s_in_w[j] = s_out_wo[j] = s_out_w[j] = lift<P>(0); }
+    for (int i = 0; i < sh.num_io; i++) {
+      P pin = row.l(sh.pulse_col(2 * i)), pout = row.l(sh.pulse_col(2 * i + 1));
+      sum_out = sum_out + pout;
+#pragma unroll
+      for (int j = 0; j < SBN_NCH; j++) {
+        s_in_wa[j] += pin * pic->WA[j][i];
+        s_in_w[j] += pin * pic->W[j][i];
+        s_out_wo[j] += pout * pic->WO[j][i];
+        s_out_w[j] += pout * pic->W[j][i];
+      }
+    }
+    cs.c(is_final - sum_out);
+#pragma unroll
+    for (int j = 0; j < SBN_NCH; j++) {
+      P b = s_in_wa[j] - vin[j] * s_in_w[j] + s_out_wo[j] - vout[j] * s_out_w[j];
+      cs.acc[j] = cs.acc[j] * cs.apow[j][sh.num_pi] + b;
+    }
+  }
+  // [3] state transitions (fq_equal_transition x12)                             exp.rs:395-461
+  {
+    Horner2<P> d_na_a, d_nb_b, d_na_new, d_nb_new;  // 32-term sums: (next_a - a), (next_b - b), (next_a - new), (next_b - new)
+#pragma unroll
+    for (int j = 0; j < SBN_NCH; j++) d_na_a.h[j] = d_nb_b.h[j] = d_na_new.h[j] = d_nb_new.h[j] = lift<P>(0);
+    for (int k = 0; k < 32; k++) {
+      P na = row.n(AX + k), nb = row.n(BX + k), nw = row.l(NX + k);  // AX..AY and NX..NY are contiguous
+      d_na_a.push(cs, na - row.l(AX + k));
+      d_nb_b.push(cs, nb - row.l(BX + k));
+      d_na_new.push(cs, na - nw);
+      d_nb_new.push(cs, nb - nw);
+    }
+    P hd[SBN_NCH], ha[SBN_NCH], hn[SBN_NCH];
+#pragma unroll
+    for (int j = 0; j < SBN_NCH; j++) {
+      P a32 = cs.apow[j][32];
+      hd[j] = d_na_new.h[j] * a32 + d_nb_b.h[j];
+      ha[j] = d_na_a.h[j] * a32 + d_nb_new.h[j];
+      hn[j] = d_na_a.h[j] * a32 + d_nb_b.h[j];
+    }
+    P zl = cs.z_last * is_not_final;
+    cs.merge(hd, zl * is_double, 64);
+    cs.merge(ha, zl * is_add, 64);
+    cs.merge(hn, zl * (one - is_double - is_add), 64);
+  }
+  // [4] eval_flags, [5] eval_g1_add, [6] eval_g1_double, [7] eval_flags again   exp.rs:462-472
+  Horner2<P> hf;
+#pragma unroll
+  for (int j = 0; j < SBN_NCH; j++) hf.h[j] = lift<P>(0);
+  flags_block(cs, row, sf, hf);
+  cs.merge(hf.h, one, FLAGS_CONSTRAINTS);
+  {
+    P h_add[SBN_NCH], h_dbl[SBN_NCH];
+    g1_gadget(cs, row, h_add, h_dbl);
+    cs.merge(h_add, is_add, G1_GADGET_CONSTRAINTS);
+    cs.merge(h_dbl, is_double, G1_GADGET_CONSTRAINTS);
+  }
+  cs.merge(hf.h, one, FLAGS_CONSTRAINTS);
+  // [8] eval_periodic_pulse(pulse_col = is_rotate, period 64, first_pulse 62)   exp.rs:473-481, pulse.rs:146-170
+  {
+    const int st = sh.start_periodic;
+    P counter = row.l(st), witness = row.l(st + 1), is_reset = row.l(sf + 1), next_counter = row.n(st);
+    cs.cf(counter - lift<P>(1));  // period - first_pulse - 1 = 1
+    cs.ct((one - is_reset) * (next_counter - counter - one));
+    cs.ct(is_reset * next_counter);
+    P delta = counter - lift<P>(63);
+    cs.c(delta * witness + is_reset - one);
+    cs.c(delta * is_reset);
+  }
+  // [9] eval_pulse over 2*num_io positions                                      exp.rs:482-488, pulse.rs:45-63
+  {
+    const int st = sh.start_io_pulses;
+    P counter = row.l(st);
+    cs.cf(counter);
+    cs.ct(row.n(st) - counter - one);
+    for (int i = 0; i < 2 * sh.num_io; i++) {
+      u64 pos = (u64)(i >> 1) * 512 + ((i & 1) ? 511 : 0);  // get_pulse_positions, exp.rs:153-163
+      P cmp = counter - lift<P>(pos);
+      P pulse = row.l(sh.pulse_col(i));
+      cs.c(cmp * row.l(sh.witness_col(i)) + pulse - one);
+      cs.c(cmp * pulse);
+    }
+  }
+  // [10] eval_u16_range_check                                                   exp.rs:489-494, range_check.rs:49-68
+  for (int k = 0; k < sh.num_rc; k++) lookup_pair(cs, row, sh.start_lookups + 1 + 2 * k, sh.start_lookups + 2 + 2 * k);
+  range_table_block(cs, row, sh.start_lookups, 65535);
+}
+
+// starky permutation.rs `eval_permutation_checks` for singleton pairs with batch size 2:
+// Z index z <-> pair z; instance 0 uses challenge_sets[0].challenges[0].gamma, instance 1 uses
+// challenge_sets[1].challenges[1].gamma.  ZRow: zl(z) / zn(z) = local / next Z values.
+template <class P, class Row, class ZRow, class Shape>
+GL_HD void permutation_checks(Cons<P>& cs, const Row& row, const ZRow& zrow, const Shape& sh, int num_zs, P gamma0, P gamma1) {
+  const P one = lift<P>(1);
+  Horner2<P> h;
+#pragma unroll
+  for (int j = 0; j < SBN_NCH; j++) h.h[j] = lift<P>(0);
+  for (int z = 0; z < num_zs; z++) h.push(cs, zrow.zl(z) - one);
+  cs.merge(h.h, cs.l_first, num_zs);
+  for (int z = 0; z < num_zs; z++) {
+    int lc, rc;
+    sh.pair(z, lc, rc);
+    P l = row.l(lc), r = row.l(rc);
+    cs.c(zrow.zn(z) * ((r + gamma0) * (r + gamma1)) - zrow.zl(z) * ((l + gamma0) * (l + gamma1)));
+  }
+}

@@ -1,0 +1,89 @@
+// Host-side pieces shared by the prover and verifier: error reporting, the Fiat-Shamir transcript
+// (plonky2 iop/challenger.rs `Challenger`, duplex/overwrite mode), FRI parameters
+// (fri/reduction_strategies.rs ConstantArityBits) and the table shapes.
+#pragma once
+#include "../../include/sbn.h"
+#include "poseidon.cuh"
+#include "air.cuh"
+#include <string>
+#include <vector>
+#include <cstdarg>
+#include <cstdio>
+
+namespace sbn {
+
+extern thread_local std::string g_last_error;
+static inline int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+  g_last_error = buf;
+  return code;
+}
+
+static constexpr u64 PROOF_MAGIC = 0x31564f5250424e53ULL;  // "SNBPROV1"
+
+struct Challenger {
+  F st[12];
+  std::vector<F> in, out;
+  Challenger() { for (auto& x : st) x = F(0); }
+  void duplex() {
+    for (size_t i = 0; i < in.size(); i++) st[i] = in[i];
+    in.clear();
+    poseidon_permute(st);
+    out.assign(st, st + P_RATE);
+  }
+  void observe(F e) { out.clear(); in.push_back(e); if (in.size() == (size_t)P_RATE) duplex(); }
+  void observe(E2 e) { observe(e.a); observe(e.b); }
+  void observe_words(const u64* w, size_t n) { for (size_t i = 0; i < n; i++) observe(F(w[i])); }
+  F challenge() {
+    if (!in.empty() || out.empty()) duplex();
+    F r = out.back(); out.pop_back(); return r;
+  }
+  E2 ext_challenge() { F a = challenge(); F b = challenge(); return E2(a, b); }
+};
+
+struct FriShape {
+  std::vector<u32> arity_bits;  // per reduction layer
+  u32 degree_bits, rate_bits, cap_height;
+  u32 lde_bits() const { return degree_bits + rate_bits; }
+  u32 total_arity() const { u32 s = 0; for (auto a : arity_bits) s += a; return s; }
+  size_t final_poly_len() const { return (size_t)1 << (degree_bits - total_arity()); }
+};
+static inline FriShape fri_shape(const sbn_config& c, u32 degree_bits) {
+  FriShape f; f.degree_bits = degree_bits; f.rate_bits = c.rate_bits; f.cap_height = c.cap_height;
+  u32 d = degree_bits;
+  while (d > c.fri_final_poly_bits && d + c.rate_bits - c.fri_arity_bits >= c.cap_height) { f.arity_bits.push_back(c.fri_arity_bits); d -= c.fri_arity_bits; }
+  return f;
+}
+
+struct AirShape {
+  int kind; u32 num_io;
+  size_t ncols, npi, npairs, nzs, nconstraints;
+};
+static inline bool air_shape(const sbn_air_desc* air, const sbn_config* cfg, AirShape& s) {
+  if (!air) return false;
+  s.kind = air->kind; s.num_io = air->num_io;
+  u32 nch = cfg ? cfg->num_challenges : 2;
+  if (air->kind == SBN_AIR_G1_OP) {
+    s.ncols = G1OpShape::NUM_COLS; s.npi = 0; s.npairs = G1OpShape::NUM_PAIRS; s.nconstraints = G1OpShape::NUM_CONSTRAINTS;
+  } else if (air->kind == SBN_AIR_G1_EXP) {
+    if (air->num_io == 0 || air->num_io > (u32)G1EXP_MAX_IO) return false;
+    G1ExpShape sh((int)air->num_io);
+    s.ncols = sh.num_cols; s.npi = sh.num_pi; s.npairs = sh.num_pairs(); s.nconstraints = sh.num_constraints();
+  } else return false;
+  // num_permutation_batches = ceil(pairs*num_challenges / (constraint_degree-1)), constraint_degree = 3
+  s.nzs = (s.npairs * nch + 1) / 2;
+  return true;
+}
+static inline bool config_supported(const sbn_config* c) {
+  return c && c->num_challenges == SBN_NCH && c->rate_bits == 1 && c->cap_height >= 1 && c->cap_height <= 8 &&
+         c->fri_arity_bits >= 1 && c->fri_arity_bits <= 4 && c->num_query_rounds >= 1 && c->num_query_rounds <= 512 &&
+         c->proof_of_work_bits <= 32;
+}
+
+}  // namespace sbn
+
+struct sbn_proof {
+  std::vector<u64> words;
+  u32 degree_bits;
+};

@@ -1,0 +1,491 @@
+// HIP kernels of the prover path (gfx950).  One header, included once by prover.hip.
+// Each kernel states the reference stage it replaces, its access
+// pattern and its algorithmic bytes.  All matrices are COLUMN-MAJOR [col][row] u64; LDE matrices
+// are kept in NATURAL row order (row i = evaluation at 7*w^i); Merkle leaf index = bitrev(row).
+#pragma once
+#include "poseidon.cuh"
+#include "air.cuh"
+
+// =================================================================================================
+// K1  batched NTT pass  (replaces plonky2_field fft.rs / PolynomialValues::ifft / coset_fft; P1,P2,P3,P5)
+// An n-point transform per column is n = R*S: pass A does R-point NTTs along the stride-S axis for a
+// tile of T consecutive inner indices, multiplies by the inter-pass twiddles and stores in place
+// layout; pass B does the S-point NTTs along the contiguous axis and stores transposed.  Both passes
+// stage an [R][T] tile through LDS (radix-2 DIF, bit-reversed on store), so every global access is a
+// run of T*8 = 128 contiguous bytes per row of the tile.
+// Algorithmic bytes per pass: 8*n read + 8*n written per column (zero-padded inputs read n_in).
+// =================================================================================================
+struct NttPassParams {
+  const u64* in; u64* out;
+  size_t in_col_stride, out_col_stride;  // elements between columns
+  u32 log_r;        // log2 of NTT length in this pass
+  u32 log_t;        // log2 of tile width
+  u32 log_n;        // log2 of the full transform length
+  size_t in_sr, in_st, out_sr, out_st;   // element strides of (r, t) in input / output
+  size_t n_in;      // input indices >= n_in read as zero (zero-padded LDE)
+  u32 r_fast_load;  // 1: r is the contiguous input axis (pass B)
+  u32 twiddle;      // 1: multiply output (k, t) by w_n^(k*t_global) (pass A)
+  const u64* tw;    // root powers w_M^e, e < M/2, of the table's size M = 2^tw_log (inverse table for iNTT)
+  u32 tw_log;
+  const u64* pre;   // optional per-index input scale (coset shift powers), indexed by input index
+  const u64* post;  // optional per-index output scale, indexed by output index
+  u64 scale;        // scalar output scale (1/n for inverse); 1 = none
+};
+
+GL_HD F tw_lookup(const u64* tw, u32 tw_log, u64 e_of_order, u32 order_log) {
+  // returns w_{2^order_log}^e using the half table of w_{2^tw_log}
+  u64 idx = (e_of_order << (tw_log - order_log)) & ((1ULL << tw_log) - 1);
+  u64 half = 1ULL << (tw_log - 1);
+  if (idx >= half) return -F(tw[idx - half]);
+  return F(tw[idx]);
+}
+
+static constexpr int NTT_THREADS = 256;
+
+__global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassParams p) {
+  extern __shared__ u64 lds[];
+  const u32 R = 1u << p.log_r, T = 1u << p.log_t;
+  const u32 LDT = T + 1;  // padded row
+  const size_t col = blockIdx.y;
+  const size_t t0 = (size_t)blockIdx.x << p.log_t;
+  const u64* in = p.in + col * p.in_col_stride;
+  u64* out = p.out + col * p.out_col_stride;
+  const u32 total = R << p.log_t;
+  // ---- load tile
+  for (u32 e = threadIdx.x; e < total; e += NTT_THREADS) {
+    u32 r, t;
+    if (p.r_fast_load) { r = e & (R - 1); t = e >> p.log_r; } else { t = e & (T - 1); r = e >> p.log_t; }
+    size_t gi = (size_t)r * p.in_sr + (t0 + t) * p.in_st;
+    u64 v = 0;
+    if (gi < p.n_in) {
+      v = in[gi];
+      if (p.pre) v = (F(v) * F(p.pre[gi])).v;
+    }
+    lds[r * LDT + t] = v;
+  }
+  __syncthreads();
+  // ---- radix-2 DIF along r
+  for (u32 s = 0; s < p.log_r; s++) {
+    u32 half = R >> (s + 1);
+    u32 nb = total >> 1;
+    for (u32 e = threadIdx.x; e < nb; e += NTT_THREADS) {
+      u32 t = e & (T - 1), b = e >> p.log_t;
+      u32 j = b & (half - 1), blk = b / half;
+      u32 i0 = blk * 2 * half + j, i1 = i0 + half;
+      F u{lds[i0 * LDT + t]}, v(lds[i1 * LDT + t]);
+      F w = tw_lookup(p.tw, p.tw_log, (u64)j << s, p.log_r);
+      lds[i0 * LDT + t] = (u + v).v;
+      lds[i1 * LDT + t] = ((u - v) * w).v;
+    }
+    __syncthreads();
+  }
+  // ---- store (LDS row q holds frequency bitrev(q))
+  for (u32 e = threadIdx.x; e < total; e += NTT_THREADS) {
+    u32 t = e & (T - 1), k = e >> p.log_t;
+    u32 q = bitrev32(k, p.log_r);
+    F v{lds[q * LDT + t]};
+    if (p.twiddle) v = v * tw_lookup(p.tw, p.tw_log, (u64)k * (t0 + t), p.log_n);
+    if (p.scale != 1) v = v * F(p.scale);
+    size_t go = (size_t)k * p.out_sr + (t0 + t) * p.out_st;
+    if (p.post) v = v * F(p.post[go]);
+    out[go] = v.v;
+  }
+}
+
+// table[i] = base^i (i < n); one thread per entry (square-and-multiply), used once per prover.
+__global__ void pow_table_kernel(u64* out, size_t n, u64 base) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = f_pow(F(base), i).v;
+}
+// v[i] *= base^i, for the small FRI layers.
+__global__ void scale_pow_kernel(u64* v, size_t n, u64 base) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) v[i] = (F(v[i]) * f_pow(F(base), i)).v;
+}
+
+// =================================================================================================
+// K2  Poseidon leaf hashing (MerkleTree::new leaves, `hash_or_noop`; P1/P2/P3)
+// One thread per LDE row; lane l reads lde[c][row0+l] for every column c => each column read is a
+// 512-byte coalesced segment per wave.  Sponge: overwrite rate lanes with 8 columns, permute.
+// Digest stored at leaf index bitrev(row).  Algorithmic bytes: 8*M*C read + 32*M written.
+// This kernel is ALU-bound (ceil(C/8) permutations per row), not HBM-bound.
+// =================================================================================================
+__global__ __launch_bounds__(256) void leaf_hash_kernel(const u64* __restrict__ lde, size_t m, u32 lde_log, u32 ncols,
+                                                        u64* __restrict__ digests) {
+  size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= m) return;
+  F s[12];
+#pragma unroll
+  for (int i = 0; i < 12; i++) s[i] = F(0);
+  size_t leaf = bitrev32((u32)row, lde_log);
+  if (ncols <= 4) {  // hash_or_noop: digest = the elements, zero padded
+    for (u32 c = 0; c < 4; c++) digests[leaf * 4 + c] = c < ncols ? lde[(size_t)c * m + row] : 0;
+    return;
+  }
+  u32 c = 0;
+  for (; c + 8 <= ncols; c += 8) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) s[i] = F(lde[(size_t)(c + i) * m + row]);
+    poseidon_permute(s);
+  }
+  if (c < ncols) {
+#pragma unroll
+    for (u32 i = 0; i < 8; i++)
+      if (c + i < ncols) s[i] = F(lde[(size_t)(c + i) * m + row]);
+    poseidon_permute(s);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) digests[leaf * 4 + i] = s[i].v;
+}
+
+// K3  Merkle inner level: parent[i] = two_to_one(child[2i], child[2i+1]).
+__global__ __launch_bounds__(256) void merkle_level_kernel(const u64* __restrict__ child, u64* __restrict__ parent, size_t nparent) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nparent) return;
+  F s[12];
+#pragma unroll
+  for (int k = 0; k < 8; k++) s[k] = F(child[i * 8 + k]);
+#pragma unroll
+  for (int k = 8; k < 12; k++) s[k] = F(0);
+  poseidon_permute(s);
+#pragma unroll
+  for (int k = 0; k < 4; k++) parent[i * 4 + k] = s[k].v;
+}
+
+// FRI layer leaves: leaf l = the 16 extension values at bit-reversed positions 16l..16l+15 of the
+// layer's evaluation vector (planes va/vb in natural order), flattened c0,c1 (fri/prover.rs).
+__global__ __launch_bounds__(256) void fri_leaf_hash_kernel(const u64* __restrict__ va, const u64* __restrict__ vb, u32 log_m, u32 arity_bits,
+                                                            u64* __restrict__ digests) {
+  size_t leaf = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t nleaf = (size_t)1 << (log_m - arity_bits);
+  if (leaf >= nleaf) return;
+  F s[12];
+#pragma unroll
+  for (int i = 0; i < 12; i++) s[i] = F(0);
+  u32 arity = 1u << arity_bits;
+  for (u32 t = 0; t < arity; t += 4) {
+#pragma unroll
+    for (u32 u = 0; u < 4; u++) {
+      u32 nat = bitrev32((u32)(leaf * arity + t + u), log_m);
+      s[2 * u] = F(va[nat]); s[2 * u + 1] = F(vb[nat]);
+    }
+    poseidon_permute(s);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) digests[leaf * 4 + i] = s[i].v;
+}
+
+__global__ void poseidon_batch_kernel(u64* states, size_t count) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  F s[12];
+  for (int k = 0; k < 12; k++) s[k] = F(states[i * 12 + k]);
+  poseidon_permute(s);
+  for (int k = 0; k < 12; k++) states[i * 12 + k] = s[k].v;
+}
+
+// =================================================================================================
+// K4  permutation Z columns (starky permutation.rs `compute_permutation_z_poly`; P2)
+// One workgroup per Z column.  Z[i] = prod_{k<i} num_k / den_k with num = (lhs+g0)(lhs+g1),
+// den = (rhs+g0)(rhs+g1).  Computed as  prefix(num)[i] * suffix(den)[i] / prod(den): two coalesced
+// block-scan sweeps and ONE field inversion per column (exact arithmetic => identical to the
+// reference's batch-inverse + running product).  Algorithmic bytes: reads 2 trace columns twice,
+// writes/reads/writes Z once: 8*N*(4+3) per column.
+// =================================================================================================
+struct PairCols { int lhs, rhs; };
+
+__device__ __forceinline__ F wave_scan_mul(F x, int lane) {  // inclusive prefix product within a wave
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    u64 o = __shfl_up((unsigned long long)x.v, d, 64);
+    if (lane >= d) x = x * F(o);
+  }
+  return x;
+}
+
+__global__ __launch_bounds__(256) void permutation_z_kernel(const u64* __restrict__ trace, size_t n, const PairCols* __restrict__ pairs,
+                                                            u64 gamma0, u64 gamma1, u64* __restrict__ zout) {
+  __shared__ u64 wtot[4];
+  __shared__ u64 carry_s;
+  const int z = blockIdx.x;
+  const u64* lhs = trace + (size_t)pairs[z].lhs * n;
+  const u64* rhs = trace + (size_t)pairs[z].rhs * n;
+  u64* zc = zout + (size_t)z * n;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const F g0(gamma0), g1(gamma1);
+  // forward sweep: exclusive prefix product of num -> zc ; running product of den
+  F carry(1), dprod(1);
+  for (size_t base = 0; base < n; base += 256) {
+    size_t i = base + tid;
+    F l{lhs[i]}, r(rhs[i]);
+    F num = (l + g0) * (l + g1);
+    dprod = dprod * ((r + g0) * (r + g1));
+    F inc = wave_scan_mul(num, lane);
+    if (lane == 63) wtot[wv] = inc.v;
+    __syncthreads();
+    F pre = carry;
+    for (int w = 0; w < wv; w++) pre = pre * F(wtot[w]);
+    // exclusive = pre * inclusive_of_previous_lane
+    u64 prev = __shfl_up((unsigned long long)inc.v, 1, 64);
+    F excl = lane == 0 ? pre : pre * F(prev);
+    zc[i] = excl.v;
+    carry = carry * F(wtot[0]) * F(wtot[1]) * F(wtot[2]) * F(wtot[3]);
+    __syncthreads();
+  }
+  // total den product -> inverse
+  {
+    F w = dprod;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) w = w * F(__shfl_xor((unsigned long long)w.v, d, 64));
+    if (lane == 0) wtot[wv] = w.v;
+    __syncthreads();
+    if (tid == 0) carry_s = f_inv(F(wtot[0]) * F(wtot[1]) * F(wtot[2]) * F(wtot[3])).v;
+    __syncthreads();
+  }
+  // backward sweep: inclusive suffix product of den, times 1/prod(den)
+  carry = F(carry_s);
+  __syncthreads();
+  for (size_t base = n; base > 0; base -= 256) {
+    // element handled by this thread, scanning from the top: position rev = tid counts from the end
+    size_t i = base - 1 - tid;
+    F r{rhs[i]};
+    F den = (r + g0) * (r + g1);
+    F inc = wave_scan_mul(den, lane);
+    if (lane == 63) wtot[wv] = inc.v;
+    __syncthreads();
+    F pre = carry;
+    for (int w = 0; w < wv; w++) pre = pre * F(wtot[w]);
+    F suf = pre * inc;  // = Dinv * prod_{k>=i} den_k
+    zc[i] = (F(zc[i]) * suf).v;
+    carry = carry * F(wtot[0]) * F(wtot[1]) * F(wtot[2]) * F(wtot[3]);
+    __syncthreads();
+  }
+}
+
+// =================================================================================================
+// K5  constraint / quotient evaluation (starky prover.rs `compute_quotient_polys`; P3)
+// One thread per LDE point i; local row = i, next row = (i + 2^quotient_degree_bits) mod M.
+// Lanes are consecutive points, so every column access is a coalesced 512-byte wave segment and the
+// "next" access re-hits the same lines.  Output: quotient values acc_j / Z_H(x_i) for j < 2.
+// Algorithmic bytes: 8*M*(C + Zc) read once, 16*M written.
+// =================================================================================================
+struct DevRow {
+  const u64* base; size_t m; size_t i, inext;
+  __device__ __forceinline__ F l(int c) const { return F(base[(size_t)c * m + i]); }
+  __device__ __forceinline__ F n(int c) const { return F(base[(size_t)c * m + inext]); }
+};
+struct DevZRow {
+  const u64* base; size_t m; size_t i, inext;
+  __device__ __forceinline__ F zl(int z) const { return F(base[(size_t)z * m + i]); }
+  __device__ __forceinline__ F zn(int z) const { return F(base[(size_t)z * m + inext]); }
+};
+struct QuotientParams {
+  const u64* lde; const u64* zlde; size_t m; u32 next_step;
+  const u64* xs; const u64* lag_first; const u64* lag_last;  // per LDE point
+  u64 zh_inv[2];   // 1/Z_H on the two residues of i mod 2
+  u64 last;        // g^-1
+  u64 alpha[SBN_NCH];
+  const u64* apow[SBN_NCH];
+  u64 gamma0, gamma1;
+  int num_zs, num_io;
+  const void* pic;  // G1ExpPiConsts<F>*
+  u64* qout;        // [SBN_NCH][m]
+};
+
+template <int KIND>
+__global__ __launch_bounds__(256) void quotient_kernel(QuotientParams p) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p.m) return;
+  size_t inext = (i + p.next_step) & (p.m - 1);
+  Cons<F> cs;
+#pragma unroll
+  for (int j = 0; j < SBN_NCH; j++) { cs.alpha[j] = F(p.alpha[j]); cs.acc[j] = F(0); cs.apow[j] = (const F*)p.apow[j]; }
+  cs.z_last = F(p.xs[i]) - F(p.last);
+  cs.l_first = F(p.lag_first[i]);
+  cs.l_last = F(p.lag_last[i]);
+  DevRow row{p.lde, p.m, i, inext};
+  DevZRow zrow{p.zlde, p.m, i, inext};
+  if (KIND == 1) {
+    g1op_eval(cs, row);
+    permutation_checks(cs, row, zrow, G1OpShape(), p.num_zs, F(p.gamma0), F(p.gamma1));
+  } else {
+    G1ExpShape sh(p.num_io);
+    g1exp_eval(cs, row, sh, (const G1ExpPiConsts<F>*)p.pic);
+    permutation_checks(cs, row, zrow, sh, p.num_zs, F(p.gamma0), F(p.gamma1));
+  }
+  F dinv(p.zh_inv[i & 1]);
+#pragma unroll
+  for (int j = 0; j < SBN_NCH; j++) p.qout[(size_t)j * p.m + i] = (cs.acc[j] * dinv).v;
+}
+
+// Coset points and Lagrange selectors on the LDE domain (prover.rs: lagrange_first/last
+// `.lde_onto_coset`, coset = cyclic_subgroup_coset_known_order).  L_0(x) = (x^N-1)/(N(x-1)),
+// L_last(x) = (x^N-1)/(N(g x-1)); one Fermat inversion per point, run once per prover.
+__global__ void domain_tables_kernel(u64* xs, u64* lag_first, u64* lag_last, size_t m, u32 lde_log, u32 degree_bits) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  F w = f_root_of_unity(lde_log);
+  F x = F(GL_GEN) * f_pow(w, i);
+  F g = f_root_of_unity(degree_bits);
+  F nn = F((u64)1 << degree_bits);
+  F zx = f_exp_pow2(x, degree_bits) - F(1);
+  xs[i] = x.v;
+  lag_first[i] = (zx * f_inv(nn * (x - F(1)))).v;
+  lag_last[i] = (zx * f_inv(nn * (g * x - F(1)))).v;
+}
+
+// =================================================================================================
+// K6  openings (StarkOpeningSet::new; P4): out[p] = poly_p(z) over the extension, for two points.
+// Block per polynomial; threads stride the coefficients against a precomputed table z^i (two planes).
+// Algorithmic bytes: 8*N per polynomial per point (the power table stays in L2).
+// =================================================================================================
+__global__ void ext_pow_table_kernel(u64* pa, u64* pb, size_t n, u64 z0, u64 z1) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  E2 r = e2_pow(E2(F(z0), F(z1)), i);
+  pa[i] = r.a.v; pb[i] = r.b.v;
+}
+__device__ __forceinline__ F block_sum(F v, u64* sh) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v = v + F(__shfl_xor((unsigned long long)v.v, d, 64));
+  __syncthreads();
+  if (lane == 0) sh[wv] = v.v;
+  __syncthreads();
+  F t(0);
+  for (unsigned w = 0; w < blockDim.x / 64; w++) t = t + F(sh[w]);
+  return t;
+}
+// evaluates at two points at once: tables (pa0,pb0) for z and (pa1,pb1) for g*z; out: [npoly][4]
+__global__ __launch_bounds__(256) void openings_kernel(const u64* __restrict__ coeffs, size_t n, const u64* pa0, const u64* pb0,
+                                                       const u64* pa1, const u64* pb1, u64* __restrict__ out) {
+  __shared__ u64 sh[4];
+  const u64* c = coeffs + (size_t)blockIdx.x * n;
+  F a0(0), b0(0), a1(0), b1(0);
+  for (size_t i = threadIdx.x; i < n; i += blockDim.x) {
+    F v{c[i]};
+    a0 += v * F(pa0[i]); b0 += v * F(pb0[i]);
+    a1 += v * F(pa1[i]); b1 += v * F(pb1[i]);
+  }
+  a0 = block_sum(a0, sh); b0 = block_sum(b0, sh); a1 = block_sum(a1, sh); b1 = block_sum(b1, sh);
+  if (threadIdx.x == 0) {
+    u64* o = out + (size_t)blockIdx.x * 4;
+    o[0] = a0.v; o[1] = b0.v; o[2] = a1.v; o[3] = b1.v;
+  }
+}
+
+// =================================================================================================
+// K7  FRI batch combine (fri/oracle.rs `prove_openings`: alpha.reduce_polys_base; P5)
+// part[g][i] = sum_{j in group g} alpha^(j - j0_g) * f_j[i]  (Horner from the group's last poly);
+// the host-side combine multiplies by alpha^(j0_g).  Thread per coefficient index, groups on
+// blockIdx.y for parallelism.  Algorithmic bytes: 8*N per polynomial, read once.
+// =================================================================================================
+__global__ __launch_bounds__(256) void fri_combine_partial_kernel(const u64* __restrict__ coeffs, size_t n, u32 npoly, u32 group_size,
+                                                                  u64 al0, u64 al1, u64* __restrict__ part_a, u64* __restrict__ part_b) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u32 g = blockIdx.y;
+  u32 j0 = g * group_size, j1 = j0 + group_size < npoly ? j0 + group_size : npoly;
+  E2 alpha{F(al0), F(al1)}, acc(F(0), F(0));
+  for (u32 j = j1; j-- > j0;) acc = acc * alpha + F(coeffs[(size_t)j * n + i]);
+  part_a[(size_t)g * n + i] = acc.a.v; part_b[(size_t)g * n + i] = acc.b.v;
+}
+// out[i] (+)= sum_g w_g * part[g][i]   (w_g given as ext pairs)
+__global__ void fri_combine_reduce_kernel(const u64* part_a, const u64* part_b, size_t n, u32 ngroups, const u64* w, u64* out_a, u64* out_b, int accumulate) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  E2 acc = accumulate ? E2(F(out_a[i]), F(out_b[i])) : E2(F(0), F(0));
+  for (u32 g = 0; g < ngroups; g++) acc += E2(F(part_a[(size_t)g * n + i]), F(part_b[(size_t)g * n + i])) * E2(F(w[2 * g]), F(w[2 * g + 1]));
+  out_a[i] = acc.a.v; out_b[i] = acc.b.v;
+}
+
+// Synthetic division by (X - z) (PolynomialCoeffs::divide_by_linear), single workgroup:
+// B_i = c_i + z*B_{i+1}; quotient q_{i-1} = B_i, q_{n-1} = 0; then out = out*mul + q (ext).
+__global__ __launch_bounds__(256) void divide_by_linear_kernel(const u64* ca, const u64* cb, size_t n, u64 z0, u64 z1,
+                                                               u64 mul0, u64 mul1, u64* oa, u64* ob, int accumulate) {
+  __shared__ u64 ha[256], hb[256];
+  const int tid = threadIdx.x;
+  const size_t L = n / 256;
+  E2 z{F(z0), F(z1)};
+  size_t s = (size_t)tid * L;
+  E2 h{F(0), F(0)};
+  for (size_t k = L; k-- > 0;) h = h * z + E2(F(ca[s + k]), F(cb[s + k]));
+  ha[tid] = h.a.v; hb[tid] = h.b.v;
+  __syncthreads();
+  if (tid == 0) {
+    E2 zl = e2_pow(z, L);
+    E2 carry{F(0), F(0)};  // B_{(t+1)L}
+    for (int t = 255; t >= 0; t--) {
+      E2 ht{F(ha[t]), F(hb[t])};
+      ha[t] = carry.a.v; hb[t] = carry.b.v;  // carry-in for chunk t
+      carry = ht + zl * carry;
+    }
+  }
+  __syncthreads();
+  E2 b{F(ha[tid]), F(hb[tid])};
+  E2 mul{F(mul0), F(mul1)};
+  for (size_t k = L; k-- > 0;) {
+    size_t i = s + k;
+    // q_i = B_{i+1}: the value of b BEFORE absorbing c_i
+    E2 q = b;
+    b = b * z + E2(F(ca[i]), F(cb[i]));
+    E2 o = accumulate ? E2(F(oa[i]), F(ob[i])) * mul + q : q;
+    oa[i] = o.a.v; ob[i] = o.b.v;
+  }
+}
+
+// FRI fold in coefficient form (fri/prover.rs: chunks(arity).map(reduce_with_powers(chunk, beta))).
+__global__ void fri_fold_kernel(const u64* ca, const u64* cb, size_t nout, u32 arity, u64 b0, u64 b1, u64* oa, u64* ob) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nout) return;
+  E2 beta{F(b0), F(b1)}, acc(F(0), F(0));
+  for (u32 t = arity; t-- > 0;) acc = acc * beta + E2(F(ca[i * arity + t]), F(cb[i * arity + t]));
+  oa[i] = acc.a.v; ob[i] = acc.b.v;
+}
+
+// K9  proof-of-work grind (fri/prover.rs `fri_proof_of_work`): candidates base..base+count, the
+// smallest hit is kept (deterministic witness).
+struct PowParams { u64 state[12]; u32 wpos; u32 min_lz; u64 base; u64 count; u64* result; };
+__global__ __launch_bounds__(256) void pow_kernel(PowParams p) {
+  u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= p.count) return;
+  F s[12];
+#pragma unroll
+  for (int i = 0; i < 12; i++) s[i] = F(p.state[i]);
+  s[p.wpos] = F(p.base + gid);
+  poseidon_permute(s);
+  u64 resp = s[P_RATE - 1].v;
+  u32 lz = resp ? (u32)__clzll((long long)resp) : 64;
+  if (lz >= p.min_lz) atomicMin((unsigned long long*)p.result, (unsigned long long)(p.base + gid));
+}
+
+// K10 query gathers, written straight in the proof's word layout.
+// rows: out[q*qstride + off + c] = mat[c*m + bitrev(idx[q])]
+__global__ void gather_rows_kernel(const u64* mat, size_t m, u32 lde_log, u32 ncols, const u32* idx, u64* out, size_t qstride, size_t off) {
+  u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+  u32 q = blockIdx.y;
+  if (c >= ncols) return;
+  size_t row = bitrev32(idx[q], lde_log);
+  out[(size_t)q * qstride + off + c] = mat[(size_t)c * m + row];
+}
+// siblings: tree levels concatenated (level l has nleaf>>l digests); leaf index = idx[q] >> shift.
+__global__ void gather_siblings_kernel(const u64* tree, size_t nleaf, u32 nlevels, const u32* idx, u32 shift, u64* out, size_t qstride, size_t off) {
+  u32 q = blockIdx.x;
+  u32 e = threadIdx.x;
+  if (e >= nlevels * 4) return;
+  u32 l = e >> 2, k = e & 3;
+  size_t x = idx[q] >> shift;
+  size_t level_off = 2 * nleaf - ((2 * nleaf) >> l);  // sum_{k<l} nleaf>>k
+  size_t sib = (x >> l) ^ 1;
+  out[(size_t)q * qstride + off + e] = tree[(level_off + sib) * 4 + k];
+}
+// FRI layer leaf: 2*arity words (c0,c1 interleaved) of leaf (idx>>shift).
+__global__ void gather_fri_leaf_kernel(const u64* va, const u64* vb, u32 log_m, u32 arity_bits, const u32* idx, u32 shift, u64* out, size_t qstride, size_t off) {
+  u32 q = blockIdx.x;
+  u32 e = threadIdx.x;
+  u32 arity = 1u << arity_bits;
+  if (e >= 2 * arity) return;
+  size_t leaf = idx[q] >> shift;
+  u32 nat = bitrev32((u32)(leaf * arity + (e >> 1)), log_m);
+  out[(size_t)q * qstride + off + e] = (e & 1) ? vb[nat] : va[nat];
+}

@@ -1,0 +1,642 @@
+// Host orchestration of prove() on one MI355X: replaces starky prover.rs `prove` for the reference's
+// G1 tables (call sites src/curves/g1/exp.rs:818-825, src/curves/g1/muladd.rs:669-676).  The host
+// owns only the Fiat-Shamir transcript and proof assembly; every polynomial / hashing / constraint
+// stage runs in the kernels of kernels.cuh on one HIP stream.
+#include "host_common.hpp"
+#include "kernels.cuh"
+#include <algorithm>
+#include <cstring>
+#include <cstdlib>
+
+using namespace sbn;
+
+namespace sbn { thread_local std::string g_last_error; }
+
+#define HIPC(expr)                                                                                   \
+  do {                                                                                               \
+    hipError_t e_ = (expr);                                                                          \
+    if (e_ != hipSuccess) return fail(SBN_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+static int g_device = 0;
+
+enum Stage {
+  ST_TRACE_NTT, ST_TRACE_HASH, ST_PERM_Z, ST_Z_NTT, ST_Z_HASH, ST_QUOTIENT_EVAL, ST_QUOTIENT_COMMIT,
+  ST_OPENINGS, ST_FRI_COMBINE, ST_FRI_LAYERS, ST_POW, ST_QUERIES, ST_COUNT
+};
+static const char* STAGE_NAMES[ST_COUNT] = {
+  "trace_ntt", "trace_hash", "perm_z", "z_ntt", "z_hash", "quotient_eval", "quotient_commit",
+  "openings", "fri_combine", "fri_layers", "pow", "queries"};
+
+struct DevTree {  // Merkle digests, levels concatenated (leaf level first)
+  u64* d = nullptr; size_t nleaf = 0; u32 nlevels = 0;  // nlevels = number of levels BELOW the cap
+  u64* level(u32 l) const { return d + (2 * nleaf - ((2 * nleaf) >> l)) * 4; }
+};
+
+struct sbn_prover {
+  AirShape air; sbn_config cfg; FriShape fri;
+  u32 degree_bits, lde_log; size_t n, m;
+  int device; hipStream_t stream;
+  // matrices
+  u64 *d_trace = nullptr, *d_coef = nullptr, *d_lde = nullptr, *d_tmp = nullptr;
+  u64 *d_zval = nullptr, *d_zcoef = nullptr, *d_zlde = nullptr;
+  u64 *d_q = nullptr, *d_qlde = nullptr;
+  DevTree tree_t, tree_z, tree_q;
+  std::vector<DevTree> fri_trees;
+  // tables
+  u64 *d_tw_f = nullptr, *d_tw_i = nullptr, *d_shift = nullptr, *d_shift_inv = nullptr;
+  u64 *d_xs = nullptr, *d_lag_first = nullptr, *d_lag_last = nullptr;
+  u64 *d_apow = nullptr;  // [2][APOW_MAX]
+  void* d_pic = nullptr;  // G1ExpPiConsts<F>
+  PairCols* d_pairs = nullptr;
+  // openings / FRI
+  u64 *d_zpow = nullptr;        // 4 planes [n]: z^i (a,b), (g z)^i (a,b)
+  u64 *d_open = nullptr;        // [(ncols + nzs + 4)][4]
+  u64 *d_part = nullptr;        // 2 planes [groups][n]
+  u64 *d_w = nullptr;           // group weights
+  u64 *d_fa = nullptr, *d_fb = nullptr;    // F0 / F1 scratch planes [n] each (a,b) x2
+  u64 *d_fcoef = nullptr;       // final poly coefficient planes [2][m]
+  u64 *d_fcoef2 = nullptr;      // ping-pong for folding [2][m/2^arity]
+  std::vector<u64*> fri_vals;   // per layer value planes [2][size]
+  u64 *d_pow = nullptr;
+  u32 *d_idx = nullptr;
+  u64 *d_qbuf = nullptr; size_t qstride = 0;
+  std::vector<u64> pi;
+  bool loaded = false;
+  hipEvent_t ev[ST_COUNT + 1];
+  float stage_ms[ST_COUNT];
+  size_t ntt_chunk;
+};
+
+static int dmalloc(u64** p, size_t words) {
+  HIPC(hipMalloc((void**)p, words * sizeof(u64)));
+  return 0;
+}
+
+// ---- NTT driver -----------------------------------------------------------------------------------
+static u32 pick_log_t(u32 log_r, u32 log_s) {
+  u32 lt = 4;
+  while (lt > 0 && ((size_t)(1u << log_r) * ((1u << lt) + 1) * 8) > 48 * 1024) lt--;
+  return std::min(lt, log_s);
+}
+// One full n-point transform per column (two passes through `tmp`).
+static int ntt_columns(sbn_prover* P, const u64* in, size_t in_cs, u64* out, size_t out_cs, u64* tmp, size_t tmp_cs, size_t ncols,
+                       u32 log_n, bool inverse, size_t n_in, const u64* pre, const u64* post, u64 scale) {
+  if (ncols == 0) return 0;
+  u32 log_n1 = (log_n + 1) / 2, log_n2 = log_n - log_n1;
+  size_t n1 = (size_t)1 << log_n1, n2 = (size_t)1 << log_n2;
+  NttPassParams a{};
+  a.in = in; a.out = tmp; a.in_col_stride = in_cs; a.out_col_stride = tmp_cs;
+  a.log_r = log_n1; a.log_t = pick_log_t(log_n1, log_n2); a.log_n = log_n;
+  a.in_sr = n2; a.in_st = 1; a.out_sr = n2; a.out_st = 1; a.n_in = n_in;
+  a.r_fast_load = 0; a.twiddle = 1; a.tw = inverse ? P->d_tw_i : P->d_tw_f; a.tw_log = P->lde_log;
+  a.pre = pre; a.post = nullptr; a.scale = 1;
+  NttPassParams b{};
+  b.in = tmp; b.out = out; b.in_col_stride = tmp_cs; b.out_col_stride = out_cs;
+  b.log_r = log_n2; b.log_t = pick_log_t(log_n2, log_n1); b.log_n = log_n;
+  b.in_sr = 1; b.in_st = n2; b.out_sr = n1; b.out_st = 1; b.n_in = (size_t)1 << log_n;
+  b.r_fast_load = 1; b.twiddle = 0; b.tw = a.tw; b.tw_log = P->lde_log;
+  b.pre = nullptr; b.post = post; b.scale = scale;
+  for (size_t c0 = 0; c0 < ncols; c0 += 32768) {
+    size_t nc = std::min<size_t>(32768, ncols - c0);
+    NttPassParams pa = a, pb = b;
+    pa.in = a.in + c0 * in_cs; pa.out = a.out + c0 * tmp_cs;
+    pb.in = b.in + c0 * tmp_cs; pb.out = b.out + c0 * out_cs;
+    dim3 ga((unsigned)(n2 >> pa.log_t), (unsigned)nc), gb((unsigned)(n1 >> pb.log_t), (unsigned)nc);
+    size_t la = ((size_t)1 << pa.log_r) * ((1u << pa.log_t) + 1) * 8, lb = ((size_t)1 << pb.log_r) * ((1u << pb.log_t) + 1) * 8;
+    hipLaunchKernelGGL(ntt_pass_kernel, ga, dim3(NTT_THREADS), la, P->stream, pa);
+    if (log_n2 > 0) hipLaunchKernelGGL(ntt_pass_kernel, gb, dim3(NTT_THREADS), lb, P->stream, pb);
+    else HIPC(hipMemcpyAsync(pb.out, pb.in, sizeof(u64), hipMemcpyDeviceToDevice, P->stream));
+  }
+  HIPC(hipGetLastError());
+  return 0;
+}
+
+static u64 host_inv_pow2(u32 k) { return f_inv(F((u64)1 << k)).v; }
+
+// values [ncols][n] -> coefficients [ncols][n]
+static int intt_values(sbn_prover* P, const u64* vals, u64* coef, size_t ncols) {
+  for (size_t c0 = 0; c0 < ncols; c0 += P->ntt_chunk) {
+    size_t nc = std::min(P->ntt_chunk, ncols - c0);
+    int rc = ntt_columns(P, vals + c0 * P->n, P->n, coef + c0 * P->n, P->n, P->d_tmp, P->m, nc, P->degree_bits, true, P->n, nullptr, nullptr,
+                         host_inv_pow2(P->degree_bits));
+    if (rc) return rc;
+  }
+  return 0;
+}
+// coefficients [ncols][n] -> coset LDE [ncols][m]   (lde(rate_bits).coset_fft(7))
+static int lde_coeffs(sbn_prover* P, const u64* coef, u64* lde, size_t ncols) {
+  for (size_t c0 = 0; c0 < ncols; c0 += P->ntt_chunk) {
+    size_t nc = std::min(P->ntt_chunk, ncols - c0);
+    int rc = ntt_columns(P, coef + c0 * P->n, P->n, lde + c0 * P->m, P->m, P->d_tmp, P->m, nc, P->lde_log, false, P->n, P->d_shift, nullptr, 1);
+    if (rc) return rc;
+  }
+  return 0;
+}
+// fused variant used for the big matrices: per chunk iNTT then LDE so the chunk stays cache resident
+static int intt_then_lde(sbn_prover* P, const u64* vals, u64* coef, u64* lde, size_t ncols) {
+  for (size_t c0 = 0; c0 < ncols; c0 += P->ntt_chunk) {
+    size_t nc = std::min(P->ntt_chunk, ncols - c0);
+    int rc = ntt_columns(P, vals + c0 * P->n, P->n, coef + c0 * P->n, P->n, P->d_tmp, P->m, nc, P->degree_bits, true, P->n, nullptr, nullptr,
+                         host_inv_pow2(P->degree_bits));
+    if (rc) return rc;
+    rc = ntt_columns(P, coef + c0 * P->n, P->n, lde + c0 * P->m, P->m, P->d_tmp, P->m, nc, P->lde_log, false, P->n, P->d_shift, nullptr, 1);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+static int tree_alloc(DevTree& t, size_t nleaf, u32 cap_height) {
+  t.nleaf = nleaf;
+  u32 lg = 0; while (((size_t)1 << lg) < nleaf) lg++;
+  t.nlevels = lg - cap_height;
+  return dmalloc(&t.d, 2 * nleaf * 4);
+}
+static int tree_build_inner(sbn_prover* P, DevTree& t) {
+  for (u32 l = 0; l < t.nlevels; l++) {
+    size_t np = t.nleaf >> (l + 1);
+    hipLaunchKernelGGL(merkle_level_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, P->stream, t.level(l), t.level(l + 1), np);
+  }
+  HIPC(hipGetLastError());
+  return 0;
+}
+static int tree_from_matrix(sbn_prover* P, DevTree& t, const u64* lde, size_t ncols) {
+  hipLaunchKernelGGL(leaf_hash_kernel, dim3((unsigned)((P->m + 255) / 256)), dim3(256), 0, P->stream, lde, P->m, P->lde_log, (u32)ncols, t.d);
+  return tree_build_inner(P, t);
+}
+static int tree_cap_to_host(sbn_prover* P, const DevTree& t, std::vector<u64>& cap) {
+  size_t capn = (size_t)1 << P->cfg.cap_height;
+  cap.resize(capn * 4);
+  HIPC(hipMemcpyAsync(cap.data(), t.level(t.nlevels), capn * 4 * sizeof(u64), hipMemcpyDeviceToHost, P->stream));
+  HIPC(hipStreamSynchronize(P->stream));
+  return 0;
+}
+
+// ---- create / destroy -----------------------------------------------------------------------------
+extern "C" int sbn_prover_create(const sbn_air_desc* air, const sbn_config* cfg, uint32_t degree_bits, sbn_prover** out) {
+  if (!air || !cfg || !out) return fail(SBN_ERR_BAD_ARG, "null argument");
+  *out = nullptr;
+  if (!config_supported(cfg)) return fail(SBN_ERR_UNSUPPORTED, "unsupported StarkConfig (need num_challenges=2, rate_bits=1)");
+  AirShape as;
+  if (!air_shape(air, cfg, as)) return fail(SBN_ERR_BAD_ARG, "unknown air kind / num_io");
+  if (degree_bits < 9 || degree_bits > 22) return fail(SBN_ERR_UNSUPPORTED, "degree_bits out of range");
+  if (as.kind == SBN_AIR_G1_EXP) {
+    if (((size_t)512 * as.num_io) != ((size_t)1 << degree_bits)) return fail(SBN_ERR_BAD_ARG, "G1_EXP needs 512*num_io rows");
+    if (degree_bits < 16) return fail(SBN_ERR_UNSUPPORTED, "G1_EXP needs >= 2^16 rows (u16 range check, range_check.rs:26)");
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(SBN_ERR_NO_DEVICE, "no HIP device available: the prover path has no CPU fallback");
+  HIPC(hipSetDevice(g_device));
+  sbn_prover* P = new sbn_prover();
+  P->air = as; P->cfg = *cfg; P->degree_bits = degree_bits; P->lde_log = degree_bits + cfg->rate_bits;
+  P->n = (size_t)1 << degree_bits; P->m = (size_t)1 << P->lde_log;
+  P->fri = fri_shape(*cfg, degree_bits);
+  P->device = g_device;
+  if (P->fri.total_arity() > degree_bits + cfg->rate_bits - cfg->cap_height) { delete P; return fail(SBN_ERR_UNSUPPORTED, "FRI total reduction arity is too large"); }
+  const char* ce = getenv("SBN_NTT_CHUNK");
+  P->ntt_chunk = ce ? (size_t)atol(ce) : 64;
+  if (P->ntt_chunk == 0) P->ntt_chunk = 64;
+  HIPC(hipStreamCreate(&P->stream));
+  for (auto& e : P->ev) HIPC(hipEventCreate(&e));
+  const size_t n = P->n, m = P->m, C = as.ncols, Z = as.nzs;
+  int rc = 0;
+  rc |= dmalloc(&P->d_trace, C * n); rc |= dmalloc(&P->d_coef, C * n); rc |= dmalloc(&P->d_lde, C * m);
+  rc |= dmalloc(&P->d_tmp, std::max(P->ntt_chunk, (size_t)4) * m);
+  rc |= dmalloc(&P->d_zval, Z * n); rc |= dmalloc(&P->d_zcoef, Z * n); rc |= dmalloc(&P->d_zlde, Z * m);
+  rc |= dmalloc(&P->d_q, 2 * m); rc |= dmalloc(&P->d_qlde, 4 * m);
+  rc |= tree_alloc(P->tree_t, m, cfg->cap_height); rc |= tree_alloc(P->tree_z, m, cfg->cap_height); rc |= tree_alloc(P->tree_q, m, cfg->cap_height);
+  rc |= dmalloc(&P->d_tw_f, m / 2); rc |= dmalloc(&P->d_tw_i, m / 2); rc |= dmalloc(&P->d_shift, m); rc |= dmalloc(&P->d_shift_inv, m);
+  rc |= dmalloc(&P->d_xs, m); rc |= dmalloc(&P->d_lag_first, m); rc |= dmalloc(&P->d_lag_last, m);
+  rc |= dmalloc(&P->d_apow, (size_t)SBN_NCH * APOW_MAX);
+  rc |= dmalloc(&P->d_zpow, 4 * n); rc |= dmalloc(&P->d_open, (C + Z + 4) * 4);
+  rc |= dmalloc(&P->d_part, 2 * 32 * n); rc |= dmalloc(&P->d_w, 64);
+  rc |= dmalloc(&P->d_fa, 4 * n); rc |= dmalloc(&P->d_fcoef, 2 * m); rc |= dmalloc(&P->d_fcoef2, 2 * m);
+  rc |= dmalloc(&P->d_pow, 1);
+  if (rc) { sbn_prover_destroy(P); return rc; }
+  P->d_fb = P->d_fa + 2 * n;
+  HIPC(hipMalloc((void**)&P->d_pic, sizeof(G1ExpPiConsts<F>)));
+  HIPC(hipMalloc((void**)&P->d_idx, cfg->num_query_rounds * sizeof(u32)));
+  // FRI layer buffers
+  {
+    u32 bits = P->lde_log;
+    for (u32 ab : P->fri.arity_bits) {
+      u64* v = nullptr; rc |= dmalloc(&v, 2 * ((size_t)1 << bits)); P->fri_vals.push_back(v);
+      DevTree t; rc |= tree_alloc(t, (size_t)1 << (bits - ab), cfg->cap_height); P->fri_trees.push_back(t);
+      bits -= ab;
+    }
+    if (rc) { sbn_prover_destroy(P); return rc; }
+  }
+  // query section stride (words per query round)
+  {
+    size_t sib = (size_t)(P->lde_log - cfg->cap_height) * 4;
+    size_t s = C + sib + (Z ? Z + sib : 0) + 4 + sib;
+    u32 bits = P->lde_log;
+    for (u32 ab : P->fri.arity_bits) { bits -= ab; s += 2 * ((size_t)1 << ab) + (size_t)(bits - cfg->cap_height) * 4; }
+    P->qstride = s;
+    rc |= dmalloc(&P->d_qbuf, s * cfg->num_query_rounds);
+    if (rc) { sbn_prover_destroy(P); return rc; }
+  }
+  // tables
+  auto blocks = [](size_t k) { return dim3((unsigned)((k + 255) / 256)); };
+  F w = f_root_of_unity(P->lde_log);
+  hipLaunchKernelGGL(pow_table_kernel, blocks(m / 2), dim3(256), 0, P->stream, P->d_tw_f, m / 2, w.v);
+  hipLaunchKernelGGL(pow_table_kernel, blocks(m / 2), dim3(256), 0, P->stream, P->d_tw_i, m / 2, f_inv(w).v);
+  hipLaunchKernelGGL(pow_table_kernel, blocks(m), dim3(256), 0, P->stream, P->d_shift, m, (u64)GL_GEN);
+  hipLaunchKernelGGL(pow_table_kernel, blocks(m), dim3(256), 0, P->stream, P->d_shift_inv, m, f_inv(F(GL_GEN)).v);
+  hipLaunchKernelGGL(domain_tables_kernel, blocks(m), dim3(256), 0, P->stream, P->d_xs, P->d_lag_first, P->d_lag_last, m, P->lde_log, degree_bits);
+  // permutation pairs
+  {
+    std::vector<PairCols> pairs(Z);
+    for (size_t z = 0; z < Z; z++) {
+      int l, r;
+      if (as.kind == SBN_AIR_G1_OP) G1OpShape::pair((int)z, l, r); else G1ExpShape((int)as.num_io).pair((int)z, l, r);
+      pairs[z].lhs = l; pairs[z].rhs = r;
+    }
+    HIPC(hipMalloc((void**)&P->d_pairs, Z * sizeof(PairCols)));
+    HIPC(hipMemcpy(P->d_pairs, pairs.data(), Z * sizeof(PairCols), hipMemcpyHostToDevice));
+  }
+  HIPC(hipStreamSynchronize(P->stream));
+  HIPC(hipGetLastError());
+  *out = P;
+  return SBN_OK;
+}
+
+extern "C" void sbn_prover_destroy(sbn_prover* P) {
+  if (!P) return;
+  hipSetDevice(P->device);
+  u64* bufs[] = {P->d_trace, P->d_coef, P->d_lde, P->d_tmp, P->d_zval, P->d_zcoef, P->d_zlde, P->d_q, P->d_qlde, P->tree_t.d, P->tree_z.d,
+                 P->tree_q.d, P->d_tw_f, P->d_tw_i, P->d_shift, P->d_shift_inv, P->d_xs, P->d_lag_first, P->d_lag_last, P->d_apow, P->d_zpow,
+                 P->d_open, P->d_part, P->d_w, P->d_fa, P->d_fcoef, P->d_fcoef2, P->d_pow, P->d_qbuf};
+  for (u64* b : bufs) if (b) hipFree(b);
+  for (u64* b : P->fri_vals) if (b) hipFree(b);
+  for (auto& t : P->fri_trees) if (t.d) hipFree(t.d);
+  if (P->d_pic) hipFree(P->d_pic);
+  if (P->d_idx) hipFree(P->d_idx);
+  if (P->d_pairs) hipFree(P->d_pairs);
+  for (auto& e : P->ev) hipEventDestroy(e);
+  hipStreamDestroy(P->stream);
+  delete P;
+}
+
+static int check_pi(sbn_prover* P, const uint64_t* pi, size_t n_pi) {
+  if (n_pi != P->air.npi) return fail(SBN_ERR_BAD_ARG, "expected %zu public inputs, got %zu", P->air.npi, n_pi);
+  if (n_pi && !pi) return fail(SBN_ERR_BAD_ARG, "null public inputs");
+  for (size_t i = 0; i < n_pi; i++) if (pi[i] >= GLP) return fail(SBN_ERR_NON_CANONICAL, "public input %zu is not canonical", i);
+  P->pi.assign(pi, pi + n_pi);
+  return 0;
+}
+extern "C" int sbn_prover_load_trace(sbn_prover* P, const uint64_t* trace, const uint64_t* pi, size_t n_pi) {
+  if (!P || !trace) return fail(SBN_ERR_BAD_ARG, "null argument");
+  int rc = check_pi(P, pi, n_pi); if (rc) return rc;
+  size_t words = P->air.ncols * P->n;
+  for (size_t i = 0; i < words; i++) if (trace[i] >= GLP) return fail(SBN_ERR_NON_CANONICAL, "trace word %zu is not canonical", i);
+  HIPC(hipSetDevice(P->device));
+  HIPC(hipMemcpy(P->d_trace, trace, words * sizeof(u64), hipMemcpyHostToDevice));
+  P->loaded = true;
+  return SBN_OK;
+}
+extern "C" int sbn_prover_load_trace_device(sbn_prover* P, const uint64_t* d_trace, const uint64_t* pi, size_t n_pi) {
+  if (!P || !d_trace) return fail(SBN_ERR_BAD_ARG, "null argument");
+  int rc = check_pi(P, pi, n_pi); if (rc) return rc;
+  HIPC(hipSetDevice(P->device));
+  if (d_trace != P->d_trace) HIPC(hipMemcpy(P->d_trace, d_trace, P->air.ncols * P->n * sizeof(u64), hipMemcpyDeviceToDevice));
+  P->loaded = true;
+  return SBN_OK;
+}
+extern "C" uint64_t* sbn_prover_trace_device_ptr(sbn_prover* P) { return P ? P->d_trace : nullptr; }
+
+extern "C" int sbn_prover_stage_times(const sbn_prover* P, float* ms, int cap) {
+  if (!P || !ms) return 0;
+  int k = std::min(cap, (int)ST_COUNT);
+  for (int i = 0; i < k; i++) ms[i] = P->stage_ms[i];
+  return k;
+}
+extern "C" const char* sbn_prover_stage_name(int i) { return (i >= 0 && i < ST_COUNT) ? STAGE_NAMES[i] : ""; }
+
+// ---- prove ----------------------------------------------------------------------------------------
+extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
+  if (!P || !out) return fail(SBN_ERR_BAD_ARG, "null argument");
+  *out = nullptr;
+  if (!P->loaded) return fail(SBN_ERR_BAD_ARG, "no trace loaded");
+  HIPC(hipSetDevice(P->device));
+  hipStream_t st = P->stream;
+  const size_t n = P->n, m = P->m, C = P->air.ncols, Z = P->air.nzs;
+  const sbn_config& cfg = P->cfg;
+  const size_t capw = ((size_t)1 << cfg.cap_height) * 4;
+  auto blocks = [](size_t k) { return dim3((unsigned)((k + 255) / 256)); };
+  int rc;
+  Challenger ch;
+  std::vector<u64> trace_cap, z_cap, q_cap;
+
+  // P1 trace commitment ---------------------------------------------------------------------------
+  HIPC(hipEventRecord(P->ev[ST_TRACE_NTT], st));
+  if ((rc = intt_then_lde(P, P->d_trace, P->d_coef, P->d_lde, C))) return rc;
+  HIPC(hipEventRecord(P->ev[ST_TRACE_HASH], st));
+  if ((rc = tree_from_matrix(P, P->tree_t, P->d_lde, C))) return rc;
+  HIPC(hipEventRecord(P->ev[ST_PERM_Z], st));
+  if ((rc = tree_cap_to_host(P, P->tree_t, trace_cap))) return rc;
+  ch.observe_words(trace_cap.data(), capw);
+
+  // P2 permutation argument -------------------------------------------------------------------------
+  // get_n_permutation_challenge_sets(num_challenges, batch_size=2): sets[s].challenges[c] = (beta, gamma)
+  F gam[2][2];
+  for (int s = 0; s < 2; s++) for (int c = 0; c < (int)cfg.num_challenges; c++) { (void)ch.challenge(); gam[s][c] = ch.challenge(); }
+  const F gamma0 = gam[0][0], gamma1 = gam[1][1];  // instance i of a batch uses sets[i].challenges[chal]
+  hipLaunchKernelGGL(permutation_z_kernel, dim3((unsigned)Z), dim3(256), 0, st, P->d_trace, n, P->d_pairs, gamma0.v, gamma1.v, P->d_zval);
+  HIPC(hipGetLastError());
+  HIPC(hipEventRecord(P->ev[ST_Z_NTT], st));
+  if ((rc = intt_then_lde(P, P->d_zval, P->d_zcoef, P->d_zlde, Z))) return rc;
+  HIPC(hipEventRecord(P->ev[ST_Z_HASH], st));
+  if ((rc = tree_from_matrix(P, P->tree_z, P->d_zlde, Z))) return rc;
+  HIPC(hipEventRecord(P->ev[ST_QUOTIENT_EVAL], st));
+  if ((rc = tree_cap_to_host(P, P->tree_z, z_cap))) return rc;
+  ch.observe_words(z_cap.data(), capw);
+
+  // P3 quotient -------------------------------------------------------------------------------------
+  F alphas[SBN_NCH];
+  for (int j = 0; j < SBN_NCH; j++) alphas[j] = ch.challenge();
+  {
+    std::vector<u64> apow((size_t)SBN_NCH * APOW_MAX);
+    std::vector<F> ap[SBN_NCH];
+    for (int j = 0; j < SBN_NCH; j++) {
+      ap[j].resize(APOW_MAX);
+      F a(1);
+      for (int k = 0; k < APOW_MAX; k++) { ap[j][k] = a; apow[(size_t)j * APOW_MAX + k] = a.v; a = a * alphas[j]; }
+    }
+    HIPC(hipMemcpyAsync(P->d_apow, apow.data(), apow.size() * sizeof(u64), hipMemcpyHostToDevice, st));
+    if (P->air.kind == SBN_AIR_G1_EXP) {
+      static thread_local G1ExpPiConsts<F> pic;
+      const F* app[SBN_NCH] = {ap[0].data(), ap[1].data()};
+      std::vector<F> pif(P->pi.size());
+      for (size_t i = 0; i < pif.size(); i++) pif[i] = F(P->pi[i]);
+      g1exp_pi_consts<F>(G1ExpShape((int)P->air.num_io), app, pif.data(), pic);
+      HIPC(hipMemcpyAsync(P->d_pic, &pic, sizeof(pic), hipMemcpyHostToDevice, st));
+    }
+    HIPC(hipStreamSynchronize(st));
+  }
+  {
+    QuotientParams qp{};
+    qp.lde = P->d_lde; qp.zlde = P->d_zlde; qp.m = m; qp.next_step = 2;  // 2^quotient_degree_bits
+    qp.xs = P->d_xs; qp.lag_first = P->d_lag_first; qp.lag_last = P->d_lag_last;
+    F gn = f_exp_pow2(F(GL_GEN), P->degree_bits);
+    qp.zh_inv[0] = f_inv(gn - F(1)).v; qp.zh_inv[1] = f_inv(-gn - F(1)).v;  // Z_H(7 w^i) = 7^N (-1)^i - 1
+    qp.last = f_inv(f_root_of_unity(P->degree_bits)).v;
+    for (int j = 0; j < SBN_NCH; j++) { qp.alpha[j] = alphas[j].v; qp.apow[j] = P->d_apow + (size_t)j * APOW_MAX; }
+    qp.gamma0 = gamma0.v; qp.gamma1 = gamma1.v; qp.num_zs = (int)Z; qp.num_io = (int)P->air.num_io; qp.pic = P->d_pic; qp.qout = P->d_q;
+    if (P->air.kind == SBN_AIR_G1_OP) hipLaunchKernelGGL(quotient_kernel<1>, blocks(m), dim3(256), 0, st, qp);
+    else hipLaunchKernelGGL(quotient_kernel<2>, blocks(m), dim3(256), 0, st, qp);
+    HIPC(hipGetLastError());
+  }
+  HIPC(hipEventRecord(P->ev[ST_QUOTIENT_COMMIT], st));
+  // coset_ifft(7) of the 2 quotient value vectors (size m), in place via tmp; the result viewed as
+  // [4][n] is exactly quotient_poly.chunks(degree) in the order q0_lo, q0_hi, q1_lo, q1_hi.
+  if ((rc = ntt_columns(P, P->d_q, m, P->d_q, m, P->d_tmp, m, 2, P->lde_log, true, m, nullptr, P->d_shift_inv, host_inv_pow2(P->lde_log)))) return rc;
+  if ((rc = lde_coeffs(P, P->d_q, P->d_qlde, 4))) return rc;
+  if ((rc = tree_from_matrix(P, P->tree_q, P->d_qlde, 4))) return rc;
+  HIPC(hipEventRecord(P->ev[ST_OPENINGS], st));
+  if ((rc = tree_cap_to_host(P, P->tree_q, q_cap))) return rc;
+  ch.observe_words(q_cap.data(), capw);
+
+  // P4 openings -------------------------------------------------------------------------------------
+  E2 zeta = ch.ext_challenge();
+  F g = f_root_of_unity(P->degree_bits);
+  if (e2_exp_pow2(zeta, P->degree_bits) == E2(F(1), F(0))) return fail(SBN_ERR_HIP, "opening point is in the subgroup");
+  E2 zeta_next = zeta * g;
+  hipLaunchKernelGGL(ext_pow_table_kernel, blocks(n), dim3(256), 0, st, P->d_zpow, P->d_zpow + n, n, zeta.a.v, zeta.b.v);
+  hipLaunchKernelGGL(ext_pow_table_kernel, blocks(n), dim3(256), 0, st, P->d_zpow + 2 * n, P->d_zpow + 3 * n, n, zeta_next.a.v, zeta_next.b.v);
+  hipLaunchKernelGGL(openings_kernel, dim3((unsigned)C), dim3(256), 0, st, P->d_coef, n, P->d_zpow, P->d_zpow + n, P->d_zpow + 2 * n, P->d_zpow + 3 * n, P->d_open);
+  hipLaunchKernelGGL(openings_kernel, dim3((unsigned)Z), dim3(256), 0, st, P->d_zcoef, n, P->d_zpow, P->d_zpow + n, P->d_zpow + 2 * n, P->d_zpow + 3 * n, P->d_open + C * 4);
+  hipLaunchKernelGGL(openings_kernel, dim3(4), dim3(256), 0, st, P->d_q, n, P->d_zpow, P->d_zpow + n, P->d_zpow + 2 * n, P->d_zpow + 3 * n, P->d_open + (C + Z) * 4);
+  HIPC(hipGetLastError());
+  std::vector<u64> open((C + Z + 4) * 4);
+  HIPC(hipMemcpyAsync(open.data(), P->d_open, open.size() * sizeof(u64), hipMemcpyDeviceToHost, st));
+  HIPC(hipEventRecord(P->ev[ST_FRI_COMBINE], st));
+  HIPC(hipStreamSynchronize(st));
+  // observe_openings: batch zeta = local ++ perm_zs ++ quotient ; batch g*zeta = next ++ perm_zs_next
+  for (size_t p = 0; p < C + Z + 4; p++) { ch.observe(F(open[4 * p])); ch.observe(F(open[4 * p + 1])); }
+  for (size_t p = 0; p < C + Z; p++) { ch.observe(F(open[4 * p + 2])); ch.observe(F(open[4 * p + 3])); }
+
+  // P5 FRI ------------------------------------------------------------------------------------------
+  E2 fri_alpha = ch.ext_challenge();
+  {
+    // F1 = sum_{j < C+Z} alpha^j f_j ; F0 = F1 + alpha^(C+Z) * sum_{j<4} alpha^j q_j
+    const u32 GS = 128;  // polys per group
+    auto combine = [&](const u64* coeffs, u32 npoly, E2 weight0, u64* oa, u64* ob, int accumulate) -> int {
+      u32 ng = (npoly + GS - 1) / GS;
+      for (u32 g0 = 0; g0 < ng; g0 += 32) {
+        u32 gc = std::min<u32>(32, ng - g0);
+        hipLaunchKernelGGL(fri_combine_partial_kernel, dim3((unsigned)((n + 255) / 256), gc), dim3(256), 0, st, coeffs + (size_t)g0 * GS * n, n,
+                           npoly - g0 * GS, GS, fri_alpha.a.v, fri_alpha.b.v, P->d_part, P->d_part + 32 * n);
+        std::vector<u64> w(2 * gc);
+        E2 ag = e2_pow(fri_alpha, GS), cur = weight0 * e2_pow(fri_alpha, (u64)g0 * GS);
+        for (u32 k = 0; k < gc; k++) { w[2 * k] = cur.a.v; w[2 * k + 1] = cur.b.v; cur = cur * ag; }
+        HIPC(hipMemcpyAsync(P->d_w, w.data(), w.size() * sizeof(u64), hipMemcpyHostToDevice, st));
+        HIPC(hipStreamSynchronize(st));  // w is a stack buffer
+        hipLaunchKernelGGL(fri_combine_reduce_kernel, blocks(n), dim3(256), 0, st, P->d_part, P->d_part + 32 * n, n, gc, P->d_w, oa, ob,
+                           (accumulate || g0 > 0) ? 1 : 0);
+      }
+      HIPC(hipGetLastError());
+      return 0;
+    };
+    u64 *f1a = P->d_fb, *f1b = P->d_fb + n, *f0a = P->d_fa, *f0b = P->d_fa + n;
+    E2 one{F(1), F(0)};
+    if ((rc = combine(P->d_coef, (u32)C, one, f1a, f1b, 0))) return rc;
+    if (Z) if ((rc = combine(P->d_zcoef, (u32)Z, e2_pow(fri_alpha, C), f1a, f1b, 1))) return rc;
+    HIPC(hipMemcpyAsync(f0a, f1a, 2 * n * sizeof(u64), hipMemcpyDeviceToDevice, st));
+    if ((rc = combine(P->d_q, 4, e2_pow(fri_alpha, C + Z), f0a, f0b, 1))) return rc;
+    // final_poly = alpha^(C+Z) * (F0 / (X - zeta)) + F1 / (X - g zeta), padded back to n, then lde -> m
+    HIPC(hipMemsetAsync(P->d_fcoef, 0, 2 * m * sizeof(u64), st));
+    E2 shift2 = e2_pow(fri_alpha, C + Z);
+    hipLaunchKernelGGL(divide_by_linear_kernel, dim3(1), dim3(256), 0, st, f0a, f0b, n, zeta.a.v, zeta.b.v, (u64)0, (u64)0, P->d_fcoef, P->d_fcoef + m, 0);
+    hipLaunchKernelGGL(divide_by_linear_kernel, dim3(1), dim3(256), 0, st, f1a, f1b, n, zeta_next.a.v, zeta_next.b.v, shift2.a.v, shift2.b.v, P->d_fcoef,
+                       P->d_fcoef + m, 1);
+    HIPC(hipGetLastError());
+  }
+  HIPC(hipEventRecord(P->ev[ST_FRI_LAYERS], st));
+  std::vector<std::vector<u64>> fri_caps;
+  std::vector<u64> final_poly;
+  {
+    // fri_committed_trees
+    u32 bits = P->lde_log;
+    u64* coef = P->d_fcoef; u64* coef_alt = P->d_fcoef2;
+    size_t clen = m;  // coefficient vector length (planes at coef, coef + clen)
+    F shift(GL_GEN);
+    for (size_t li = 0; li < P->fri.arity_bits.size(); li++) {
+      u32 ab = P->fri.arity_bits[li];
+      u64* va = P->fri_vals[li]; u64* vb = va + clen;
+      // values = coeffs.coset_fft(shift): scale by shift^i then NTT (2 base planes)
+      HIPC(hipMemcpyAsync(va, coef, 2 * clen * sizeof(u64), hipMemcpyDeviceToDevice, st));
+      hipLaunchKernelGGL(scale_pow_kernel, blocks(clen), dim3(256), 0, st, va, clen, shift.v);
+      hipLaunchKernelGGL(scale_pow_kernel, blocks(clen), dim3(256), 0, st, vb, clen, shift.v);
+      if ((rc = ntt_columns(P, va, clen, va, clen, P->d_tmp, m, 2, bits, false, clen, nullptr, nullptr, 1))) return rc;
+      DevTree& t = P->fri_trees[li];
+      hipLaunchKernelGGL(fri_leaf_hash_kernel, blocks(t.nleaf), dim3(256), 0, st, va, vb, bits, ab, t.d);
+      if ((rc = tree_build_inner(P, t))) return rc;
+      std::vector<u64> cap;
+      if ((rc = tree_cap_to_host(P, t, cap))) return rc;
+      ch.observe_words(cap.data(), capw);
+      fri_caps.push_back(cap);
+      E2 beta = ch.ext_challenge();
+      size_t nout = clen >> ab;
+      hipLaunchKernelGGL(fri_fold_kernel, blocks(nout), dim3(256), 0, st, coef, coef + clen, nout, 1u << ab, beta.a.v, beta.b.v, coef_alt, coef_alt + nout);
+      HIPC(hipGetLastError());
+      std::swap(coef, coef_alt);
+      clen = nout; bits -= ab;
+      shift = f_pow(shift, (u64)1 << ab);
+    }
+    size_t fl = clen >> cfg.rate_bits;  // coefficients beyond are zero
+    final_poly.resize(2 * fl);
+    std::vector<u64> fa(fl), fb(fl);
+    HIPC(hipMemcpyAsync(fa.data(), coef, fl * sizeof(u64), hipMemcpyDeviceToHost, st));
+    HIPC(hipMemcpyAsync(fb.data(), coef + clen, fl * sizeof(u64), hipMemcpyDeviceToHost, st));
+    HIPC(hipStreamSynchronize(st));
+    for (size_t i = 0; i < fl; i++) { final_poly[2 * i] = fa[i]; final_poly[2 * i + 1] = fb[i]; ch.observe(F(fa[i])); ch.observe(F(fb[i])); }
+  }
+  HIPC(hipEventRecord(P->ev[ST_POW], st));
+  // fri_proof_of_work: smallest witness
+  u64 pow_witness = ~0ULL;
+  {
+    PowParams pp{};
+    for (int i = 0; i < 12; i++) pp.state[i] = ch.st[i].v;
+    for (size_t i = 0; i < ch.in.size(); i++) pp.state[i] = ch.in[i].v;
+    pp.wpos = (u32)ch.in.size(); pp.min_lz = cfg.proof_of_work_bits; pp.result = P->d_pow;
+    const u64 BATCH = 1ULL << 22;
+    for (u64 base = 0; pow_witness == ~0ULL; base += BATCH) {
+      if (base >= GLP - BATCH) return fail(SBN_ERR_HIP, "proof of work failed");
+      u64 init = ~0ULL;
+      HIPC(hipMemcpyAsync(P->d_pow, &init, sizeof(u64), hipMemcpyHostToDevice, st));
+      pp.base = base; pp.count = BATCH;
+      hipLaunchKernelGGL(pow_kernel, blocks(BATCH), dim3(256), 0, st, pp);
+      HIPC(hipMemcpyAsync(&pow_witness, P->d_pow, sizeof(u64), hipMemcpyDeviceToHost, st));
+      HIPC(hipStreamSynchronize(st));
+    }
+    ch.observe(F(pow_witness));
+    F resp = ch.challenge();
+    u32 lz = resp.v ? (u32)__builtin_clzll(resp.v) : 64;
+    if (lz < cfg.proof_of_work_bits) return fail(SBN_ERR_HIP, "proof-of-work witness check failed");
+  }
+  HIPC(hipEventRecord(P->ev[ST_QUERIES], st));
+  // fri_prover_query_rounds
+  const u32 nq = cfg.num_query_rounds;
+  std::vector<u64> qwords(P->qstride * nq);
+  {
+    std::vector<u32> idx(nq);
+    for (u32 q = 0; q < nq; q++) idx[q] = (u32)(ch.challenge().v % m);
+    HIPC(hipMemcpyAsync(P->d_idx, idx.data(), nq * sizeof(u32), hipMemcpyHostToDevice, st));
+    size_t off = 0;
+    const u32 nsib = P->lde_log - cfg.cap_height;
+    auto initial = [&](const u64* mat, size_t ncols, const DevTree& t) {
+      hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((ncols + 255) / 256), nq), dim3(256), 0, st, mat, m, P->lde_log, (u32)ncols, P->d_idx, P->d_qbuf, P->qstride, off);
+      off += ncols;
+      hipLaunchKernelGGL(gather_siblings_kernel, dim3(nq), dim3(128), 0, st, t.d, t.nleaf, nsib, P->d_idx, 0u, P->d_qbuf, P->qstride, off);
+      off += (size_t)nsib * 4;
+    };
+    initial(P->d_lde, C, P->tree_t);
+    if (Z) initial(P->d_zlde, Z, P->tree_z);
+    initial(P->d_qlde, 4, P->tree_q);
+    u32 bits = P->lde_log, shift = 0;
+    for (size_t li = 0; li < P->fri.arity_bits.size(); li++) {
+      u32 ab = P->fri.arity_bits[li];
+      shift += ab;
+      size_t len = (size_t)1 << bits;
+      hipLaunchKernelGGL(gather_fri_leaf_kernel, dim3(nq), dim3(64), 0, st, P->fri_vals[li], P->fri_vals[li] + len, bits, ab, P->d_idx, shift, P->d_qbuf, P->qstride, off);
+      off += 2 * ((size_t)1 << ab);
+      const DevTree& t = P->fri_trees[li];
+      hipLaunchKernelGGL(gather_siblings_kernel, dim3(nq), dim3(128), 0, st, t.d, t.nleaf, t.nlevels, P->d_idx, shift, P->d_qbuf, P->qstride, off);
+      off += (size_t)t.nlevels * 4;
+      bits -= ab;
+    }
+    HIPC(hipGetLastError());
+    if (off != P->qstride) return fail(SBN_ERR_HIP, "internal: query layout mismatch (%zu vs %zu)", off, P->qstride);
+    HIPC(hipMemcpyAsync(qwords.data(), P->d_qbuf, qwords.size() * sizeof(u64), hipMemcpyDeviceToHost, st));
+  }
+  HIPC(hipEventRecord(P->ev[ST_COUNT], st));
+  HIPC(hipStreamSynchronize(st));
+  for (int i = 0; i < ST_COUNT; i++) HIPC(hipEventElapsedTime(&P->stage_ms[i], P->ev[i], P->ev[i + 1]));
+
+  // assemble canonical proof words (layout: include/sbn.h) -----------------------------------------
+  sbn_proof* pr = new sbn_proof();
+  pr->degree_bits = P->degree_bits;
+  std::vector<u64>& w = pr->words;
+  w.reserve(12 + 3 * capw + open.size() + fri_caps.size() * capw + qwords.size() + final_poly.size() + 1 + P->pi.size());
+  u64 hdr[12] = {PROOF_MAGIC, P->degree_bits, C, Z, 4, P->pi.size(), cfg.cap_height, cfg.rate_bits, fri_caps.size(), cfg.fri_arity_bits,
+                 final_poly.size() / 2, nq};
+  w.insert(w.end(), hdr, hdr + 12);
+  w.insert(w.end(), trace_cap.begin(), trace_cap.end());
+  if (Z) w.insert(w.end(), z_cap.begin(), z_cap.end());
+  w.insert(w.end(), q_cap.begin(), q_cap.end());
+  for (size_t p = 0; p < C; p++) { w.push_back(open[4 * p]); w.push_back(open[4 * p + 1]); }          // local_values
+  for (size_t p = 0; p < C; p++) { w.push_back(open[4 * p + 2]); w.push_back(open[4 * p + 3]); }      // next_values
+  for (size_t p = C; p < C + Z; p++) { w.push_back(open[4 * p]); w.push_back(open[4 * p + 1]); }      // permutation_zs
+  for (size_t p = C; p < C + Z; p++) { w.push_back(open[4 * p + 2]); w.push_back(open[4 * p + 3]); }  // permutation_zs_next
+  for (size_t p = C + Z; p < C + Z + 4; p++) { w.push_back(open[4 * p]); w.push_back(open[4 * p + 1]); }  // quotient_polys
+  for (auto& cap : fri_caps) w.insert(w.end(), cap.begin(), cap.end());
+  w.insert(w.end(), qwords.begin(), qwords.end());
+  w.insert(w.end(), final_poly.begin(), final_poly.end());
+  w.push_back(pow_witness);
+  w.insert(w.end(), P->pi.begin(), P->pi.end());
+  *out = pr;
+  return SBN_OK;
+}
+
+// ---- building blocks for parity tests ---------------------------------------------------------------
+extern "C" int sbn_commit_values(const uint64_t* cols, size_t ncols, size_t n, uint32_t rate_bits, uint32_t cap_height, uint64_t* cap_out,
+                                 uint64_t* coeffs_out, uint64_t* lde_out) {
+  if (!cols || !cap_out || ncols == 0) return fail(SBN_ERR_BAD_ARG, "null argument");
+  if (rate_bits != 1 || n < 512 || (n & (n - 1))) return fail(SBN_ERR_UNSUPPORTED, "need rate_bits=1 and n a power of two >= 512");
+  u32 lg = 0; while (((size_t)1 << lg) < n) lg++;
+  // a throw-away prover-like context built on the G1_OP shape would waste memory; build a minimal one
+  sbn_prover P{};
+  sbn_standard_fast_config(&P.cfg); P.cfg.cap_height = cap_height;
+  P.degree_bits = lg; P.lde_log = lg + 1; P.n = n; P.m = 2 * n; P.ntt_chunk = 64; P.device = g_device;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(SBN_ERR_NO_DEVICE, "no HIP device available: no CPU fallback");
+  HIPC(hipSetDevice(g_device));
+  HIPC(hipStreamCreate(&P.stream));
+  u64 *d_vals = nullptr, *d_coef = nullptr, *d_lde = nullptr;
+  int rc = 0;
+  rc |= dmalloc(&d_vals, ncols * n); rc |= dmalloc(&d_coef, ncols * n); rc |= dmalloc(&d_lde, ncols * P.m); rc |= dmalloc(&P.d_tmp, 64 * P.m);
+  rc |= dmalloc(&P.d_tw_f, P.m / 2); rc |= dmalloc(&P.d_tw_i, P.m / 2); rc |= dmalloc(&P.d_shift, P.m);
+  rc |= tree_alloc(P.tree_t, P.m, cap_height);
+  if (!rc) {
+    auto blocks = [](size_t k) { return dim3((unsigned)((k + 255) / 256)); };
+    F w = f_root_of_unity(P.lde_log);
+    hipLaunchKernelGGL(pow_table_kernel, blocks(P.m / 2), dim3(256), 0, P.stream, P.d_tw_f, P.m / 2, w.v);
+    hipLaunchKernelGGL(pow_table_kernel, blocks(P.m / 2), dim3(256), 0, P.stream, P.d_tw_i, P.m / 2, f_inv(w).v);
+    hipLaunchKernelGGL(pow_table_kernel, blocks(P.m), dim3(256), 0, P.stream, P.d_shift, P.m, (u64)GL_GEN);
+    if (hipMemcpy(d_vals, cols, ncols * n * sizeof(u64), hipMemcpyHostToDevice) != hipSuccess) rc = fail(SBN_ERR_HIP, "H2D failed");
+  }
+  if (!rc) rc = intt_then_lde(&P, d_vals, d_coef, d_lde, ncols);
+  if (!rc) rc = tree_from_matrix(&P, P.tree_t, d_lde, ncols);
+  std::vector<u64> cap;
+  if (!rc) rc = tree_cap_to_host(&P, P.tree_t, cap);
+  if (!rc) memcpy(cap_out, cap.data(), cap.size() * sizeof(u64));
+  if (!rc && coeffs_out && hipMemcpy(coeffs_out, d_coef, ncols * n * sizeof(u64), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(SBN_ERR_HIP, "D2H failed");
+  if (!rc && lde_out && hipMemcpy(lde_out, d_lde, ncols * P.m * sizeof(u64), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(SBN_ERR_HIP, "D2H failed");
+  for (u64* b : {d_vals, d_coef, d_lde, P.d_tmp, P.d_tw_f, P.d_tw_i, P.d_shift, P.tree_t.d}) if (b) hipFree(b);
+  hipStreamDestroy(P.stream);
+  return rc;
+}
+
+extern "C" int sbn_poseidon_permute_batch(uint64_t* states, size_t count) {
+  if (!states) return fail(SBN_ERR_BAD_ARG, "null argument");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(SBN_ERR_NO_DEVICE, "no HIP device available: no CPU fallback");
+  HIPC(hipSetDevice(g_device));
+  for (size_t i = 0; i < count * 12; i++) if (states[i] >= GLP) return fail(SBN_ERR_NON_CANONICAL, "state word %zu is not canonical", i);
+  u64* d = nullptr;
+  HIPC(hipMalloc((void**)&d, count * 12 * sizeof(u64)));
+  HIPC(hipMemcpy(d, states, count * 12 * sizeof(u64), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(poseidon_batch_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, 0, d, count);
+  HIPC(hipMemcpy(states, d, count * 12 * sizeof(u64), hipMemcpyDeviceToHost));
+  hipFree(d);
+  return SBN_OK;
+}
+
+extern "C" int sbn_set_device(int device) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return fail(SBN_ERR_NO_DEVICE, "device %d not available", device);
+  g_device = device;
+  return SBN_OK;
+}
+extern "C" int sbn_device_count(void) { int n = 0; return hipGetDeviceCount(&n) == hipSuccess ? n : 0; }
