@@ -101,15 +101,17 @@ static inline GF sbox7(GF x) {
   return x4 * x3;
 }
 static inline void mds_layer(PState& s) {
-  // poseidon.rs `mds_row_shf`: out[r] = sum_i s[(i+r)%12]*CIRC[i] + s[r]*DIAG[r]
-  PState o;
+  // poseidon.rs `mds_row_shf`: out[r] = sum_i s[(i+r)%12]*CIRC[i] + s[r]*DIAG[r].
+  // The entries are < 2^6, so the 32-bit halves of the state are accumulated separately in u64
+  // (as plonky2's `mds_layer` does) and recombined with one 128-bit reduction per output.
+  u64 lo[24], hi[24];
+  for (int i = 0; i < 12; i++) { lo[i] = lo[i + 12] = s[i].v & 0xffffffffULL; hi[i] = hi[i + 12] = s[i].v >> 32; }
   for (int r = 0; r < 12; r++) {
-    u128 acc = 0;
-    for (int i = 0; i < 12; i++) acc += (u128)s[(i + r) % 12].v * MDS_CIRC[i];
-    acc += (u128)s[r].v * MDS_DIAG[r];
-    o[r].v = gl_reduce128(acc);
+    u64 sl = 0, sh = 0;
+    for (int i = 0; i < 12; i++) { sl += lo[i + r] * MDS_CIRC[i]; sh += hi[i + r] * MDS_CIRC[i]; }
+    sl += lo[r] * MDS_DIAG[r]; sh += hi[r] * MDS_DIAG[r];
+    s[r].v = gl_reduce128((u128)sl + ((u128)sh << 32));
   }
-  s = o;
 }
 // poseidon.rs `Poseidon::poseidon` (naive form).
 static inline void poseidon_permute(PState& s) {

@@ -10,6 +10,9 @@
 #include "fri.hpp"
 #include <memory>
 #include <string>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 
 namespace orc {
 
@@ -142,6 +145,16 @@ static inline FriOpenings to_fri_openings(const StarkOpeningSet& o) {
   return f;
 }
 
+struct StageTimer {  // ORC_TIMING=1 prints per-stage wall time to stderr
+  bool on; std::chrono::steady_clock::time_point t;
+  StageTimer() : on(getenv("ORC_TIMING") != nullptr), t(std::chrono::steady_clock::now()) {}
+  void lap(const char* name) {
+    auto n = std::chrono::steady_clock::now();
+    if (on) fprintf(stderr, "[oracle] %-22s %8.3f s\n", name, std::chrono::duration<double>(n - t).count());
+    t = n;
+  }
+};
+
 struct ProveStages {  // optional per-stage outputs for parity tests
   std::vector<PermChallengeSet> perm_sets;
   std::vector<GF> alphas;
@@ -159,7 +172,9 @@ static inline StarkProofWithPublicInputs prove(const Air& air, const StarkConfig
   assert(fp.total_arities() <= degree_bits + rate_bits - cap_height);
   assert(trace.size() == air.num_columns() && public_inputs.size() == air.num_public_inputs());
 
+  StageTimer tm;
   PolynomialBatch trace_commitment = PolynomialBatch::from_values(trace, rate_bits, cap_height);
+  tm.lap("trace commitment");
   Challenger ch;
   ch.observe_cap(trace_commitment.tree.cap());
 
@@ -174,7 +189,9 @@ static inline StarkProofWithPublicInputs prove(const Air& air, const StarkConfig
     std::vector<std::vector<GF>> zs(batches.size());
 #pragma omp parallel for schedule(dynamic, 4)
     for (size_t i = 0; i < batches.size(); i++) zs[i] = compute_permutation_z_poly(batches[i], trace);
+    tm.lap("permutation z polys");
     zs_commitment = PolynomialBatch::from_values(zs, rate_bits, cap_height);
+    tm.lap("z commitment");
     ch.observe_cap(zs_commitment.tree.cap());
   }
   std::vector<GF> alphas;
@@ -225,6 +242,7 @@ static inline StarkProofWithPublicInputs prove(const Air& air, const StarkConfig
     GF dinv = zh_inv[i % zh_inv.size()];
     for (size_t j = 0; j < nch; j++) qvals[j][i] = cons.acc[j] * dinv;
   }
+  tm.lap("quotient evaluation");
   std::vector<std::vector<GF>> quotient_chunks;
   for (size_t j = 0; j < nch; j++) {
     std::vector<GF> coeffs = coset_ifft(qvals[j], GF(GL_GENERATOR));
@@ -234,6 +252,7 @@ static inline StarkProofWithPublicInputs prove(const Air& air, const StarkConfig
   }
   PolynomialBatch quotient_commitment = PolynomialBatch::from_coeffs(quotient_chunks, rate_bits, cap_height);
   ch.observe_cap(quotient_commitment.tree.cap());
+  tm.lap("quotient commitment");
 
   Ext zeta = ch.get_ext_challenge();
   GF g = gf_root_of_unity(degree_bits);
@@ -265,12 +284,14 @@ static inline StarkProofWithPublicInputs prove(const Air& air, const StarkConfig
   os.quotient_polys = eval_commitment(zeta, quotient_commitment);
   FriOpenings fo = to_fri_openings(os);
   for (auto& b : fo.batches) for (auto& e : b) ch.observe(e);
+  tm.lap("openings");
 
   std::vector<const PolynomialBatch*> oracles;
   oracles.push_back(&trace_commitment);
   if (uses_perm) oracles.push_back(&zs_commitment);
   oracles.push_back(&quotient_commitment);
   out.proof.opening_proof = prove_openings(stark_fri_instance(air, cfg, zeta, g), oracles, ch, fp);
+  tm.lap("fri (prove_openings)");
   out.proof.trace_cap = trace_commitment.tree.cap();
   if (uses_perm) out.proof.permutation_zs_cap = zs_commitment.tree.cap();
   out.proof.quotient_polys_cap = quotient_commitment.tree.cap();

@@ -13,7 +13,13 @@
 typedef uint64_t u64;
 typedef uint32_t u32;
 
+// Forced inlining only in device code: on the host the same templates are instantiated over E2 for the
+// verifier, where forced inlining of the whole constraint tree costs minutes of compile time.
+#if defined(__HIP_DEVICE_COMPILE__)
 #define GL_HD __host__ __device__ __forceinline__
+#else
+#define GL_HD __host__ __device__ inline
+#endif
 
 static constexpr u64 GLP = 0xFFFFFFFF00000001ULL;
 static constexpr u64 GLEPS = 0xFFFFFFFFULL;

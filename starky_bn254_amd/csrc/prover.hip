@@ -20,12 +20,14 @@ namespace sbn { thread_local std::string g_last_error; }
 
 static int g_device = 0;
 
+// Stage k spans [ev[k], ev[k+1]) on the prover's stream.  "*_leaf_hash" stages contain exactly one
+// leaf_hash_kernel launch (the dominant kernel), so their time is that kernel's launch duration.
 enum Stage {
-  ST_TRACE_NTT, ST_TRACE_HASH, ST_PERM_Z, ST_Z_NTT, ST_Z_HASH, ST_QUOTIENT_EVAL, ST_QUOTIENT_COMMIT,
+  ST_TRACE_NTT, ST_TRACE_LEAF, ST_TRACE_TREE, ST_PERM_Z, ST_Z_NTT, ST_Z_LEAF, ST_Z_TREE, ST_QUOTIENT_EVAL, ST_QUOTIENT_COMMIT,
   ST_OPENINGS, ST_FRI_COMBINE, ST_FRI_LAYERS, ST_POW, ST_QUERIES, ST_COUNT
 };
 static const char* STAGE_NAMES[ST_COUNT] = {
-  "trace_ntt", "trace_hash", "perm_z", "z_ntt", "z_hash", "quotient_eval", "quotient_commit",
+  "trace_ntt", "trace_leaf_hash", "trace_tree", "perm_z", "z_ntt", "z_leaf_hash", "z_tree", "quotient_eval", "quotient_commit",
   "openings", "fri_combine", "fri_layers", "pow", "queries"};
 
 struct DevTree {  // Merkle digests, levels concatenated (leaf level first)
@@ -160,8 +162,9 @@ static int tree_build_inner(sbn_prover* P, DevTree& t) {
   HIPC(hipGetLastError());
   return 0;
 }
-static int tree_from_matrix(sbn_prover* P, DevTree& t, const u64* lde, size_t ncols) {
+static int tree_from_matrix(sbn_prover* P, DevTree& t, const u64* lde, size_t ncols, int ev_after_leaf = -1) {
   hipLaunchKernelGGL(leaf_hash_kernel, dim3((unsigned)((P->m + 255) / 256)), dim3(256), 0, P->stream, lde, P->m, P->lde_log, (u32)ncols, t.d);
+  if (ev_after_leaf >= 0) HIPC(hipEventRecord(P->ev[ev_after_leaf], P->stream));
   return tree_build_inner(P, t);
 }
 static int tree_cap_to_host(sbn_prover* P, const DevTree& t, std::vector<u64>& cap) {
@@ -331,8 +334,8 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
   // P1 trace commitment ---------------------------------------------------------------------------
   HIPC(hipEventRecord(P->ev[ST_TRACE_NTT], st));
   if ((rc = intt_then_lde(P, P->d_trace, P->d_coef, P->d_lde, C))) return rc;
-  HIPC(hipEventRecord(P->ev[ST_TRACE_HASH], st));
-  if ((rc = tree_from_matrix(P, P->tree_t, P->d_lde, C))) return rc;
+  HIPC(hipEventRecord(P->ev[ST_TRACE_LEAF], st));
+  if ((rc = tree_from_matrix(P, P->tree_t, P->d_lde, C, ST_TRACE_TREE))) return rc;
   HIPC(hipEventRecord(P->ev[ST_PERM_Z], st));
   if ((rc = tree_cap_to_host(P, P->tree_t, trace_cap))) return rc;
   ch.observe_words(trace_cap.data(), capw);
@@ -346,8 +349,8 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
   HIPC(hipGetLastError());
   HIPC(hipEventRecord(P->ev[ST_Z_NTT], st));
   if ((rc = intt_then_lde(P, P->d_zval, P->d_zcoef, P->d_zlde, Z))) return rc;
-  HIPC(hipEventRecord(P->ev[ST_Z_HASH], st));
-  if ((rc = tree_from_matrix(P, P->tree_z, P->d_zlde, Z))) return rc;
+  HIPC(hipEventRecord(P->ev[ST_Z_LEAF], st));
+  if ((rc = tree_from_matrix(P, P->tree_z, P->d_zlde, Z, ST_Z_TREE))) return rc;
   HIPC(hipEventRecord(P->ev[ST_QUOTIENT_EVAL], st));
   if ((rc = tree_cap_to_host(P, P->tree_z, z_cap))) return rc;
   ch.observe_words(z_cap.data(), capw);
@@ -500,7 +503,7 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
     for (int i = 0; i < 12; i++) pp.state[i] = ch.st[i].v;
     for (size_t i = 0; i < ch.in.size(); i++) pp.state[i] = ch.in[i].v;
     pp.wpos = (u32)ch.in.size(); pp.min_lz = cfg.proof_of_work_bits; pp.result = P->d_pow;
-    const u64 BATCH = 1ULL << 22;
+    const u64 BATCH = 1ULL << 20;
     for (u64 base = 0; pow_witness == ~0ULL; base += BATCH) {
       if (base >= GLP - BATCH) return fail(SBN_ERR_HIP, "proof of work failed");
       u64 init = ~0ULL;

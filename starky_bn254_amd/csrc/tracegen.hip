@@ -1,5 +1,420 @@
-// placeholder, replaced below
+// Host witness generation for the G1 tables: replaces G1ExpStark::generate_trace /
+// generate_public_inputs (src/curves/g1/exp.rs:255-327) and G1Stark::generate_trace
+// (src/curves/g1/muladd.rs:481-546), which the reference runs serially with arkworks + num-bigint.
+//
+// Native design (independent of the test oracle's restatement):
+//  * Fq in 4x64 Montgomery form; all instances advance in LOCKSTEP so the affine-slope divisions of
+//    one row step are served by ONE field inversion (Montgomery's batch trick; binary extended GCD).
+//  * new_x / new_y come from the curve formulas in Fq; the signed quotient of each modular gadget is
+//    an exact division by p done limb-by-limb from the low end (Hensel), no big-integer division.
+//  * pulse witnesses 1/(row - pos) are table lookups into inv[1..N) (one batch inversion per trace).
+//  * range-check columns use a counting sort (values < 2^16) and the reference's merge
+//    (src/utils/lookup.rs:60-111) to place unused table values.
 #include "host_common.hpp"
+#include <thread>
+#include <atomic>
+#include <cstring>
+#include <functional>
+
 using namespace sbn;
-extern "C" int sbn_generate_trace_g1_exp(const uint32_t*, size_t, uint64_t*, uint64_t*) { return fail(SBN_ERR_UNSUPPORTED, "not built yet"); }
-extern "C" int sbn_generate_trace_g1_op(const uint32_t*, size_t, uint64_t*) { return fail(SBN_ERR_UNSUPPORTED, "not built yet"); }
+typedef unsigned __int128 u128;
+
+namespace {
+
+// ---- Fq ---------------------------------------------------------------------------------------------
+struct Fq { u64 l[4]; };
+const u64 PL[4] = {0x3c208c16d87cfd47ULL, 0x97816a916871ca8dULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
+
+inline bool geq_p(const u64* a) {
+  for (int i = 3; i >= 0; i--) { if (a[i] != PL[i]) return a[i] > PL[i]; }
+  return true;
+}
+inline u64 add4(u64* r, const u64* a, const u64* b) { u128 c = 0; for (int i = 0; i < 4; i++) { c += (u128)a[i] + b[i]; r[i] = (u64)c; c >>= 64; } return (u64)c; }
+inline u64 sub4(u64* r, const u64* a, const u64* b) {
+  u64 br = 0;
+  for (int i = 0; i < 4; i++) { u128 t = (u128)a[i] - b[i] - br; r[i] = (u64)t; br = (u64)(t >> 64) & 1; }
+  return br;
+}
+struct Ctx {
+  u64 n0inv; Fq r2, one_m;
+  Ctx() {
+    u64 inv = 1; for (int i = 0; i < 6; i++) inv *= 2 - PL[0] * inv;
+    n0inv = 0 - inv;
+    u64 x[4] = {1, 0, 0, 0};
+    for (int i = 0; i < 512; i++) {
+      u64 d[4]; u64 c = add4(d, x, x);
+      if (c || geq_p(d)) sub4(d, d, PL);
+      memcpy(x, d, 32);
+      if (i == 255) memcpy(one_m.l, x, 32);
+    }
+    memcpy(r2.l, x, 32);
+  }
+};
+const Ctx& ctx() { static const Ctx c; return c; }
+
+inline Fq mmul(const Fq& a, const Fq& b) {
+  const u64 n0 = ctx().n0inv;
+  u64 t[5] = {0, 0, 0, 0, 0};
+  for (int i = 0; i < 4; i++) {
+    u128 c = 0; u64 hi;
+    for (int j = 0; j < 4; j++) { c += (u128)a.l[j] * b.l[i] + t[j]; t[j] = (u64)c; c >>= 64; }
+    c += t[4]; t[4] = (u64)c; hi = (u64)(c >> 64);
+    u64 mq = t[0] * n0;
+    c = ((u128)mq * PL[0] + t[0]) >> 64;
+    for (int j = 1; j < 4; j++) { c += (u128)mq * PL[j] + t[j]; t[j - 1] = (u64)c; c >>= 64; }
+    c += t[4]; t[3] = (u64)c; t[4] = hi + (u64)(c >> 64);
+  }
+  Fq r; memcpy(r.l, t, 32);
+  if (t[4] || geq_p(r.l)) sub4(r.l, r.l, PL);
+  return r;
+}
+inline Fq to_m(const u64* x) { Fq a; memcpy(a.l, x, 32); return mmul(a, ctx().r2); }
+inline void from_m(const Fq& a, u64* out) { Fq o = {{1, 0, 0, 0}}; Fq r = mmul(a, o); memcpy(out, r.l, 32); }
+inline Fq fadd(const Fq& a, const Fq& b) { Fq r; u64 c = add4(r.l, a.l, b.l); if (c || geq_p(r.l)) sub4(r.l, r.l, PL); return r; }
+inline Fq fsub(const Fq& a, const Fq& b) { Fq r; if (sub4(r.l, a.l, b.l)) add4(r.l, r.l, PL); return r; }
+inline bool fzero(const Fq& a) { return !(a.l[0] | a.l[1] | a.l[2] | a.l[3]); }
+
+// Inverse of a standard-form value via binary extended GCD; returns standard form (value < p, nonzero).
+void inv_std(const u64* a_in, u64* out) {
+  u64 u[4], v[4], x1[4] = {1, 0, 0, 0}, x2[4] = {0, 0, 0, 0};
+  memcpy(u, a_in, 32); memcpy(v, PL, 32);
+  auto is_one = [](const u64* a) { return a[0] == 1 && !(a[1] | a[2] | a[3]); };
+  auto shr1 = [](u64* a, u64 top) { for (int i = 0; i < 3; i++) a[i] = (a[i] >> 1) | (a[i + 1] << 63); a[3] = (a[3] >> 1) | (top << 63); };
+  auto halve = [&](u64* x) { if (x[0] & 1) { u64 c = add4(x, x, PL); shr1(x, c); } else shr1(x, 0); };
+  auto geq = [](const u64* a, const u64* b) { for (int i = 3; i >= 0; i--) if (a[i] != b[i]) return a[i] > b[i]; return true; };
+  while (!is_one(u) && !is_one(v)) {
+    while (!(u[0] & 1)) { shr1(u, 0); halve(x1); }
+    while (!(v[0] & 1)) { shr1(v, 0); halve(x2); }
+    if (geq(u, v)) { sub4(u, u, v); if (sub4(x1, x1, x2)) add4(x1, x1, PL); }
+    else { sub4(v, v, u); if (sub4(x2, x2, x1)) add4(x2, x2, PL); }
+  }
+  memcpy(out, is_one(u) ? x1 : x2, 32);
+}
+// Batch inversion of Montgomery-form elements (all nonzero), in place.
+void batch_inv(std::vector<Fq>& v) {
+  size_t n = v.size(); if (!n) return;
+  std::vector<Fq> pre(n);
+  Fq acc = ctx().one_m;
+  for (size_t i = 0; i < n; i++) { pre[i] = acc; acc = mmul(acc, v[i]); }
+  u64 s[4], si[4]; from_m(acc, s); inv_std(s, si);
+  Fq inv = to_m(si);
+  for (size_t i = n; i-- > 0;) { Fq t = v[i]; v[i] = mmul(inv, pre[i]); inv = mmul(inv, t); }
+}
+
+inline void limbs16(const u64* x, int64_t* out) { for (int i = 0; i < 16; i++) out[i] = (int64_t)((x[i / 4] >> (16 * (i % 4))) & 0xffff); }
+
+// ---- modular gadget witness (src/modular/modular.rs:38-100, modular_zero.rs:33-80) -----------------------
+struct ModW { int64_t quot_abs[17]; int sign; int64_t aux_lo[31], aux_hi[31]; int64_t out_aux_red[16]; };
+
+const int64_t* modulus_limbs() { static int64_t m[16]; static bool init = (limbs16(PL, m), true); (void)init; return m; }
+
+// pol_input: 31 signed coefficients; output: value of the gadget's output (standard form, < p; zero for mod-zero).
+bool mod_witness(const int64_t* pol_input, const u64* output, bool has_output, ModW& w) {
+  const int64_t* ml = modulus_limbs();
+  // d = P(2^16) - output as 9-limb two's complement
+  u64 d[9] = {0};
+  for (int i = 0; i < 31; i++) {
+    int64_t c = pol_input[i];
+    unsigned sh = 16 * i, ls = sh / 64, bs = sh % 64;
+    u64 ext = c < 0 ? ~0ULL : 0;
+    u128 carry = 0;
+    for (unsigned k = ls; k < 9; k++) {
+      unsigned q = k - ls;
+      u64 cur = q == 0 ? (u64)c : ext, prev = q == 0 ? 0 : (q == 1 ? (u64)c : ext);
+      u64 word = bs ? ((cur << bs) | (q ? (prev >> (64 - bs)) : 0)) : cur;
+      carry += (u128)d[k] + word; d[k] = (u64)carry; carry >>= 64;
+    }
+  }
+  if (has_output) {
+    u64 br = 0;
+    for (int k = 0; k < 9; k++) { u64 o = k < 4 ? output[k] : 0; u128 t = (u128)d[k] - o - br; d[k] = (u64)t; br = (u64)(t >> 64) & 1; }
+  }
+  // exact division by p, low limb first: q_i = d_i * p^-1 mod 2^64 ; d -= q_i * p << 64 i
+  const u64 pinv = 0 - ctx().n0inv;
+  u64 q[5];
+  for (int i = 0; i < 5; i++) {
+    q[i] = d[i] * pinv;
+    u128 br = 0;
+    for (int j = 0; j < 4 && i + j < 9; j++) {
+      u128 prod = (u128)q[i] * PL[j] + br;
+      u64 lo = (u64)prod; br = prod >> 64;
+      if (d[i + j] < lo) br += 1;
+      d[i + j] -= lo;
+    }
+    for (int k = i + 4; k < 9 && br; k++) { u64 b = (u64)br; br = d[k] < b ? 1 : 0; d[k] -= b; }
+  }
+  // remaining high limbs: 0 if q >= 0, or -(p << 320) if q < 0 (q is two's complement in 320 bits)
+  bool neg = q[4] >> 63;
+  {
+    u64 exp[4] = {0, 0, 0, 0};
+    if (neg) { u64 z[4] = {0, 0, 0, 0}; sub4(exp, z, PL); }
+    for (int k = 0; k < 5; k++) if (d[k]) return false;
+    for (int k = 0; k < 4; k++) if (d[5 + k] != exp[k]) return false;  // input was not congruent to output mod p
+  }
+  if (neg) { u128 c = 1; for (int i = 0; i < 5; i++) { c += (u64)~q[i]; q[i] = (u64)c; c >>= 64; } }
+  w.sign = neg ? -1 : 1;
+  for (int i = 0; i < 17; i++) w.quot_abs[i] = (int64_t)((q[i / 4] >> (16 * (i % 4))) & 0xffff);
+  for (int i = 17; i < 20; i++) if ((q[i / 4] >> (16 * (i % 4))) & 0xffff) return false;
+  int64_t outl[16] = {0};
+  if (has_output) {
+    limbs16(output, outl);
+    u64 t[4]; sub4(t, output, PL);  // 2^256 - p + output
+    limbs16(t, w.out_aux_red);
+  }
+  int64_t constr[32];
+  for (int i = 0; i < 31; i++) constr[i] = pol_input[i];
+  constr[31] = 0;
+  for (int i = 0; i < 16; i++) constr[i] -= outl[i];
+  for (int i = 0; i < 17; i++) { int64_t qi = w.sign * w.quot_abs[i]; if (qi) for (int j = 0; j < 16; j++) constr[i + j] -= qi * ml[j]; }
+  int64_t prev = 0;
+  for (int k = 0; k < 31; k++) {
+    int64_t a = k == 0 ? -(constr[0] >> 16) : (prev - constr[k]) >> 16;  // pol_remove_root_2exp
+    prev = a;
+    int64_t s = a + (1 << 29);
+    if (s < 0 || s > (1 << 30)) return false;
+    w.aux_lo[k] = s & 0xffff; w.aux_hi[k] = (s >> 16) & 0xffff;
+  }
+  return true;
+}
+
+inline void conv16(const int64_t* a, const int64_t* b, int64_t* out) {
+  for (int k = 0; k < 31; k++) out[k] = 0;
+  for (int i = 0; i < 16; i++) for (int j = 0; j < 16; j++) out[i + j] += a[i] * b[j];
+}
+
+// Writes the 320 G1Output columns (muladd.rs:79-94) for one add / double given lambda (standard form).
+bool g1_output_row(bool is_double, const u64* ax, const u64* ay, const u64* bx, const u64* by, const u64* lam, const u64* nx, const u64* ny, u64* lv) {
+  int64_t l[16], axl[16], ayl[16], bxl[16], byl[16], nxl[16], t16[16], c[31], zero_pol[31], inx[31], iny[31];
+  limbs16(lam, l); limbs16(ax, axl); limbs16(ay, ayl); limbs16(nx, nxl);
+  if (is_double) { memcpy(bxl, axl, sizeof axl); memcpy(byl, ayl, sizeof ayl); } else { limbs16(bx, bxl); limbs16(by, byl); }
+  if (is_double) {
+    conv16(l, ayl, zero_pol); for (int k = 0; k < 31; k++) zero_pol[k] *= 2;
+    conv16(axl, axl, c); for (int k = 0; k < 31; k++) zero_pol[k] -= 3 * c[k];
+  } else {
+    for (int i = 0; i < 16; i++) t16[i] = bxl[i] - axl[i];
+    conv16(l, t16, zero_pol); for (int i = 0; i < 16; i++) zero_pol[i] -= byl[i] - ayl[i];
+  }
+  conv16(l, l, inx); for (int i = 0; i < 16; i++) inx[i] -= axl[i] + bxl[i];
+  for (int i = 0; i < 16; i++) t16[i] = axl[i] - nxl[i];
+  conv16(l, t16, iny); for (int i = 0; i < 16; i++) iny[i] -= ayl[i];
+  ModW wz, wx, wy;
+  if (!mod_witness(zero_pol, nullptr, false, wz) || !mod_witness(inx, nx, true, wx) || !mod_witness(iny, ny, true, wy)) return false;
+  int cur = 0;
+  auto put16 = [&](const int64_t* v) { for (int i = 0; i < 16; i++) lv[cur++] = (u64)v[i]; };
+  int64_t nyl[16]; limbs16(ny, nyl);
+  put16(l); put16(nxl); put16(nyl);
+  auto put_aux = [&](const ModW& w, bool oar) {
+    if (oar) put16(w.out_aux_red);
+    for (int i = 0; i < 17; i++) lv[cur++] = (u64)w.quot_abs[i];
+    for (int i = 0; i < 31; i++) lv[cur++] = (u64)w.aux_lo[i];
+    for (int i = 0; i < 31; i++) lv[cur++] = (u64)w.aux_hi[i];
+  };
+  put_aux(wz, false); put_aux(wx, true); put_aux(wy, true);
+  lv[cur++] = wz.sign > 0 ? 1 : GLP - 1; lv[cur++] = wx.sign > 0 ? 1 : GLP - 1; lv[cur++] = wy.sign > 0 ? 1 : GLP - 1;
+  return cur == 320;
+}
+
+void parallel_for(size_t n, const std::function<void(size_t)>& f) {
+  unsigned nt = std::thread::hardware_concurrency(); if (nt == 0) nt = 4; if (nt > 32) nt = 32;
+  if (nt > n) nt = (unsigned)n;
+  if (nt <= 1) { for (size_t i = 0; i < n; i++) f(i); return; }
+  std::atomic<size_t> next(0);
+  std::vector<std::thread> th;
+  for (unsigned t = 0; t < nt; t++) th.emplace_back([&] { for (size_t i; (i = next.fetch_add(1)) < n;) f(i); });
+  for (auto& t : th) t.join();
+}
+
+// permuted_cols (lookup.rs:60-111) for values < range (counting sort); table = 0..range-1 then range-1 repeated.
+void permuted_cols_u(const u64* col, size_t n, u32 range, u64* sorted_out, u64* perm_table_out) {
+  std::vector<u32> hist(range, 0);
+  for (size_t i = 0; i < n; i++) hist[col[i]]++;
+  { size_t k = 0; for (u32 v = 0; v < range; v++) for (u32 c = 0; c < hist[v]; c++) sorted_out[k++] = v; }
+  auto table_at = [&](size_t j) -> u64 { return j < range ? j : range - 1; };
+  std::vector<size_t> unused_inds; std::vector<u64> unused_vals;
+  size_t i = 0, j = 0;
+  while (j < n && i < n) {
+    u64 iv = sorted_out[i], tv = table_at(j);
+    if (iv > tv) { unused_vals.push_back(tv); j++; }
+    else if (iv < tv) { if (!unused_vals.empty()) { perm_table_out[i] = unused_vals.back(); unused_vals.pop_back(); } else unused_inds.push_back(i); i++; }
+    else { perm_table_out[i] = tv; i++; j++; }
+  }
+  for (; j < n; j++) unused_vals.push_back(table_at(j));
+  for (; i < n; i++) unused_inds.push_back(i);
+  for (size_t k = 0; k < unused_inds.size(); k++) perm_table_out[unused_inds[k]] = unused_vals[k];
+}
+
+inline void from_u32(const uint32_t* w, u64* out) { for (int i = 0; i < 4; i++) out[i] = (u64)w[2 * i] | ((u64)w[2 * i + 1] << 32); }
+inline void put_limbs(u64* dst, size_t stride, const u64* v) { for (int i = 0; i < 16; i++) dst[i * stride] = (v[i / 4] >> (16 * (i % 4))) & 0xffff; }
+
+// Goldilocks inverses of 1..n-1 (batch).
+std::vector<u64> small_inverses(size_t n) {
+  std::vector<u64> pre(n), inv(n);
+  F acc(1);
+  for (size_t k = 1; k < n; k++) { pre[k] = acc.v; acc = acc * F(k); }
+  F ia = f_inv(acc);
+  for (size_t k = n; k-- > 1;) { inv[k] = (ia * F(pre[k])).v; ia = ia * F(k); }
+  inv[0] = 0;
+  return inv;
+}
+
+}  // namespace
+
+extern "C" int sbn_generate_trace_g1_exp(const uint32_t* ios, size_t num_io, uint64_t* trace, uint64_t* pi_out) {
+  if (!ios || !trace || !pi_out || num_io == 0 || num_io > (size_t)G1EXP_MAX_IO) return fail(SBN_ERR_BAD_ARG, "bad arguments");
+  const G1ExpShape sh((int)num_io);
+  const size_t RPB = 512, n = RPB * num_io;
+  if (n < 65536) return fail(SBN_ERR_UNSUPPORTED, "G1_EXP needs >= 2^16 rows (u16 range check, range_check.rs:26)");
+  const int sf = sh.start_flags;
+  auto col = [&](int c) { return trace + (size_t)c * n; };
+  memset(trace, 0, (size_t)sh.num_cols * n * sizeof(u64));
+  // --- flags columns (flags.rs:46-134), per instance, closed form per row
+  for (size_t k = 0; k < num_io; k++) {
+    const uint32_t* e = ios + 40 * k + 32;
+    u64 limbs[8]; for (int i = 0; i < 8; i++) limbs[i] = e[i];
+    u64 bit = limbs[0] & 1; limbs[0] >>= 1;  // first row
+    for (size_t r = 0; r < RPB; r++) {
+      size_t row = k * RPB + r;
+      u64 a = r & 1, b = 1 - a;
+      col(sf)[row] = r == RPB - 1; col(sf + 1)[row] = (r % 64) == 62;
+      col(sf + 2)[row] = a; col(sf + 3)[row] = b; col(sf + 4)[row] = bit * b; col(sf + 5)[row] = bit;
+      for (int i = 0; i < 8; i++) col(sf + 6 + i)[row] = limbs[i];
+      // transition to row r+1
+      bool split = a == 1, rotate = (r % 64) == 62;
+      if (split) { bit = limbs[0] & 1; limbs[0] >>= 1; }
+      if (rotate) { for (int i = 0; i < 7; i++) limbs[i] = limbs[i + 1]; limbs[7] = 0; }
+    }
+  }
+  // --- curve state in lockstep over the instances (exp.rs:165-230)
+  std::vector<Fq> ax(num_io), ay(num_io), bx(num_io), by(num_io), lam(num_io), nx(num_io), ny(num_io);
+  std::vector<char> active(num_io), was_double(num_io, 0), had_op(num_io, 0);
+  for (size_t k = 0; k < num_io; k++) {
+    u64 t[4];
+    from_u32(ios + 40 * k, t); if (geq_p(t)) return fail(SBN_ERR_BAD_ARG, "x.x >= p"); ax[k] = to_m(t);
+    from_u32(ios + 40 * k + 8, t); if (geq_p(t)) return fail(SBN_ERR_BAD_ARG, "x.y >= p"); ay[k] = to_m(t);
+    from_u32(ios + 40 * k + 16, t); if (geq_p(t)) return fail(SBN_ERR_BAD_ARG, "offset.x >= p"); bx[k] = to_m(t);
+    from_u32(ios + 40 * k + 24, t); if (geq_p(t)) return fail(SBN_ERR_BAD_ARG, "offset.y >= p"); by[k] = to_m(t);
+  }
+  std::atomic<int> bad(0);
+  std::vector<Fq> den;
+  std::vector<u64> std_vals(num_io * 28);  // per instance: ax ay bx by lam nx ny (standard form)
+  for (size_t r = 0; r < RPB; r++) {
+    const bool dbl = r & 1;
+    // apply the previous row's result to the state
+    if (r > 0) for (size_t k = 0; k < num_io; k++) if (had_op[k]) { if (was_double[k]) { ax[k] = nx[k]; ay[k] = ny[k]; } else { bx[k] = nx[k]; by[k] = ny[k]; } }
+    den.clear();
+    for (size_t k = 0; k < num_io; k++) {
+      active[k] = dbl ? 1 : (char)col(sf + 4)[k * RPB + r];
+      if (active[k]) { Fq d = dbl ? fadd(ay[k], ay[k]) : fsub(bx[k], ax[k]); if (fzero(d)) return fail(SBN_ERR_WITNESS, "degenerate affine operation (instance %zu, row %zu)", k, r); den.push_back(d); }
+    }
+    batch_inv(den);
+    size_t di = 0;
+    for (size_t k = 0; k < num_io; k++) {
+      had_op[k] = active[k]; was_double[k] = dbl;
+      if (!active[k]) continue;
+      Fq num;
+      if (dbl) { Fq x2 = mmul(ax[k], ax[k]); num = fadd(fadd(x2, x2), x2); } else num = fsub(by[k], ay[k]);
+      lam[k] = mmul(num, den[di++]);
+      Fq l2 = mmul(lam[k], lam[k]);
+      nx[k] = dbl ? fsub(fsub(l2, ax[k]), ax[k]) : fsub(fsub(l2, ax[k]), bx[k]);
+      ny[k] = fsub(mmul(lam[k], fsub(ax[k], nx[k])), ay[k]);
+    }
+    for (size_t k = 0; k < num_io; k++) {
+      u64* s = &std_vals[k * 28];
+      from_m(ax[k], s); from_m(ay[k], s + 4); from_m(bx[k], s + 8); from_m(by[k], s + 12);
+      if (active[k]) { from_m(lam[k], s + 16); from_m(nx[k], s + 20); from_m(ny[k], s + 24); }
+    }
+    parallel_for(num_io, [&](size_t k) {
+      size_t row = k * RPB + r;
+      const u64* s = &std_vals[k * 28];
+      put_limbs(col(0) + row, n, s); put_limbs(col(16) + row, n, s + 4); put_limbs(col(32) + row, n, s + 8); put_limbs(col(48) + row, n, s + 12);
+      u64 lv[320];
+      if (active[k]) {
+        if (!g1_output_row(dbl, s, s + 4, s + 8, s + 12, s + 16, s + 20, s + 24, lv)) { bad = 1; return; }
+      } else {  // G1Output::default (muladd.rs:61-75)
+        for (int i = 0; i < 317; i++) lv[i] = 0;
+        lv[317] = lv[318] = lv[319] = 1;
+      }
+      for (int c = 0; c < 320; c++) col(64 + c)[row] = lv[c];
+    });
+    if (bad) return fail(SBN_ERR_WITNESS, "modular witness generation failed at row step %zu", r);
+  }
+  // --- public inputs (exp.rs:124-135, 320-327): x.x x.y off.x off.y exp_val out.x out.y as u32 limbs
+  for (size_t k = 0; k < num_io; k++) {
+    u64* p = pi_out + 56 * k;
+    for (int i = 0; i < 32; i++) p[i] = ios[40 * k + i];
+    for (int i = 0; i < 8; i++) p[32 + i] = ios[40 * k + 32 + i];
+    u64 ox[4], oy[4]; from_m(bx[k], ox); from_m(by[k], oy);  // b at the last row
+    for (int i = 0; i < 8; i++) { p[40 + i] = (ox[i / 2] >> (32 * (i % 2))) & 0xffffffffULL; p[48 + i] = (oy[i / 2] >> (32 * (i % 2))) & 0xffffffffULL; }
+  }
+  // --- periodic pulse (pulse.rs:100-144): counter starts at 1, period 64; witness = 1/(counter-63)
+  std::vector<u64> inv = small_inverses(n);
+  {
+    u64* cnt = col(sh.start_periodic); u64* wit = col(sh.start_periodic + 1);
+    for (size_t i = 0; i < n; i++) { u64 c = (i + 1) % 64; cnt[i] = c; wit[i] = c == 63 ? 0 : (-F(inv[63 - c])).v; }
+  }
+  // --- io pulses (pulse.rs:20-43): counter, then (witness, pulse) per position
+  {
+    u64* cnt = col(sh.start_io_pulses);
+    for (size_t i = 0; i < n; i++) cnt[i] = i;
+    parallel_for(2 * num_io, [&](size_t q) {
+      size_t pos = (q >> 1) * RPB + ((q & 1) ? RPB - 1 : 0);
+      u64* wit = col(sh.witness_col((int)q)); u64* pul = col(sh.pulse_col((int)q));
+      for (size_t i = 0; i < n; i++) wit[i] = i > pos ? inv[i - pos] : (i < pos ? (-F(inv[pos - i])).v : 0);
+      pul[pos] = 1;
+    });
+  }
+  // --- u16 range check (range_check.rs:20-47)
+  {
+    u64* table = col(sh.start_lookups);
+    for (size_t i = 0; i < n; i++) table[i] = i < 65536 ? i : 65535;
+    parallel_for((size_t)sh.num_rc, [&](size_t k) {
+      const u64* c = col((int)k);
+      for (size_t i = 0; i < n; i++) if (c[i] >= 65536) { bad = 1; return; }
+      permuted_cols_u(c, n, 65536, col(sh.start_lookups + 1 + 2 * (int)k), col(sh.start_lookups + 2 + 2 * (int)k));
+    });
+    if (bad) return fail(SBN_ERR_WITNESS, "range-checked column holds a value >= 2^16");
+  }
+  return SBN_OK;
+}
+
+extern "C" int sbn_generate_trace_g1_op(const uint32_t* pts, size_t rows, uint64_t* trace) {
+  typedef G1OpShape S;
+  if (!pts || !trace || rows < 256 || (rows & (rows - 1))) return fail(SBN_ERR_BAD_ARG, "rows must be a power of two >= 256");
+  const size_t n = rows;
+  auto col = [&](int c) { return trace + (size_t)c * n; };
+  memset(trace, 0, (size_t)S::NUM_COLS * n * sizeof(u64));
+  std::vector<Fq> den(n);
+  std::vector<u64> a(n * 16);  // ax ay bx by standard
+  for (size_t r = 0; r < n; r++) {
+    for (int q = 0; q < 4; q++) { from_u32(pts + 32 * r + 8 * q, &a[r * 16 + 4 * q]); if (geq_p(&a[r * 16 + 4 * q])) return fail(SBN_ERR_BAD_ARG, "coordinate >= p"); }
+    den[r] = fsub(to_m(&a[r * 16 + 8]), to_m(&a[r * 16]));
+    if (fzero(den[r])) return fail(SBN_ERR_WITNESS, "degenerate affine add at row %zu", r);
+  }
+  batch_inv(den);
+  std::atomic<int> bad(0);
+  parallel_for(n, [&](size_t r) {
+    const u64* s = &a[r * 16];
+    Fq x1 = to_m(s), y1 = to_m(s + 4), x2 = to_m(s + 8), y2 = to_m(s + 12);
+    Fq lam = mmul(fsub(y2, y1), den[r]);
+    Fq nx = fsub(fsub(mmul(lam, lam), x1), x2), ny = fsub(mmul(lam, fsub(x1, nx)), y1);
+    u64 ls[4], nxs[4], nys[4]; from_m(lam, ls); from_m(nx, nxs); from_m(ny, nys);
+    put_limbs(col(0) + r, n, s); put_limbs(col(16) + r, n, s + 4); put_limbs(col(32) + r, n, s + 8); put_limbs(col(48) + r, n, s + 12);
+    u64 lv[320];
+    if (!g1_output_row(false, s, s + 4, s + 8, s + 12, ls, nxs, nys, lv)) { bad = 1; return; }
+    for (int c = 0; c < 320; c++) col(64 + c)[r] = lv[c];
+    col(S::MAIN_COLS - 2)[r] = 1;  // is_add ; is_double = 0
+  });
+  if (bad) return fail(SBN_ERR_WITNESS, "modular witness generation failed");
+  // split range check (range_check.rs:116-160): table 0..255 then 255; per target lo, perm(lo), table', hi, perm(hi), table'
+  u64* table = col(S::MAIN_COLS);
+  for (size_t i = 0; i < n; i++) table[i] = i < 256 ? i : 255;
+  parallel_for((size_t)S::NUM_RC, [&](size_t k) {
+    const u64* c = col(S::START_RC + (int)k);
+    int o = S::MAIN_COLS + 1 + 6 * (int)k;
+    for (size_t i = 0; i < n; i++) { if (c[i] >= 65536) { bad = 1; return; } col(o)[i] = c[i] & 0xff; col(o + 3)[i] = c[i] >> 8; }
+    permuted_cols_u(col(o), n, 256, col(o + 1), col(o + 2));
+    permuted_cols_u(col(o + 3), n, 256, col(o + 4), col(o + 5));
+  });
+  if (bad) return fail(SBN_ERR_WITNESS, "range-checked column holds a value >= 2^16");
+  return SBN_OK;
+}

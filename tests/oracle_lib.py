@@ -212,3 +212,60 @@ def verify(kind, num_io, words):
     why = C.c_char_p()
     rc = lib().orc_verify(kind, num_io, ptr(words), len(words), C.byref(why))
     return rc, (why.value or b"").decode()
+
+
+# ---------------------------------------------------------------- extra probes
+def modular_witness(pol_input, zero_mode):
+    a = np.array(pol_input, dtype=np.int64)
+    out = np.zeros(112, dtype=np.int64)
+    lib().orc_modular_witness(ptr(a), int(zero_mode), ptr(out))
+    o = [int(x) for x in out]
+    return {"output": o[0:16], "out_aux_red": o[16:32], "quot_abs": o[32:49], "aux_lo": o[49:80], "aux_hi": o[80:111], "sign": o[111]}
+
+
+def fq_mul(a, b):
+    A = np.array(u32_limbs(a), dtype=np.uint32); B = np.array(u32_limbs(b), dtype=np.uint32)
+    out = np.zeros(8, dtype=np.uint32)
+    lib().orc_fq_mul(ptr(A), ptr(B), ptr(out))
+    return sum(int(v) << (32 * i) for i, v in enumerate(out))
+
+
+def fq_inv(a):
+    A = np.array(u32_limbs(a), dtype=np.uint32)
+    out = np.zeros(8, dtype=np.uint32)
+    lib().orc_fq_inv(ptr(A), ptr(out))
+    return sum(int(v) << (32 * i) for i, v in enumerate(out))
+
+
+def flags_table(limbs):
+    a = np.array(limbs, dtype=np.uint32)
+    out = np.zeros((512, 14), dtype=np.uint64)
+    lib().orc_flags_table(ptr(a), ptr(out))
+    return out
+
+
+def permuted_cols(inputs, table):
+    i = np.array(inputs, dtype=np.uint64); t = np.array(table, dtype=np.uint64)
+    so = np.zeros_like(i); pt = np.zeros_like(i)
+    lib().orc_permuted_cols(ptr(i), ptr(t), len(i), ptr(so), ptr(pt))
+    return [int(x) for x in so], [int(x) for x in pt]
+
+
+def eval_constraints(kind, num_io, lv, nv, pi, alphas, z_last, l_first, l_last):
+    lv = np.ascontiguousarray(lv, dtype=np.uint64); nv = np.ascontiguousarray(nv, dtype=np.uint64)
+    pi = np.ascontiguousarray(pi, dtype=np.uint64); al = np.array(alphas, dtype=np.uint64)
+    acc = np.zeros(len(al), dtype=np.uint64)
+    rc = lib().orc_eval_constraints(kind, num_io, ptr(lv), ptr(nv), ptr(pi), ptr(al), len(al), z_last, l_first, l_last, ptr(acc))
+    assert rc == 0
+    return [int(x) for x in acc]
+
+
+def challenger_probe(inputs, m):
+    a = np.array(inputs, dtype=np.uint64)
+    out = np.zeros(m, dtype=np.uint64)
+    lib().orc_challenger_probe(ptr(a), len(a), ptr(out), m)
+    return [int(x) for x in out]
+
+
+def gf_pow(b, e):
+    return pow(b, e, GL_P)

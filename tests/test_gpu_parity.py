@@ -1,0 +1,155 @@
+"""GPU parity tests (run on the MI355X box with `-m gpu`): every call goes through the C ABI of
+libsbn254.so and is compared bit-for-bit with the CPU oracle, the committed golden digests, and -- at
+the full BASELINE size -- through size-independent properties (independent verifier accepts, tamper
+rejection, determinism)."""
+import hashlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+P = 0xFFFFFFFF00000001
+
+
+@pytest.fixture(scope="module")
+def gpu(S):
+    if S.lib().sbn_device_count() < 1:
+        pytest.fail("no HIP device: GPU tests must run on the MI355X box (there is no CPU fallback)")
+    return S
+
+
+def test_poseidon_permutation_batch(gpu, O, golden):
+    kat = golden["poseidon_kat"]["vectors"]
+    states = np.array([[int(x, 16) for x in v["input"]] for v in kat], dtype=np.uint64)
+    out = gpu.poseidon_permute_batch(states)
+    assert [[int(x) for x in r] for r in out] == [[int(x, 16) for x in v["output"]] for v in kat]
+    rng = np.random.default_rng(5)
+    st = rng.integers(0, P, size=(4096, 12), dtype=np.uint64)
+    st[0] = P - 1; st[1] = 0; st[2, :] = [P - 1, 0, 1, 0xFFFFFFFF, 0xFFFFFFFF00000000, 1 << 32, 1 << 63, 2, 3, 4, 5, 6]
+    out = gpu.poseidon_permute_batch(st)
+    for r in list(range(8)) + [100, 4095]:
+        assert [int(x) for x in out[r]] == O.poseidon_permute([int(x) for x in st[r]])
+    with pytest.raises(gpu.SbnError) as e:               # non-canonical input is refused
+        gpu.poseidon_permute_batch(np.full((1, 12), P, dtype=np.uint64))
+    assert e.value.code == -2
+
+
+@pytest.mark.parametrize("ncols,n", [(1, 512), (3, 512), (4, 1024), (5, 512), (8, 2048), (9, 4096), (20, 1024), (17, 65536), (130, 16384)])
+def test_commit_matches_oracle(gpu, O, ncols, n):
+    """PolynomialBatch::from_values: iNTT, coset LDE (shift 7, blow-up 2), Poseidon leaves, Merkle cap.
+    Covers <=4 columns (hash_or_noop copies the row), a ragged last sponge block, and NTT sizes that
+    use one, and both, LDS tile widths."""
+    rng = np.random.default_rng(ncols * 1000 + n)
+    cols = rng.integers(0, P, size=(ncols, n), dtype=np.uint64)
+    cols[0, :4] = [0, P - 1, 1, 0xFFFFFFFF00000000]
+    cap, co, lde = gpu.commit_values(cols, want_coeffs=True, want_lde=True)
+    rcap, rco, rlde = O.commit_values(cols, want_coeffs=True, want_lde=True)
+    assert np.array_equal(co, rco)
+    assert np.array_equal(lde, rlde)
+    assert np.array_equal(cap, rcap)
+
+
+def test_commit_linearity_large(gpu):
+    """Size-independent property at the G1 trace height: LDE is linear, LDE(a) + LDE(b) == LDE(a+b) mod p."""
+    rng = np.random.default_rng(9)
+    n = 65536
+    a = rng.integers(0, P, size=(6, n), dtype=np.uint64)
+    b = rng.integers(0, P, size=(6, n), dtype=np.uint64)
+    s = ((a.astype(object) + b.astype(object)) % P).astype(np.uint64)
+    _, _, la = gpu.commit_values(a, want_lde=True)
+    _, _, lb = gpu.commit_values(b, want_lde=True)
+    _, _, ls = gpu.commit_values(s, want_lde=True)
+    assert np.array_equal(((la.astype(object) + lb.astype(object)) % P).astype(np.uint64), ls)
+
+
+@pytest.mark.parametrize("rows,seed", [(512, 0), (1024, 3)])
+def test_g1stark_proof_bit_exact(gpu, O, golden, rows, seed):
+    """BASELINE config[0] (plumbing): G1Stark proof bytes == oracle proof bytes == committed digest."""
+    pts, _ = O.g1op_inputs(rows, seed)
+    trace = gpu.G1Stark().generate_trace(pts)
+    stark = gpu.G1Stark()
+    cfg = stark.config()
+    proof = gpu.prove(stark, cfg, trace, np.zeros(0, dtype=np.uint64))
+    ref, _ = O.prove(O.AIR_G1_OP, 0, trace, np.zeros(0, dtype=np.uint64))
+    assert np.array_equal(proof.words, ref)
+    g = golden["proof_digests"][f"g1op_rows{rows}_seed{seed}"]
+    assert hashlib.sha256(proof.to_bytes()).hexdigest() == g["proof_sha256"]
+    assert O.verify(O.AIR_G1_OP, 0, proof.words) == (0, "")
+    gpu.verify_stark_proof(stark, proof, cfg)
+    assert proof.recover_degree_bits(cfg) == rows.bit_length() - 1
+
+
+@pytest.fixture(scope="module")
+def g1exp_gpu_proof(gpu, g1exp_case):
+    stark = gpu.G1ExpStark(128)
+    cfg = stark.config()
+    prover = gpu.Prover(stark, cfg, 16)
+    prover.load_trace(g1exp_case["trace"], g1exp_case["pi"])
+    p1 = prover.prove()
+    p2 = prover.prove()
+    times = prover.stage_times()
+    prover.close()
+    return stark, cfg, p1, p2, times
+
+
+def test_g1exp_proof_matches_oracle_digest(g1exp_gpu_proof, golden):
+    """BASELINE config[1]: G1ExpStark(128), 2^16 rows: GPU proof bytes == the CPU oracle's (committed sha256)."""
+    _, _, p1, p2, times = g1exp_gpu_proof
+    g = golden["proof_digests"]["g1exp_io128_seed1"]
+    assert len(p1.words) == g["proof_words"]
+    assert [int(x) for x in p1.words[12:16]] == g["trace_cap0"]
+    assert hashlib.sha256(p1.to_bytes()).hexdigest() == g["proof_sha256"]
+    assert np.array_equal(p1.words, p2.words)                      # deterministic (smallest PoW witness)
+    assert set(times) >= {"trace_ntt", "trace_leaf_hash", "quotient_eval", "fri_layers"} and all(v >= 0 for v in times.values())
+
+
+def test_g1exp_proof_verifies_and_tamper_is_rejected(gpu, O, g1exp_gpu_proof):
+    stark, cfg, p1, _, _ = g1exp_gpu_proof
+    assert O.verify(O.AIR_G1_EXP, 128, p1.words) == (0, "")        # independent verifier (oracle)
+    gpu.verify_stark_proof(stark, p1, cfg)                          # product verifier
+    w = p1.words
+    ncol, nz = 1676, 762
+    openings = 12 + 3 * 64
+    for idx in (13, openings + 3, openings + 2 * ncol + 1, len(w) - 7168 - 1, len(w) - 1):
+        t = w.copy()
+        t[idx] = (int(t[idx]) + 1) % P
+        assert O.verify(O.AIR_G1_EXP, 128, t)[0] != 0
+        with pytest.raises(gpu.SbnError):
+            gpu.verify_stark_proof(stark, gpu.Proof(t, 16), cfg)
+
+
+def test_g1exp_full_oracle_proof_equality(gpu, O, g1exp_case, g1exp_gpu_proof):
+    """Runs the CPU oracle's prove() on the same trace on the box (about a minute) and compares every word."""
+    _, _, p1, _, _ = g1exp_gpu_proof
+    ref, _ = O.prove(O.AIR_G1_EXP, 128, g1exp_case["trace"], g1exp_case["pi"])
+    assert np.array_equal(p1.words, ref)
+
+
+def test_prover_argument_errors(gpu, g1op_case):
+    stark = gpu.G1Stark()
+    cfg = stark.config()
+    tr = g1op_case["trace"].copy()
+    tr[5, 7] = P                                                    # non-canonical trace word
+    with pytest.raises(gpu.SbnError) as e:
+        gpu.prove(stark, cfg, tr, g1op_case["pi"])
+    assert e.value.code == -2
+    with pytest.raises(gpu.SbnError) as e:                          # wrong public-input count
+        gpu.prove(stark, cfg, g1op_case["trace"], np.zeros(3, dtype=np.uint64))
+    assert e.value.code == -1
+    with pytest.raises(gpu.SbnError) as e:                          # G1ExpStark below 2^16 rows
+        gpu.Prover(gpu.G1ExpStark(4), cfg, 11)
+    assert e.value.code in (-1, -7)
+    with pytest.raises(gpu.SbnError):                               # prove before load
+        gpu.Prover(stark, cfg, 9).prove()
+
+
+def test_invalid_witness_yields_rejected_proof(gpu, O, g1op_case):
+    tr = g1op_case["trace"].copy()
+    tr[64 + 16, 9] = (int(tr[64 + 16, 9]) + 1) % 65536
+    stark = gpu.G1Stark()
+    proof = gpu.prove(stark, stark.config(), tr, g1op_case["pi"])
+    ref, _ = O.prove(O.AIR_G1_OP, 0, tr, g1op_case["pi"])
+    assert np.array_equal(proof.words, ref)                         # still the same bytes as the oracle...
+    assert O.verify(O.AIR_G1_OP, 0, proof.words)[0] != 0           # ...and both verifiers reject them
+    with pytest.raises(gpu.SbnError):
+        gpu.verify_stark_proof(stark, proof, stark.config())

@@ -1,0 +1,104 @@
+"""CPU tests: AIR constraints vanish on generated traces; oracle prove -> verify; tamper rejection;
+committed proof digests."""
+import hashlib
+
+import numpy as np
+import pytest
+
+P = 0xFFFFFFFF00000001
+
+
+def _trace_domain_consumer_args(n, i):
+    """On the trace domain H: L_first = [i == 0], L_last = [i == n-1], z_last = w^i - w^(n-1)."""
+    lg = n.bit_length() - 1
+    w = pow(1753635133440165772, 1 << (32 - lg), P)
+    x = pow(w, i, P)
+    return (x - pow(w, n - 1, P)) % P, int(i == 0), int(i == n - 1)
+
+
+def test_g1op_constraints_vanish_on_trace(O, g1op_case):
+    tr = g1op_case["trace"]
+    n = tr.shape[1]
+    alphas = [0x1234567890abcdef, 0x0fedcba987654321]
+    for i in (0, 1, 17, 255, 256, n - 2, n - 1):
+        zl, lf, ll = _trace_domain_consumer_args(n, i)
+        acc = O.eval_constraints(O.AIR_G1_OP, 0, tr[:, i], tr[:, (i + 1) % n], np.zeros(0, dtype=np.uint64), alphas, zl, lf, ll)
+        assert acc == [0, 0], f"row {i}"
+    # a corrupted limb must violate something
+    bad = tr[:, 5].copy()
+    bad[70] = (int(bad[70]) + 1) % 65536
+    zl, lf, ll = _trace_domain_consumer_args(n, 5)
+    assert O.eval_constraints(O.AIR_G1_OP, 0, bad, tr[:, 6], np.zeros(0, dtype=np.uint64), alphas, zl, lf, ll) != [0, 0]
+
+
+def test_g1exp_constraints_vanish_on_trace(O, g1exp_case):
+    tr, pi = g1exp_case["trace"], g1exp_case["pi"]
+    n = tr.shape[1]
+    alphas = [0xdeadbeefcafef00d, 0x1111111122222222]
+    rows = [0, 1, 2, 61, 62, 63, 64, 510, 511, 512, 513, 1023, 1024, 40000, n - 2, n - 1]
+    for i in rows:
+        zl, lf, ll = _trace_domain_consumer_args(n, i)
+        acc = O.eval_constraints(O.AIR_G1_EXP, 128, tr[:, i], tr[:, (i + 1) % n], pi, alphas, zl, lf, ll)
+        assert acc == [0, 0], f"row {i}"
+    # wrong public input (instance 0 output.x limb) breaks the binding on that instance's last row
+    pi2 = pi.copy()
+    pi2[40] = (int(pi2[40]) + 1) & 0xFFFFFFFF
+    zl, lf, ll = _trace_domain_consumer_args(n, 511)
+    assert O.eval_constraints(O.AIR_G1_EXP, 128, tr[:, 511], tr[:, 512], pi2, alphas, zl, lf, ll) != [0, 0]
+
+
+def test_g1exp_shape(O):
+    L = O.lib()
+    assert L.orc_air_num_columns(O.AIR_G1_EXP, 128) == 1676
+    assert L.orc_air_num_public_inputs(O.AIR_G1_EXP, 128) == 7168
+    assert L.orc_air_num_permutation_zs(O.AIR_G1_EXP, 128) == 762
+    assert L.orc_air_num_columns(O.AIR_G1_OP, 0) == 2283
+    assert L.orc_air_num_permutation_zs(O.AIR_G1_OP, 0) == 1264
+
+
+def test_g1op_prove_verify_and_digest(O, g1op_case, golden):
+    w = g1op_case["proof"]
+    g = golden["proof_digests"]["g1op_rows512_seed0"]
+    assert hashlib.sha256(g1op_case["trace"].tobytes()).hexdigest() == g["trace_sha256"]
+    assert len(w) == g["proof_words"]
+    assert hashlib.sha256(w.astype("<u8").tobytes()).hexdigest() == g["proof_sha256"]
+    assert O.verify(O.AIR_G1_OP, 0, w) == (0, "")
+    # header: degree_bits 9, 2283 columns, 1264 Zs, 4 quotient polys, 0 PI, cap 4, rate 1, 1 FRI layer, arity 4, 32 final coeffs, 84 queries
+    assert [int(x) for x in w[1:12]] == [9, 2283, 1264, 4, 0, 4, 1, 1, 4, 32, 84]
+
+
+@pytest.mark.parametrize("where", ["trace_cap", "opening", "fri_cap", "query_leaf", "final_poly", "pow", "truncate", "noncanonical"])
+def test_oracle_rejects_tampering(O, g1op_case, where):
+    w = g1op_case["proof"].copy()
+    ncol, nz = 2283, 1264
+    caps = 12 + 3 * 64
+    openings = caps
+    fri_caps = openings + 2 * (2 * ncol + 2 * nz + 4)
+    queries = fri_caps + 64
+    if where == "trace_cap":
+        w[12] ^= 1
+    elif where == "opening":
+        w[openings + 10] = (int(w[openings + 10]) + 1) % P
+    elif where == "fri_cap":
+        w[fri_caps + 3] ^= 1
+    elif where == "query_leaf":
+        w[queries + 7] = (int(w[queries + 7]) + 1) % P
+    elif where == "final_poly":
+        w[-2 - 5] = (int(w[-2 - 5]) + 1) % P
+    elif where == "pow":
+        w[-1] = (int(w[-1]) + 1) % P
+    elif where == "truncate":
+        w = w[:-3]
+    elif where == "noncanonical":
+        w[openings] = P
+    rc, why = O.verify(O.AIR_G1_OP, 0, w)
+    assert rc != 0, why
+
+
+def test_oracle_rejects_invalid_witness(O, g1op_case):
+    """A trace that violates a constraint yields a proof the verifier rejects (quotient not a polynomial)."""
+    tr = g1op_case["trace"].copy()
+    tr[64 + 16, 9] = (int(tr[64 + 16, 9]) + 1) % 65536      # new_x limb 0 of row 9
+    w, _ = O.prove(O.AIR_G1_OP, 0, tr, np.zeros(0, dtype=np.uint64))
+    rc, why = O.verify(O.AIR_G1_OP, 0, w)
+    assert rc != 0

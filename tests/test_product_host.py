@@ -1,0 +1,113 @@
+"""CPU tests of the product's host side: the C-ABI library loads and exports every declared symbol,
+table shapes, witness generation (host code) bit-equal to the oracle, the host verifier accepts the
+oracle's proofs and rejects tampered ones, and the prover refuses to run without a GPU (no fallback)."""
+import ctypes as C
+import hashlib
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P = 0xFFFFFFFF00000001
+
+
+def test_library_exports_every_declared_symbol(S):
+    hdr = open(os.path.join(ROOT, "include", "sbn.h")).read()
+    declared = set(re.findall(r"\b(sbn_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"sbn_status", "sbn_air_kind"}
+    L = S.lib()
+    missing = [d for d in sorted(declared) if not hasattr(L, d)]
+    assert not missing, missing
+    assert set(S.EXPORTS) == declared
+
+
+def test_shapes_and_config(S):
+    st = S.G1ExpStark(128)
+    assert (st.num_columns, st.num_public_inputs, st.num_permutation_zs(), st.num_constraints) == (1676, 7168, 762, 9027)
+    g = S.G1Stark()
+    assert (g.num_columns, g.num_public_inputs, g.num_permutation_zs()) == (2283, 0, 1264)
+    c = st.config()
+    assert (c.security_bits, c.num_challenges, c.rate_bits, c.cap_height, c.proof_of_work_bits, c.fri_arity_bits,
+            c.fri_final_poly_bits, c.num_query_rounds) == (100, 2, 1, 4, 16, 4, 5, 84)
+    assert S.G1ExpStark(0).num_columns == 0 and S.G1ExpStark(129).num_columns == 0     # unknown shapes report 0
+
+
+def test_tracegen_g1op_matches_oracle(S, O):
+    for rows, seed in ((512, 0), (1024, 3)):
+        pts, _ = O.g1op_inputs(rows, seed)
+        assert np.array_equal(S.G1Stark().generate_trace(pts), O.g1op_trace(pts))
+
+
+def test_tracegen_g1exp_matches_oracle_and_golden(S, g1exp_case, golden):
+    tr, pi = S.G1ExpStark(128).generate_trace_and_public_inputs(g1exp_case["ios"])
+    assert np.array_equal(pi, g1exp_case["pi"])
+    assert np.array_equal(tr, g1exp_case["trace"])
+    g = golden["proof_digests"]["g1exp_io128_seed1"]
+    assert hashlib.sha256(tr.tobytes()).hexdigest() == g["trace_sha256"]
+    assert hashlib.sha256(pi.tobytes()).hexdigest() == g["pi_sha256"]
+
+
+def test_tracegen_error_behaviour(S, O):
+    pts, _ = O.g1op_inputs(512, 0)
+    bad = pts.copy()
+    bad[3, 16:32] = bad[3, 0:16]                       # b == a: affine add degenerates (x2 - x1 = 0)
+    with pytest.raises(S.SbnError) as e:
+        S.G1Stark().generate_trace(bad)
+    assert e.value.code == -8
+    bad = pts.copy()
+    bad[0, 0:8] = 0xFFFFFFFF                           # coordinate >= p
+    with pytest.raises(S.SbnError) as e:
+        S.G1Stark().generate_trace(bad)
+    assert e.value.code == -1
+    with pytest.raises(S.SbnError):                    # rows not a power of two
+        S.G1Stark().generate_trace(pts[:300])
+    ios, _ = O.g1exp_inputs(4, 1)
+    with pytest.raises(S.SbnError) as e:               # < 2^16 rows: range_check.rs:26
+        S.G1ExpStark(4).generate_trace_and_public_inputs(ios)
+    assert e.value.code == -7
+
+
+def test_host_verifier_accepts_oracle_proof_and_rejects_tampering(S, g1op_case):
+    stark = S.G1Stark()
+    cfg = stark.config()
+    w = g1op_case["proof"]
+    S.verify_stark_proof(stark, S.Proof(w, 9), cfg)
+    for idx, delta in ((12, 1), (12 + 3 * 64 + 5, 1), (len(w) - 1, 1), (12 + 3 * 64 + 2 * (2 * 2283 + 2 * 1264 + 4) + 64 + 11, 1)):
+        t = w.copy()
+        t[idx] = (int(t[idx]) + delta) % P
+        with pytest.raises(S.SbnError) as e:
+            S.verify_stark_proof(stark, S.Proof(t, 9), cfg)
+        assert e.value.code == -6
+    with pytest.raises(S.SbnError) as e:               # malformed: truncated
+        S.verify_stark_proof(stark, S.Proof(w[:-1], 9), cfg)
+    assert e.value.code == -5
+    t = w.copy(); t[12 + 3 * 64] = P                   # non-canonical element
+    with pytest.raises(S.SbnError) as e:
+        S.verify_stark_proof(stark, S.Proof(t, 9), cfg)
+    assert e.value.code == -5
+    with pytest.raises(S.SbnError):                    # proof of another table
+        S.verify_stark_proof(S.G1ExpStark(128), S.Proof(w, 9), cfg)
+
+
+def test_no_cpu_fallback(S, g1op_case):
+    """Without a HIP device the prover path must fail loudly (SBN_ERR_NO_DEVICE), never compute on the CPU."""
+    if S.lib().sbn_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(S.SbnError) as e:
+        S.prove(S.G1Stark(), S.G1Stark().config(), g1op_case["trace"], g1op_case["pi"])
+    assert e.value.code == -3
+    with pytest.raises(S.SbnError) as e:
+        S.commit_values(np.zeros((2, 512), dtype=np.uint64))
+    assert e.value.code == -3
+
+
+def test_product_never_loads_the_oracle():
+    """The shipped package must not reference oracle/ in any form."""
+    pkg = os.path.join(ROOT, "starky_bn254_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".cuh", ".hpp", ".cpp", "Makefile")):
+                txt = open(os.path.join(dp, f), errors="ignore").read()
+                assert "liboracle" not in txt and "oracle/" not in txt and "oracle_lib" not in txt, os.path.join(dp, f)
