@@ -152,6 +152,78 @@ __global__ __launch_bounds__(256) void merkle_level_kernel(const u64* __restrict
   for (int k = 0; k < 4; k++) parent[i * 4 + k] = s[k].v;
 }
 
+// K2' chunked sponge absorption: the leaf hash of a wide matrix is a sequential sponge over its columns,
+// so it can run per COLUMN CHUNK right behind the NTT that produced the chunk (second HIP stream): the
+// LDE chunk is then read from the Infinity Cache instead of HBM and the HBM-bound NTT of chunk k+1
+// overlaps the ALU-bound hashing of chunk k.  Sponge state: [12][m] words, column-major (coalesced).
+// ncols_chunk is a multiple of 8 except for the last chunk; `first` starts from the zero state, `last`
+// writes the digest to leaf bitrev(row).
+__global__ __launch_bounds__(256) void leaf_absorb_kernel(const u64* __restrict__ lde_chunk, size_t m, u32 lde_log, u32 ncols_chunk,
+                                                          u64* __restrict__ state, int first, int last, u64* __restrict__ digests) {
+  size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= m) return;
+  F s[12];
+  if (first) {
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = F(0);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = F(state[(size_t)i * m + row]);
+  }
+  u32 c = 0;
+  for (; c + 8 <= ncols_chunk; c += 8) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) s[i] = F(lde_chunk[(size_t)(c + i) * m + row]);
+    poseidon_permute(s);
+  }
+  if (c < ncols_chunk) {
+#pragma unroll
+    for (u32 i = 0; i < 8; i++)
+      if (c + i < ncols_chunk) s[i] = F(lde_chunk[(size_t)(c + i) * m + row]);
+    poseidon_permute(s);
+  }
+  if (last) {
+    size_t leaf = bitrev32((u32)row, lde_log);
+#pragma unroll
+    for (int i = 0; i < 4; i++) digests[leaf * 4 + i] = s[i].v;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 12; i++) state[(size_t)i * m + row] = s[i].v;
+  }
+}
+
+// K3' fused Merkle levels: a workgroup owns 2*blockDim consecutive digests of level `l0` and hashes
+// up to `nlev` levels above them through LDS, writing every level to the tree (levels concatenated,
+// level l at word offset 4*(2*nleaf - (2*nleaf >> l))).  Two launches build a 2^17-leaf tree.
+__global__ __launch_bounds__(256) void merkle_subtree_kernel(u64* __restrict__ tree, size_t nleaf, u32 l0, u32 nlev) {
+  __shared__ u64 buf[2 * 256 * 4];
+  const u32 tid = threadIdx.x, nt = blockDim.x;
+  const u64* child = tree + (2 * nleaf - ((2 * nleaf) >> l0)) * 4;
+  size_t base = (size_t)blockIdx.x * 2 * nt;  // first child digest of this workgroup
+  for (u32 e = tid; e < 2 * nt * 4; e += nt) buf[e] = child[base * 4 + e];
+  __syncthreads();
+  u32 active = nt;
+  for (u32 lv = 1; lv <= nlev; lv++) {
+    F s[12];
+    if (tid < active) {
+#pragma unroll
+      for (int k = 0; k < 8; k++) s[k] = F(buf[tid * 8 + k]);
+#pragma unroll
+      for (int k = 8; k < 12; k++) s[k] = F(0);
+      poseidon_permute(s);
+    }
+    __syncthreads();
+    if (tid < active) {
+      u64* out = tree + (2 * nleaf - ((2 * nleaf) >> (l0 + lv))) * 4;
+      size_t idx = ((size_t)blockIdx.x * 2 * nt >> lv) + tid;
+#pragma unroll
+      for (int k = 0; k < 4; k++) { buf[tid * 4 + k] = s[k].v; out[idx * 4 + k] = s[k].v; }
+    }
+    __syncthreads();
+    active >>= 1;
+  }
+}
+
 // FRI layer leaves: leaf l = the 16 extension values at bit-reversed positions 16l..16l+15 of the
 // layer's evaluation vector (planes va/vb in natural order), flattened c0,c1 (fri/prover.rs).
 __global__ __launch_bounds__(256) void fri_leaf_hash_kernel(const u64* __restrict__ va, const u64* __restrict__ vb, u32 log_m, u32 arity_bits,

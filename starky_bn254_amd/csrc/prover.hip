@@ -20,15 +20,19 @@ namespace sbn { thread_local std::string g_last_error; }
 
 static int g_device = 0;
 
-// Stage k spans [ev[k], ev[k+1]) on the prover's stream.  "*_leaf_hash" stages contain exactly one
-// leaf_hash_kernel launch (the dominant kernel), so their time is that kernel's launch duration.
+// Stage k spans [ev[k], ev[k+1]) on the prover's main stream.  The commit stages overlap NTT (main
+// stream) with sponge absorption (hash stream); the absorption kernels are additionally timed one by
+// one with events on the hash stream (EXTRA_* entries = sum over the chunk launches of one proof).
 enum Stage {
-  ST_TRACE_NTT, ST_TRACE_LEAF, ST_TRACE_TREE, ST_PERM_Z, ST_Z_NTT, ST_Z_LEAF, ST_Z_TREE, ST_QUOTIENT_EVAL, ST_QUOTIENT_COMMIT,
+  ST_TRACE_COMMIT, ST_PERM_Z, ST_Z_COMMIT, ST_QUOTIENT_EVAL, ST_QUOTIENT_COMMIT,
   ST_OPENINGS, ST_FRI_COMBINE, ST_FRI_LAYERS, ST_POW, ST_QUERIES, ST_COUNT
 };
-static const char* STAGE_NAMES[ST_COUNT] = {
-  "trace_ntt", "trace_leaf_hash", "trace_tree", "perm_z", "z_ntt", "z_leaf_hash", "z_tree", "quotient_eval", "quotient_commit",
-  "openings", "fri_combine", "fri_layers", "pow", "queries"};
+enum Extra { EX_TRACE_ABSORB_MS, EX_TRACE_ABSORB_LAUNCHES, EX_Z_ABSORB_MS, EX_Z_ABSORB_LAUNCHES, EX_COUNT };
+static const char* STAGE_NAMES[ST_COUNT + EX_COUNT] = {
+  "trace_commit", "perm_z", "z_commit", "quotient_eval", "quotient_commit",
+  "openings", "fri_combine", "fri_layers", "pow", "queries",
+  "trace_absorb_kernels_ms", "trace_absorb_launches", "z_absorb_kernels_ms", "z_absorb_launches"};
+static constexpr int MAX_CHUNKS = 256;
 
 struct DevTree {  // Merkle digests, levels concatenated (leaf level first)
   u64* d = nullptr; size_t nleaf = 0; u32 nlevels = 0;  // nlevels = number of levels BELOW the cap
@@ -66,8 +70,13 @@ struct sbn_prover {
   std::vector<u64> pi;
   bool loaded = false;
   hipEvent_t ev[ST_COUNT + 1];
-  float stage_ms[ST_COUNT];
+  float stage_ms[ST_COUNT + EX_COUNT];
   size_t ntt_chunk;
+  hipStream_t hstream = nullptr;             // sponge absorption / Merkle stream
+  hipEvent_t chunk_ready[MAX_CHUNKS];        // main -> hash: LDE chunk k is complete
+  hipEvent_t abs_ev[2 * MAX_CHUNKS];         // hash stream: before/after each absorb launch
+  hipEvent_t hash_done;                      // hash -> main
+  u64* d_sponge = nullptr;                   // [12][m] sponge state carried between column chunks
 };
 
 static int dmalloc(u64** p, size_t words) {
@@ -148,24 +157,69 @@ static int intt_then_lde(sbn_prover* P, const u64* vals, u64* coef, u64* lde, si
   return 0;
 }
 
+static int intt_then_lde_chunk(sbn_prover* P, const u64* vals, u64* coef, u64* lde, size_t c0, size_t nc) {
+  int rc = ntt_columns(P, vals + c0 * P->n, P->n, coef + c0 * P->n, P->n, P->d_tmp, P->m, nc, P->degree_bits, true, P->n, nullptr, nullptr,
+                       host_inv_pow2(P->degree_bits));
+  if (rc) return rc;
+  return ntt_columns(P, coef + c0 * P->n, P->n, lde + c0 * P->m, P->m, P->d_tmp, P->m, nc, P->lde_log, false, P->n, P->d_shift, nullptr, 1);
+}
+
 static int tree_alloc(DevTree& t, size_t nleaf, u32 cap_height) {
   t.nleaf = nleaf;
   u32 lg = 0; while (((size_t)1 << lg) < nleaf) lg++;
   t.nlevels = lg - cap_height;
   return dmalloc(&t.d, 2 * nleaf * 4);
 }
-static int tree_build_inner(sbn_prover* P, DevTree& t) {
-  for (u32 l = 0; l < t.nlevels; l++) {
-    size_t np = t.nleaf >> (l + 1);
-    hipLaunchKernelGGL(merkle_level_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, P->stream, t.level(l), t.level(l + 1), np);
+static int tree_build_inner(sbn_prover* P, DevTree& t, hipStream_t st) {
+  u32 l0 = 0;
+  while (l0 < t.nlevels) {
+    size_t nodes = t.nleaf >> l0;
+    u32 nt = (u32)std::min<size_t>(256, nodes / 2);
+    u32 lg = 0; while ((1u << lg) < nt) lg++;
+    u32 nlev = std::min(t.nlevels - l0, lg + 1);
+    hipLaunchKernelGGL(merkle_subtree_kernel, dim3((unsigned)(nodes / (2 * nt))), dim3(nt), 0, st, t.d, t.nleaf, l0, nlev);
+    l0 += nlev;
   }
   HIPC(hipGetLastError());
   return 0;
 }
-static int tree_from_matrix(sbn_prover* P, DevTree& t, const u64* lde, size_t ncols, int ev_after_leaf = -1) {
+// narrow matrices (quotient chunks): single-launch leaf hash + tree on the main stream
+static int tree_from_matrix(sbn_prover* P, DevTree& t, const u64* lde, size_t ncols) {
   hipLaunchKernelGGL(leaf_hash_kernel, dim3((unsigned)((P->m + 255) / 256)), dim3(256), 0, P->stream, lde, P->m, P->lde_log, (u32)ncols, t.d);
-  if (ev_after_leaf >= 0) HIPC(hipEventRecord(P->ev[ev_after_leaf], P->stream));
-  return tree_build_inner(P, t);
+  return tree_build_inner(P, t, P->stream);
+}
+// PolynomialBatch::from_values for a wide matrix: per column chunk iNTT + coset LDE on the main stream,
+// sponge absorption of that chunk on the hash stream, then the Merkle levels; main waits at the end.
+static int intt_then_lde_chunk(sbn_prover* P, const u64* vals, u64* coef, u64* lde, size_t c0, size_t nc);
+static int commit_pipeline(sbn_prover* P, const u64* vals, u64* coef, u64* lde, size_t ncols, DevTree& t, int ex_ms, int ex_launches) {
+  size_t ch = P->ntt_chunk;
+  size_t nchunks = (ncols + ch - 1) / ch;
+  if (nchunks > (size_t)MAX_CHUNKS) return fail(SBN_ERR_UNSUPPORTED, "too many column chunks");
+  for (size_t k = 0; k < nchunks; k++) {
+    size_t c0 = k * ch, nc = std::min(ch, ncols - c0);
+    int rc = intt_then_lde_chunk(P, vals, coef, lde, c0, nc);
+    if (rc) return rc;
+    HIPC(hipEventRecord(P->chunk_ready[k], P->stream));
+    HIPC(hipStreamWaitEvent(P->hstream, P->chunk_ready[k], 0));
+    HIPC(hipEventRecord(P->abs_ev[2 * k], P->hstream));
+    hipLaunchKernelGGL(leaf_absorb_kernel, dim3((unsigned)((P->m + 255) / 256)), dim3(256), 0, P->hstream, lde + c0 * P->m, P->m, P->lde_log, (u32)nc,
+                       P->d_sponge, k == 0 ? 1 : 0, k + 1 == nchunks ? 1 : 0, t.d);
+    HIPC(hipEventRecord(P->abs_ev[2 * k + 1], P->hstream));
+  }
+  int rc = tree_build_inner(P, t, P->hstream);
+  if (rc) return rc;
+  HIPC(hipEventRecord(P->hash_done, P->hstream));
+  HIPC(hipStreamWaitEvent(P->stream, P->hash_done, 0));
+  P->stage_ms[ST_COUNT + ex_launches] = (float)nchunks;
+  (void)ex_ms;
+  return 0;
+}
+static int absorb_times(sbn_prover* P, size_t ncols, int ex_ms) {
+  size_t nchunks = (ncols + P->ntt_chunk - 1) / P->ntt_chunk;
+  float tot = 0;
+  for (size_t k = 0; k < nchunks; k++) { float ms = 0; HIPC(hipEventElapsedTime(&ms, P->abs_ev[2 * k], P->abs_ev[2 * k + 1])); tot += ms; }
+  P->stage_ms[ST_COUNT + ex_ms] = tot;
+  return 0;
 }
 static int tree_cap_to_host(sbn_prover* P, const DevTree& t, std::vector<u64>& cap) {
   size_t capn = (size_t)1 << P->cfg.cap_height;
@@ -200,7 +254,12 @@ extern "C" int sbn_prover_create(const sbn_air_desc* air, const sbn_config* cfg,
   P->ntt_chunk = ce ? (size_t)atol(ce) : 64;
   if (P->ntt_chunk == 0) P->ntt_chunk = 64;
   HIPC(hipStreamCreate(&P->stream));
+  HIPC(hipStreamCreate(&P->hstream));
   for (auto& e : P->ev) HIPC(hipEventCreate(&e));
+  for (auto& e : P->abs_ev) HIPC(hipEventCreate(&e));
+  for (auto& e : P->chunk_ready) HIPC(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  HIPC(hipEventCreateWithFlags(&P->hash_done, hipEventDisableTiming));
+  for (auto& v : P->stage_ms) v = 0;
   const size_t n = P->n, m = P->m, C = as.ncols, Z = as.nzs;
   int rc = 0;
   rc |= dmalloc(&P->d_trace, C * n); rc |= dmalloc(&P->d_coef, C * n); rc |= dmalloc(&P->d_lde, C * m);
@@ -212,7 +271,7 @@ extern "C" int sbn_prover_create(const sbn_air_desc* air, const sbn_config* cfg,
   rc |= dmalloc(&P->d_xs, m); rc |= dmalloc(&P->d_lag_first, m); rc |= dmalloc(&P->d_lag_last, m);
   rc |= dmalloc(&P->d_apow, (size_t)SBN_NCH * APOW_MAX);
   rc |= dmalloc(&P->d_zpow, 4 * n); rc |= dmalloc(&P->d_open, (C + Z + 4) * 4);
-  rc |= dmalloc(&P->d_part, 2 * 32 * n); rc |= dmalloc(&P->d_w, 64);
+  rc |= dmalloc(&P->d_part, 2 * 32 * n); rc |= dmalloc(&P->d_w, 4096); rc |= dmalloc(&P->d_sponge, 12 * m);
   rc |= dmalloc(&P->d_fa, 4 * n); rc |= dmalloc(&P->d_fcoef, 2 * m); rc |= dmalloc(&P->d_fcoef2, 2 * m);
   rc |= dmalloc(&P->d_pow, 1);
   if (rc) { sbn_prover_destroy(P); return rc; }
@@ -266,18 +325,23 @@ extern "C" int sbn_prover_create(const sbn_air_desc* air, const sbn_config* cfg,
 
 extern "C" void sbn_prover_destroy(sbn_prover* P) {
   if (!P) return;
-  hipSetDevice(P->device);
+  (void)hipSetDevice(P->device);
   u64* bufs[] = {P->d_trace, P->d_coef, P->d_lde, P->d_tmp, P->d_zval, P->d_zcoef, P->d_zlde, P->d_q, P->d_qlde, P->tree_t.d, P->tree_z.d,
                  P->tree_q.d, P->d_tw_f, P->d_tw_i, P->d_shift, P->d_shift_inv, P->d_xs, P->d_lag_first, P->d_lag_last, P->d_apow, P->d_zpow,
                  P->d_open, P->d_part, P->d_w, P->d_fa, P->d_fcoef, P->d_fcoef2, P->d_pow, P->d_qbuf};
-  for (u64* b : bufs) if (b) hipFree(b);
-  for (u64* b : P->fri_vals) if (b) hipFree(b);
-  for (auto& t : P->fri_trees) if (t.d) hipFree(t.d);
-  if (P->d_pic) hipFree(P->d_pic);
-  if (P->d_idx) hipFree(P->d_idx);
-  if (P->d_pairs) hipFree(P->d_pairs);
-  for (auto& e : P->ev) hipEventDestroy(e);
-  hipStreamDestroy(P->stream);
+  for (u64* b : bufs) if (b) (void)hipFree(b);
+  for (u64* b : P->fri_vals) if (b) (void)hipFree(b);
+  for (auto& t : P->fri_trees) if (t.d) (void)hipFree(t.d);
+  if (P->d_pic) (void)hipFree(P->d_pic);
+  if (P->d_idx) (void)hipFree(P->d_idx);
+  if (P->d_pairs) (void)hipFree(P->d_pairs);
+  for (auto& e : P->ev) (void)hipEventDestroy(e);
+  for (auto& e : P->abs_ev) (void)hipEventDestroy(e);
+  for (auto& e : P->chunk_ready) (void)hipEventDestroy(e);
+  (void)hipEventDestroy(P->hash_done);
+  if (P->d_sponge) (void)hipFree(P->d_sponge);
+  (void)hipStreamDestroy(P->hstream);
+  (void)hipStreamDestroy(P->stream);
   delete P;
 }
 
@@ -310,11 +374,11 @@ extern "C" uint64_t* sbn_prover_trace_device_ptr(sbn_prover* P) { return P ? P->
 
 extern "C" int sbn_prover_stage_times(const sbn_prover* P, float* ms, int cap) {
   if (!P || !ms) return 0;
-  int k = std::min(cap, (int)ST_COUNT);
+  int k = std::min(cap, (int)(ST_COUNT + EX_COUNT));
   for (int i = 0; i < k; i++) ms[i] = P->stage_ms[i];
   return k;
 }
-extern "C" const char* sbn_prover_stage_name(int i) { return (i >= 0 && i < ST_COUNT) ? STAGE_NAMES[i] : ""; }
+extern "C" const char* sbn_prover_stage_name(int i) { return (i >= 0 && i < ST_COUNT + EX_COUNT) ? STAGE_NAMES[i] : ""; }
 
 // ---- prove ----------------------------------------------------------------------------------------
 extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
@@ -332,12 +396,11 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
   std::vector<u64> trace_cap, z_cap, q_cap;
 
   // P1 trace commitment ---------------------------------------------------------------------------
-  HIPC(hipEventRecord(P->ev[ST_TRACE_NTT], st));
-  if ((rc = intt_then_lde(P, P->d_trace, P->d_coef, P->d_lde, C))) return rc;
-  HIPC(hipEventRecord(P->ev[ST_TRACE_LEAF], st));
-  if ((rc = tree_from_matrix(P, P->tree_t, P->d_lde, C, ST_TRACE_TREE))) return rc;
+  HIPC(hipEventRecord(P->ev[ST_TRACE_COMMIT], st));
+  if ((rc = commit_pipeline(P, P->d_trace, P->d_coef, P->d_lde, C, P->tree_t, EX_TRACE_ABSORB_MS, EX_TRACE_ABSORB_LAUNCHES))) return rc;
   HIPC(hipEventRecord(P->ev[ST_PERM_Z], st));
   if ((rc = tree_cap_to_host(P, P->tree_t, trace_cap))) return rc;
+  if ((rc = absorb_times(P, C, EX_TRACE_ABSORB_MS))) return rc;
   ch.observe_words(trace_cap.data(), capw);
 
   // P2 permutation argument -------------------------------------------------------------------------
@@ -347,12 +410,11 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
   const F gamma0 = gam[0][0], gamma1 = gam[1][1];  // instance i of a batch uses sets[i].challenges[chal]
   hipLaunchKernelGGL(permutation_z_kernel, dim3((unsigned)Z), dim3(256), 0, st, P->d_trace, n, P->d_pairs, gamma0.v, gamma1.v, P->d_zval);
   HIPC(hipGetLastError());
-  HIPC(hipEventRecord(P->ev[ST_Z_NTT], st));
-  if ((rc = intt_then_lde(P, P->d_zval, P->d_zcoef, P->d_zlde, Z))) return rc;
-  HIPC(hipEventRecord(P->ev[ST_Z_LEAF], st));
-  if ((rc = tree_from_matrix(P, P->tree_z, P->d_zlde, Z, ST_Z_TREE))) return rc;
+  HIPC(hipEventRecord(P->ev[ST_Z_COMMIT], st));
+  if ((rc = commit_pipeline(P, P->d_zval, P->d_zcoef, P->d_zlde, Z, P->tree_z, EX_Z_ABSORB_MS, EX_Z_ABSORB_LAUNCHES))) return rc;
   HIPC(hipEventRecord(P->ev[ST_QUOTIENT_EVAL], st));
   if ((rc = tree_cap_to_host(P, P->tree_z, z_cap))) return rc;
+  if ((rc = absorb_times(P, Z, EX_Z_ABSORB_MS))) return rc;
   ch.observe_words(z_cap.data(), capw);
 
   // P3 quotient -------------------------------------------------------------------------------------
@@ -423,30 +485,33 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
   E2 fri_alpha = ch.ext_challenge();
   {
     // F1 = sum_{j < C+Z} alpha^j f_j ; F0 = F1 + alpha^(C+Z) * sum_{j<4} alpha^j q_j
-    const u32 GS = 128;  // polys per group
-    auto combine = [&](const u64* coeffs, u32 npoly, E2 weight0, u64* oa, u64* ob, int accumulate) -> int {
+    const u32 GS = 128;  // polys per group; groups run on grid.y, <= 32 per launch
+    // all group weights alpha^(offset + g*GS) are known up front: one upload, no host sync in the loop
+    std::vector<u64> wall;
+    auto plan = [&](u32 npoly, E2 weight0) { size_t off = wall.size(); u32 ng = (npoly + GS - 1) / GS; E2 ag = e2_pow(fri_alpha, GS), cur = weight0;
+                                             for (u32 k = 0; k < ng; k++) { wall.push_back(cur.a.v); wall.push_back(cur.b.v); cur = cur * ag; } return off; };
+    E2 one{F(1), F(0)};
+    size_t w_t = plan((u32)C, one), w_z = Z ? plan((u32)Z, e2_pow(fri_alpha, C)) : 0, w_q = plan(4, e2_pow(fri_alpha, C + Z));
+    if (wall.size() > 4096) return fail(SBN_ERR_UNSUPPORTED, "too many FRI combine groups");
+    HIPC(hipMemcpyAsync(P->d_w, wall.data(), wall.size() * sizeof(u64), hipMemcpyHostToDevice, st));
+    auto combine = [&](const u64* coeffs, u32 npoly, size_t woff, u64* oa, u64* ob, int accumulate) -> int {
       u32 ng = (npoly + GS - 1) / GS;
       for (u32 g0 = 0; g0 < ng; g0 += 32) {
         u32 gc = std::min<u32>(32, ng - g0);
         hipLaunchKernelGGL(fri_combine_partial_kernel, dim3((unsigned)((n + 255) / 256), gc), dim3(256), 0, st, coeffs + (size_t)g0 * GS * n, n,
                            npoly - g0 * GS, GS, fri_alpha.a.v, fri_alpha.b.v, P->d_part, P->d_part + 32 * n);
-        std::vector<u64> w(2 * gc);
-        E2 ag = e2_pow(fri_alpha, GS), cur = weight0 * e2_pow(fri_alpha, (u64)g0 * GS);
-        for (u32 k = 0; k < gc; k++) { w[2 * k] = cur.a.v; w[2 * k + 1] = cur.b.v; cur = cur * ag; }
-        HIPC(hipMemcpyAsync(P->d_w, w.data(), w.size() * sizeof(u64), hipMemcpyHostToDevice, st));
-        HIPC(hipStreamSynchronize(st));  // w is a stack buffer
-        hipLaunchKernelGGL(fri_combine_reduce_kernel, blocks(n), dim3(256), 0, st, P->d_part, P->d_part + 32 * n, n, gc, P->d_w, oa, ob,
+        hipLaunchKernelGGL(fri_combine_reduce_kernel, blocks(n), dim3(256), 0, st, P->d_part, P->d_part + 32 * n, n, gc, P->d_w + woff + 2 * g0, oa, ob,
                            (accumulate || g0 > 0) ? 1 : 0);
       }
       HIPC(hipGetLastError());
       return 0;
     };
     u64 *f1a = P->d_fb, *f1b = P->d_fb + n, *f0a = P->d_fa, *f0b = P->d_fa + n;
-    E2 one{F(1), F(0)};
-    if ((rc = combine(P->d_coef, (u32)C, one, f1a, f1b, 0))) return rc;
-    if (Z) if ((rc = combine(P->d_zcoef, (u32)Z, e2_pow(fri_alpha, C), f1a, f1b, 1))) return rc;
+    if ((rc = combine(P->d_coef, (u32)C, w_t, f1a, f1b, 0))) return rc;
+    if (Z) if ((rc = combine(P->d_zcoef, (u32)Z, w_z, f1a, f1b, 1))) return rc;
     HIPC(hipMemcpyAsync(f0a, f1a, 2 * n * sizeof(u64), hipMemcpyDeviceToDevice, st));
-    if ((rc = combine(P->d_q, 4, e2_pow(fri_alpha, C + Z), f0a, f0b, 1))) return rc;
+    if ((rc = combine(P->d_q, 4, w_q, f0a, f0b, 1))) return rc;
+    HIPC(hipStreamSynchronize(st));  // `wall` (pageable host memory) must outlive its upload
     // final_poly = alpha^(C+Z) * (F0 / (X - zeta)) + F1 / (X - g zeta), padded back to n, then lde -> m
     HIPC(hipMemsetAsync(P->d_fcoef, 0, 2 * m * sizeof(u64), st));
     E2 shift2 = e2_pow(fri_alpha, C + Z);
@@ -474,7 +539,7 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
       if ((rc = ntt_columns(P, va, clen, va, clen, P->d_tmp, m, 2, bits, false, clen, nullptr, nullptr, 1))) return rc;
       DevTree& t = P->fri_trees[li];
       hipLaunchKernelGGL(fri_leaf_hash_kernel, blocks(t.nleaf), dim3(256), 0, st, va, vb, bits, ab, t.d);
-      if ((rc = tree_build_inner(P, t))) return rc;
+      if ((rc = tree_build_inner(P, t, st))) return rc;
       std::vector<u64> cap;
       if ((rc = tree_cap_to_host(P, t, cap))) return rc;
       ch.observe_words(cap.data(), capw);
@@ -610,14 +675,23 @@ extern "C" int sbn_commit_values(const uint64_t* cols, size_t ncols, size_t n, u
     if (hipMemcpy(d_vals, cols, ncols * n * sizeof(u64), hipMemcpyHostToDevice) != hipSuccess) rc = fail(SBN_ERR_HIP, "H2D failed");
   }
   if (!rc) rc = intt_then_lde(&P, d_vals, d_coef, d_lde, ncols);
-  if (!rc) rc = tree_from_matrix(&P, P.tree_t, d_lde, ncols);
+  if (!rc && ncols <= 4) rc = tree_from_matrix(&P, P.tree_t, d_lde, ncols);
+  if (!rc && ncols > 4) {  // same chunked sponge as the prover (chunks of 64 columns), on one stream
+    rc = dmalloc(&P.d_sponge, 12 * P.m);
+    for (size_t c0 = 0; !rc && c0 < ncols; c0 += 64) {
+      size_t nc = std::min<size_t>(64, ncols - c0);
+      hipLaunchKernelGGL(leaf_absorb_kernel, dim3((unsigned)((P.m + 255) / 256)), dim3(256), 0, P.stream, d_lde + c0 * P.m, P.m, P.lde_log, (u32)nc, P.d_sponge,
+                         c0 == 0 ? 1 : 0, c0 + 64 >= ncols ? 1 : 0, P.tree_t.d);
+    }
+    if (!rc) rc = tree_build_inner(&P, P.tree_t, P.stream);
+  }
   std::vector<u64> cap;
   if (!rc) rc = tree_cap_to_host(&P, P.tree_t, cap);
   if (!rc) memcpy(cap_out, cap.data(), cap.size() * sizeof(u64));
   if (!rc && coeffs_out && hipMemcpy(coeffs_out, d_coef, ncols * n * sizeof(u64), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(SBN_ERR_HIP, "D2H failed");
   if (!rc && lde_out && hipMemcpy(lde_out, d_lde, ncols * P.m * sizeof(u64), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(SBN_ERR_HIP, "D2H failed");
-  for (u64* b : {d_vals, d_coef, d_lde, P.d_tmp, P.d_tw_f, P.d_tw_i, P.d_shift, P.tree_t.d}) if (b) hipFree(b);
-  hipStreamDestroy(P.stream);
+  for (u64* b : {d_vals, d_coef, d_lde, P.d_tmp, P.d_tw_f, P.d_tw_i, P.d_shift, P.tree_t.d, P.d_sponge}) if (b) (void)hipFree(b);
+  (void)hipStreamDestroy(P.stream);
   return rc;
 }
 
@@ -632,7 +706,7 @@ extern "C" int sbn_poseidon_permute_batch(uint64_t* states, size_t count) {
   HIPC(hipMemcpy(d, states, count * 12 * sizeof(u64), hipMemcpyHostToDevice));
   hipLaunchKernelGGL(poseidon_batch_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, 0, d, count);
   HIPC(hipMemcpy(states, d, count * 12 * sizeof(u64), hipMemcpyDeviceToHost));
-  hipFree(d);
+  (void)hipFree(d);
   return SBN_OK;
 }
 
