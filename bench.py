@@ -33,7 +33,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--seed", type=int, default=1000)
     ap.add_argument("--skip-cpu-baseline", action="store_true")
-    ap.add_argument("--traffic-bytes", type=float, default=None, help="PMC-measured HBM bytes per dominant-kernel launch (from profiles/)")
+    ap.add_argument("--traffic-bytes", type=float, default=None,
+                    help="PMC-measured HBM bytes per dominant-kernel launch; default: profiles/*_pmc_summary.json (separate rocprofv3 --pmc passes)")
     args = ap.parse_args()
 
     import numpy as np
@@ -99,6 +100,8 @@ def main():
 
     if rank == 0:
         steps = max(args.steps, 1)
+        if args.traffic_bytes is None:
+            args.traffic_bytes = committed_traffic("leaf_absorb_kernel")
         n, m, C = 1 << DEGREE_BITS, 1 << (DEGREE_BITS + 1), stark.num_columns
         Zc = stark.num_permutation_zs(cfg)
         stage_ms = {k: v / steps for k, v in stage_acc.items()}
@@ -141,6 +144,16 @@ def main():
     prover.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def committed_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the newest committed PMC summary (tools/summarize_pmc.py)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
+    if not files:
+        return None
+    d = json.load(open(files[-1]))
+    return d.get(kernel, {}).get("hbm_bytes_per_launch_corrected")
 
 
 def synthetic_ios(num_io, seed):

@@ -568,8 +568,11 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
     for (int i = 0; i < 12; i++) pp.state[i] = ch.st[i].v;
     for (size_t i = 0; i < ch.in.size(); i++) pp.state[i] = ch.in[i].v;
     pp.wpos = (u32)ch.in.size(); pp.min_lz = cfg.proof_of_work_bits; pp.result = P->d_pow;
-    const u64 BATCH = 1ULL << 20;
-    for (u64 base = 0; pow_witness == ~0ULL; base += BATCH) {
+    // candidates are scanned in increasing windows (2^17, then 2^20 each): a 16-bit PoW is found in the
+    // first window with probability 1 - e^-2; the smallest witness over the scanned prefix is kept.
+    u64 base = 0;
+    for (int round = 0; pow_witness == ~0ULL; round++) {
+      const u64 BATCH = round == 0 ? (1ULL << 17) : (1ULL << 20);
       if (base >= GLP - BATCH) return fail(SBN_ERR_HIP, "proof of work failed");
       u64 init = ~0ULL;
       HIPC(hipMemcpyAsync(P->d_pow, &init, sizeof(u64), hipMemcpyHostToDevice, st));
@@ -577,6 +580,7 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
       hipLaunchKernelGGL(pow_kernel, blocks(BATCH), dim3(256), 0, st, pp);
       HIPC(hipMemcpyAsync(&pow_witness, P->d_pow, sizeof(u64), hipMemcpyDeviceToHost, st));
       HIPC(hipStreamSynchronize(st));
+      base += BATCH;
     }
     ch.observe(F(pow_witness));
     F resp = ch.challenge();
