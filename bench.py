@@ -33,6 +33,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--seed", type=int, default=1000)
     ap.add_argument("--skip-cpu-baseline", action="store_true")
+    ap.add_argument("--table", choices=["g1", "g2"], default="g1",
+                    help="g1 = G1ExpStark(128), the BASELINE metric (default); g2 = G2ExpStark(128), BASELINE config[3]")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="PMC-measured HBM bytes per dominant-kernel launch; default: profiles/*_pmc_summary.json (separate rocprofv3 --pmc passes)")
     args = ap.parse_args()
@@ -63,9 +65,9 @@ def main():
 
     # synthetic inputs: random G1 points and 256-bit scalars (src/curves/g1/exp.rs:794-809), one instance set per rank
     from starky_bn254_amd import sharding
-    stark = S.G1ExpStark(NUM_IO)
+    stark = S.G1ExpStark(NUM_IO) if args.table == "g1" else S.G2ExpStark(NUM_IO)
     cfg = stark.config()
-    ios = synthetic_ios(NUM_IO, sharding.unit_seed(args.seed, rank))
+    ios = synthetic_ios(NUM_IO, sharding.unit_seed(args.seed, rank), args.table)
     t0 = time.time()
     trace, pi = stark.generate_trace_and_public_inputs(ios)
     t_tracegen = time.time() - t0
@@ -112,18 +114,18 @@ def main():
         alg_bytes = tot_bytes / launches
         dom_ms = stage_ms.get("trace_absorb_kernels_ms", float("nan")) / launches
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms and dom_ms > 0 else None
-        p_cols = 1 + 381 + 762                             # distinct trace columns read by the permutation argument
+        p_cols = 1 + 3 * (Zc // 2)                         # distinct trace columns read by the permutation argument
         proof_alg_bytes = 8.0 * n * (6 * C + 7 * Zc + p_cols)   # 8.67 GB
         ms_per_step = elapsed / steps * 1e3
         line = {
-            "metric": "G1 scalar-mult proofs/sec at trace height 2^16",
+            "metric": "G1 scalar-mult proofs/sec at trace height 2^16" if args.table == "g1" else "G2 scalar-mult proofs/sec at trace height 2^16",
             "value": world * steps / elapsed,
             "unit": "proofs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "G1ExpStark(num_io=128): prove() of a 2^16-row x 1676-column trace (128 scalar mults), trace resident in HBM",
+            "config": {"workload": f"{type(stark).__name__}(num_io=128): prove() of a 2^16-row x {C}-column trace (128 scalar mults), trace resident in HBM",
                        "degree_bits": DEGREE_BITS, "num_columns": C, "num_public_inputs": stark.num_public_inputs,
                        "permutation_zs": Zc, "fri": "rate_bits=1 cap=4 arity=16 queries=84 pow_bits=16",
                        "proofs_per_rank": args.steps, "parallelism": f"independent proofs x{world}, no collective"},
@@ -139,7 +141,7 @@ def main():
             "host": {"tracegen_s": t_tracegen, "h2d_s": t_h2d, "trace_bytes": int(trace.nbytes)},
         }
         if world == 1 and not args.skip_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(trace, pi)
+            line["cpu_baseline"] = cpu_baseline(trace, pi, args.table)
         print(json.dumps(line), flush=True)
     prover.close()
     if dist is not None:
@@ -156,11 +158,14 @@ def committed_traffic(kernel):
     return d.get(kernel, {}).get("hbm_bytes_per_launch_corrected")
 
 
-def synthetic_ios(num_io, seed):
-    """num_io x (x, offset: random G1 affine points; exp_val: 8 uniform u32 limbs), u32 LE limbs."""
+def synthetic_ios(num_io, seed, table="g1"):
+    """num_io x (x, offset: random affine points; exp_val: 8 uniform u32 limbs), u32 LE limbs.
+    g1: points on y^2 = x^3 + 3 over Fq; g2: points on the twist y^2 = x^3 + 3/(9+i) over Fq2."""
     import numpy as np
     P = 21888242871839275222246405745257275088696311157297823662689037894645226208583
     rng = np.random.default_rng(seed)
+    if table == "g2":
+        return synthetic_ios_g2(num_io, rng, P)
 
     def point():
         while True:
@@ -178,14 +183,64 @@ def synthetic_ios(num_io, seed):
     return ios
 
 
-def cpu_baseline(trace, pi):
+def synthetic_ios_g2(num_io, rng, P):
+    import numpy as np
+
+    def mul(a, b):
+        return ((a[0] * b[0] - a[1] * b[1]) % P, (a[0] * b[1] + a[1] * b[0]) % P)
+
+    def add(a, b):
+        return ((a[0] + b[0]) % P, (a[1] + b[1]) % P)
+
+    def inv(a):
+        n = pow(a[0] * a[0] + a[1] * a[1], -1, P)
+        return (a[0] * n % P, (-a[1]) * n % P)
+
+    def fpow(a, e):
+        r = (1, 0)
+        while e:
+            if e & 1:
+                r = mul(r, a)
+            a = mul(a, a)
+            e >>= 1
+        return r
+
+    def sqrt(a):                                   # p = 3 mod 4
+        a1 = fpow(a, (P - 3) // 4)
+        alpha = mul(mul(a1, a1), a)
+        if mul(fpow(alpha, P), alpha) == (P - 1, 0):
+            return None
+        x0 = mul(a1, a)
+        if alpha == (P - 1, 0):
+            return mul((0, 1), x0)
+        return mul(fpow(add((1, 0), alpha), (P - 1) // 2), x0)
+
+    b2 = mul((3, 0), inv((9, 1)))
+
+    def point():
+        while True:
+            x = (int.from_bytes(rng.bytes(32), "little") % P, int.from_bytes(rng.bytes(32), "little") % P)
+            rhs = add(mul(mul(x, x), x), b2)
+            y = sqrt(rhs)
+            if y is not None and mul(y, y) == rhs:
+                return [x[0], x[1], y[0], y[1]]
+
+    ios = np.zeros((num_io, 72), dtype=np.uint32)
+    for k in range(num_io):
+        for j, v in enumerate(point() + point()):
+            ios[k, 8 * j:8 * j + 8] = [(v >> (32 * i)) & 0xFFFFFFFF for i in range(8)]
+        ios[k, 64:72] = rng.integers(0, 1 << 32, size=8, dtype=np.uint64)
+    return ios
+
+
+def cpu_baseline(trace, pi, table="g1"):
     """The CPU oracle's prove() (a restatement "port", OpenMP over all host cores) on the SAME trace.
     Sample: one full proof -- the smallest unit of this workload (the table cannot be smaller than 2^16 rows)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
-    words, secs = O.prove(O.AIR_G1_EXP, NUM_IO, trace, pi)
+    words, secs = O.prove(O.AIR_G1_EXP if table == "g1" else O.AIR_G2_EXP, NUM_IO, trace, pi)
     return {"value": 1.0 / secs, "unit": "proofs/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": "1 full G1ExpStark(128) 2^16-row prove() on the same trace (oracle/, OpenMP on all host cores)",
+            "sample": "1 full 2^16-row prove() on the same trace (oracle/, OpenMP on all host cores): the smallest unit of this workload",
             "seconds": secs}
 
 

@@ -53,11 +53,12 @@ typedef enum sbn_status {
 
 /* Table kinds.  G1_OP = reference `G1Stark` (src/curves/g1/muladd.rs:462-624);
  * G1_EXP = reference `G1ExpStark` (src/curves/g1/exp.rs:232-742). */
-typedef enum sbn_air_kind { SBN_AIR_G1_OP = 1, SBN_AIR_G1_EXP = 2 } sbn_air_kind;
+typedef enum sbn_air_kind { SBN_AIR_G1_OP = 1, SBN_AIR_G1_EXP = 2, SBN_AIR_G2_EXP = 3 } sbn_air_kind;
+/* G2_EXP = reference `G2ExpStark` (src/curves/g2/exp.rs:248-807): the same machine over Fq2 coordinates. */
 
 typedef struct sbn_air_desc {
   int32_t kind;    /* sbn_air_kind */
-  uint32_t num_io; /* G1_EXP: number of scalar-mult instances (rows = 512*num_io); G1_OP: ignored */
+  uint32_t num_io; /* G1_EXP / G2_EXP: number of scalar-mult instances (rows = 512*num_io); G1_OP: ignored */
 } sbn_air_desc;
 
 /* Mirrors starky `StarkConfig` + plonky2 `FriConfig` (reference: stark.config() ->
@@ -94,6 +95,10 @@ size_t sbn_air_num_constraints(const sbn_air_desc* air); /* AIR constraints per 
  * ios: num_io x 40 u32 = x.x[8] x.y[8] offset.x[8] offset.y[8] exp_val[8]  (u32 limbs, LE).
  * trace_out: column-major [num_columns][512*num_io]; pi_out: [56*num_io]. */
 int sbn_generate_trace_g1_exp(const uint32_t* ios, size_t num_io, uint64_t* trace_out, uint64_t* pi_out);
+/* G2ExpStark::generate_trace / generate_public_inputs (src/curves/g2/exp.rs:307-342).
+ * ios: num_io x 72 u32 = x.x.c0 x.x.c1 x.y.c0 x.y.c1 offset.x.c0 offset.x.c1 offset.y.c0 offset.y.c1 exp_val
+ * (8 u32 limbs each); trace_out: [num_columns][512*num_io]; pi_out: [104*num_io]. */
+int sbn_generate_trace_g2_exp(const uint32_t* ios, size_t num_io, uint64_t* trace_out, uint64_t* pi_out);
 /* pts: rows x 32 u32 = a.x[8] a.y[8] b.x[8] b.y[8]; trace_out: [num_columns][rows]. */
 int sbn_generate_trace_g1_op(const uint32_t* pts, size_t rows, uint64_t* trace_out);
 

@@ -493,6 +493,127 @@ static inline void eval_split_u16_range_check(Consumer<P>& yc, const P* lv, cons
   yc.constraint_last_row(cur - cst<P>(255));
 }
 
+
+// ---- src/fields/fq2.rs, src/curves/g2/muladd.rs -------------------------------------------------------------
+template <class T> using Fq2Limbs = Arr<Arr<T, 16>, 2>;
+template <class T> using Fq2Wide = Arr<Arr<T, 31>, 2>;
+// pol_mul_fq2 fq2.rs:41-58
+template <class T> static inline Fq2Wide<T> pol_mul_fq2(const Fq2Limbs<T>& x, const Fq2Limbs<T>& y) {
+  Fq2Wide<T> z;
+  z[0] = pol_sub_normal(pol_mul_wide(x[0], y[0]), pol_mul_wide(x[1], y[1]));
+  Arr<T, 31> a = pol_mul_wide(x[0], y[1]), b = pol_mul_wide(x[1], y[0]);
+  for (int i = 0; i < 31; i++) z[1][i] = a[i] + b[i];
+  return z;
+}
+template <class T> static inline Fq2Wide<T> to_wide_fq2(const Fq2Limbs<T>& x) { Fq2Wide<T> z; z[0] = widen(x[0]); z[1] = widen(x[1]); return z; }
+template <class T, size_t N> static inline Arr<Arr<T, N>, 2> pol_sub_fq2(const Arr<Arr<T, N>, 2>& x, const Arr<Arr<T, N>, 2>& y) {
+  Arr<Arr<T, N>, 2> z; z[0] = pol_sub_normal(x[0], y[0]); z[1] = pol_sub_normal(x[1], y[1]); return z;
+}
+template <class T, size_t N> static inline Arr<Arr<T, N>, 2> pol_add_fq2(const Arr<Arr<T, N>, 2>& x, const Arr<Arr<T, N>, 2>& y) {
+  Arr<Arr<T, N>, 2> z; for (int c = 0; c < 2; c++) for (size_t i = 0; i < N; i++) z[c][i] = x[c][i] + y[c][i]; return z;
+}
+template <class T, size_t N> static inline Arr<Arr<T, N>, 2> pol_mul_scalar_fq2(const Arr<Arr<T, N>, 2>& x, T c) {
+  Arr<Arr<T, N>, 2> z; z[0] = pol_mul_scalar(x[0], c); z[1] = pol_mul_scalar(x[1], c); return z;
+}
+template <class T> struct G2Output {  // muladd.rs:32-40 ; 640 columns (:56-80)
+  Fq2Limbs<T> lambda, new_x, new_y;
+  ModulusAuxZero<T> aux_zeros[2]; ModulusAux<T> auxs[4];
+  T quot_sign_zeros[2], quot_signs[4];
+};
+static const int G2_OUTPUT_COLS = 40 * N_LIMBS;
+template <class T> static inline Fq2Limbs<T> read_fq2(const T* lv, int& cur) { Fq2Limbs<T> r; r[0] = read16(lv, cur); r[1] = read16(lv, cur); return r; }
+template <class T> static inline G2Output<T> read_g2_output(const T* lv, int& cur) {  // :82-116
+  G2Output<T> o;
+  o.lambda = read_fq2(lv, cur); o.new_x = read_fq2(lv, cur); o.new_y = read_fq2(lv, cur);
+  for (int i = 0; i < 2; i++) { o.aux_zeros[i].quot_abs = readn<T, 17>(lv, cur); o.aux_zeros[i].aux_input_lo = readn<T, 31>(lv, cur); o.aux_zeros[i].aux_input_hi = readn<T, 31>(lv, cur); }
+  for (int i = 0; i < 4; i++) { o.auxs[i].out_aux_red = read16(lv, cur); o.auxs[i].quot_abs = readn<T, 17>(lv, cur); o.auxs[i].aux_input_lo = readn<T, 31>(lv, cur); o.auxs[i].aux_input_hi = readn<T, 31>(lv, cur); }
+  for (int i = 0; i < 2; i++) o.quot_sign_zeros[i] = lv[cur++];
+  for (int i = 0; i < 4; i++) o.quot_signs[i] = lv[cur++];
+  return o;
+}
+template <class P>
+static inline void eval_g2_tail(Consumer<P>& yc, P filter, const Fq2Wide<P>& zero_pol, const Fq2Wide<P>& new_x_input, const Fq2Limbs<P>& x1, const Fq2Limbs<P>& y1, const G2Output<P>& o) {
+  Arr<P, 16> modulus = bn254_modulus_p<P>();
+  for (int i = 0; i < 2; i++) eval_modular_zero(yc, filter, modulus, zero_pol[i], o.quot_sign_zeros[i], o.aux_zeros[i]);
+  for (int i = 0; i < 2; i++) eval_modular_op(yc, filter, modulus, new_x_input[i], o.new_x[i], o.quot_signs[i], o.auxs[i]);
+  Fq2Wide<P> new_y_input = pol_sub_fq2(pol_mul_fq2(o.lambda, pol_sub_fq2(x1, o.new_x)), to_wide_fq2(y1));
+  for (int i = 0; i < 2; i++) eval_modular_op(yc, filter, modulus, new_y_input[i], o.new_y[i], o.quot_signs[i + 2], o.auxs[i + 2]);
+}
+// eval_g2_add :416-472
+template <class P>
+static inline void eval_g2_add(Consumer<P>& yc, P filter, const Fq2Limbs<P>& a_x, const Fq2Limbs<P>& a_y, const Fq2Limbs<P>& b_x, const Fq2Limbs<P>& b_y, const G2Output<P>& o) {
+  Fq2Wide<P> zero_pol = pol_sub_fq2(pol_mul_fq2(o.lambda, pol_sub_fq2(b_x, a_x)), to_wide_fq2(pol_sub_fq2(b_y, a_y)));
+  Fq2Wide<P> new_x_input = pol_sub_fq2(pol_mul_fq2(o.lambda, o.lambda), to_wide_fq2(pol_add_fq2(a_x, b_x)));
+  eval_g2_tail(yc, filter, zero_pol, new_x_input, a_x, a_y, o);
+}
+// eval_g2_double :203-261
+template <class P>
+static inline void eval_g2_double(Consumer<P>& yc, P filter, const Fq2Limbs<P>& x, const Fq2Limbs<P>& y, const G2Output<P>& o) {
+  Fq2Wide<P> zero_pol = pol_sub_fq2(pol_mul_scalar_fq2(pol_mul_fq2(o.lambda, y), cst<P>(2)), pol_mul_scalar_fq2(pol_mul_fq2(x, x), cst<P>(3)));
+  Fq2Wide<P> new_x_input = pol_sub_fq2(pol_mul_fq2(o.lambda, o.lambda), to_wide_fq2(pol_mul_scalar_fq2(x, cst<P>(2))));
+  eval_g2_tail(yc, filter, zero_pol, new_x_input, x, y, o);
+}
+
+// Fq2 = Fq[i]/(i^2+1) witness arithmetic (arkworks Fq2 in the reference, muladd.rs:118-126, :330-341)
+struct Fq2 { Fq c0, c1; };
+static inline Fq2 fq2_add(const Fq2& a, const Fq2& b) { return {fq_add(a.c0, b.c0), fq_add(a.c1, b.c1)}; }
+static inline Fq2 fq2_sub(const Fq2& a, const Fq2& b) { return {fq_sub(a.c0, b.c0), fq_sub(a.c1, b.c1)}; }
+static inline Fq2 fq2_mul(const Fq2& a, const Fq2& b) {
+  return {fq_sub(fq_mul(a.c0, b.c0), fq_mul(a.c1, b.c1)), fq_add(fq_mul(a.c0, b.c1), fq_mul(a.c1, b.c0))};
+}
+static inline Fq2 fq2_inv(const Fq2& a) {
+  Fq n = fq_inv(fq_add(fq_mul(a.c0, a.c0), fq_mul(a.c1, a.c1)));
+  return {fq_mul(a.c0, n), fq_sub(fq_from_u64(0), fq_mul(a.c1, n))};
+}
+struct U256x2 { U256 c0, c1; };
+struct G2Affine { U256x2 x, y; };
+static inline Fq2 fq2_from(const U256x2& v) { return {fq_from_u256(v.c0), fq_from_u256(v.c1)}; }
+
+// generate_g2_add (:330-414) / generate_g2_double (:118-201): writes lv[0..640), returns new_x, new_y.
+static inline void generate_g2_op(bool is_double, const U256x2& ax, const U256x2& ay, const U256x2& bx, const U256x2& by, GF* lv, U256x2& nx, U256x2& ny) {
+  Fq2 x1 = fq2_from(ax), y1 = fq2_from(ay), lambda;
+  if (is_double) {
+    Fq2 x2 = fq2_mul(x1, x1);
+    Fq2 num = fq2_add(fq2_add(x2, x2), x2), den = fq2_add(y1, y1);
+    assert(!(den.c0.m.is_zero() && den.c1.m.is_zero()));
+    lambda = fq2_mul(num, fq2_inv(den));
+  } else {
+    Fq2 x2 = fq2_from(bx), y2 = fq2_from(by), den = fq2_sub(x2, x1);
+    assert(!(den.c0.m.is_zero() && den.c1.m.is_zero()));
+    lambda = fq2_mul(fq2_sub(y2, y1), fq2_inv(den));
+  }
+  auto limbs2 = [](const U256x2& v) { Fq2Limbs<int64_t> r; r[0] = u256_to_limbs16(v.c0); r[1] = u256_to_limbs16(v.c1); return r; };
+  Fq2Limbs<int64_t> l; l[0] = u256_to_limbs16(fq_to_u256(lambda.c0)); l[1] = u256_to_limbs16(fq_to_u256(lambda.c1));
+  Fq2Limbs<int64_t> axl = limbs2(ax), ayl = limbs2(ay), bxl = is_double ? axl : limbs2(bx), byl = is_double ? ayl : limbs2(by);
+  Fq2Wide<int64_t> zero_pol;
+  if (is_double) zero_pol = pol_sub_fq2(pol_mul_scalar_fq2(pol_mul_fq2(l, ayl), (int64_t)2), pol_mul_scalar_fq2(pol_mul_fq2(axl, axl), (int64_t)3));
+  else zero_pol = pol_sub_fq2(pol_mul_fq2(l, pol_sub_fq2(bxl, axl)), to_wide_fq2(pol_sub_fq2(byl, ayl)));
+  ModWitness wz[2], wx[2], wy[2];
+  for (int i = 0; i < 2; i++) wz[i] = generate_modular_witness(zero_pol[i], true);
+  Fq2Wide<int64_t> new_x_input = pol_sub_fq2(pol_mul_fq2(l, l), to_wide_fq2(pol_add_fq2(axl, bxl)));
+  for (int i = 0; i < 2; i++) wx[i] = generate_modular_witness(new_x_input[i], false);
+  Fq2Limbs<int64_t> nxl; nxl[0] = wx[0].output; nxl[1] = wx[1].output;
+  Fq2Wide<int64_t> new_y_input = pol_sub_fq2(pol_mul_fq2(l, pol_sub_fq2(axl, nxl)), to_wide_fq2(ayl));
+  for (int i = 0; i < 2; i++) wy[i] = generate_modular_witness(new_y_input[i], false);
+  int cur = 0;
+  for (int c = 0; c < 2; c++) for (int i = 0; i < 16; i++) lv[cur++] = GF((u64)l[c][i]);
+  for (int c = 0; c < 2; c++) for (int i = 0; i < 16; i++) lv[cur++] = GF((u64)wx[c].output[i]);
+  for (int c = 0; c < 2; c++) for (int i = 0; i < 16; i++) lv[cur++] = GF((u64)wy[c].output[i]);
+  for (int i = 0; i < 2; i++) write_mod_aux(lv, cur, wz[i], false);
+  for (int i = 0; i < 2; i++) write_mod_aux(lv, cur, wx[i], true);
+  for (int i = 0; i < 2; i++) write_mod_aux(lv, cur, wy[i], true);
+  for (int i = 0; i < 2; i++) lv[cur++] = GF::from_i64(wz[i].quot_sign);
+  for (int i = 0; i < 2; i++) lv[cur++] = GF::from_i64(wx[i].quot_sign);
+  for (int i = 0; i < 2; i++) lv[cur++] = GF::from_i64(wy[i].quot_sign);
+  assert(cur == G2_OUTPUT_COLS);
+  nx.c0 = limbs16_to_u256(wx[0].output.data()); nx.c1 = limbs16_to_u256(wx[1].output.data());
+  ny.c0 = limbs16_to_u256(wy[0].output.data()); ny.c1 = limbs16_to_u256(wy[1].output.data());
+}
+static inline void write_g2_output_default(GF* lv) {  // G2Output::default :42-54
+  for (int i = 0; i < G2_OUTPUT_COLS - 6; i++) lv[i] = GF();
+  for (int i = G2_OUTPUT_COLS - 6; i < G2_OUTPUT_COLS; i++) lv[i] = GF::one();
+}
+
 // ---- tables ---------------------------------------------------------------------------------------------------------
 template <class Derived>
 struct AirBase : Air {
@@ -673,6 +794,126 @@ struct G1ExpAir : AirBase<G1ExpAir> {
       put(in.x.x); put(in.x.y); put(in.offset.x); put(in.offset.y);
       for (int i = 0; i < 8; i++) pi.push_back(GF(in.exp_val[i]));
       put(in.output.x); put(in.output.y);
+    }
+    return pi;
+  }
+};
+
+// G2ExpStark: src/curves/g2/exp.rs (same machine as G1ExpStark over Fq2 coordinates).
+struct G2ExpIONative { G2Affine x, offset; uint32_t exp_val[NUM_INPUT_LIMBS]; G2Affine output; };  // :90-95
+struct G2ExpAir : AirBase<G2ExpAir> {
+  size_t num_io;
+  int start_flags_col, num_main_cols, start_periodic_pulse_col, start_io_pulses_col, start_lookups_col, num_range_check_cols;  // constants :6-34
+  size_t ncols, npi;
+  std::vector<size_t> pulse_positions;
+  explicit G2ExpAir(size_t n) : num_io(n) {
+    start_flags_col = 48 * N_LIMBS;
+    num_main_cols = start_flags_col + NUM_FLAGS_COLS;
+    start_periodic_pulse_col = num_main_cols;
+    start_io_pulses_col = start_periodic_pulse_col + 2;
+    start_lookups_col = start_io_pulses_col + 1 + 4 * (int)num_io;
+    num_range_check_cols = 48 * N_LIMBS - 6;
+    ncols = start_lookups_col + 1 + 2 * num_range_check_cols;
+    npi = 13 * NUM_INPUT_LIMBS * num_io;
+    size_t rpb = 2 * INPUT_LIMB_BITS * NUM_INPUT_LIMBS;
+    for (size_t i = 0; i < num_io; i++) { pulse_positions.push_back(i * rpb); pulse_positions.push_back(i * rpb + rpb - 1); }
+  }
+  size_t num_columns() const override { return ncols; }
+  size_t num_public_inputs() const override { return npi; }
+  std::vector<std::pair<size_t, size_t>> permutation_pairs() const override {  // :800-806
+    std::vector<std::pair<size_t, size_t>> p;
+    for (int i = 0; i < num_range_check_cols; i++) {
+      p.push_back({(size_t)start_lookups_col, (size_t)start_lookups_col + 1 + 2 * i + 1});
+      p.push_back({(size_t)i, (size_t)start_lookups_col + 1 + 2 * i});
+    }
+    return p;
+  }
+  template <class P> void eval_t(const P* lv, const P* nv, const P* pi, Consumer<P>& yc) const {  // :345-507
+    int is_final_col = start_flags_col, is_double_col = start_flags_col + 2, is_add_col = start_flags_col + 4, start_limbs_col = start_flags_col + 6;
+    P one = cst<P>(1);
+    int cur = 0;
+    Fq2Limbs<P> a_x = read_fq2(lv, cur), a_y = read_fq2(lv, cur), b_x = read_fq2(lv, cur), b_y = read_fq2(lv, cur);
+    G2Output<P> output = read_g2_output(lv, cur);
+    P is_add = lv[is_add_col], is_double = lv[is_double_col], is_final = lv[is_final_col];
+    P is_not_final = one - is_final;
+    P sum_is_output = P();
+    for (size_t i = 1; i < 2 * num_io; i += 2) sum_is_output = sum_is_output + lv[get_pulse_col(start_io_pulses_col, (int)i)];
+    yc.constraint(is_final - sum_is_output);  // :374-379
+    {  // public inputs :382-414
+      Arr<P, 8> a32[4] = {G1ExpAir::u16_to_u32(a_x[0]), G1ExpAir::u16_to_u32(a_x[1]), G1ExpAir::u16_to_u32(a_y[0]), G1ExpAir::u16_to_u32(a_y[1])};
+      Arr<P, 8> b32[4] = {G1ExpAir::u16_to_u32(b_x[0]), G1ExpAir::u16_to_u32(b_x[1]), G1ExpAir::u16_to_u32(b_y[0]), G1ExpAir::u16_to_u32(b_y[1])};
+      Arr<P, 8> limbs; for (int k = 0; k < 8; k++) limbs[k] = lv[start_limbs_col + k];
+      limbs[0] = limbs[0] * cst<P>(2) + is_add;
+      size_t pc = 0;
+      for (size_t i = 0; i < 2 * num_io; i += 2) {
+        const P* io = pi + pc; pc += 104;  // x[4] offset[4] exp_val output[4]   (read_g2_exp_io :158-178)
+        P is_in = lv[get_pulse_col(start_io_pulses_col, (int)i)], is_out = lv[get_pulse_col(start_io_pulses_col, (int)i + 1)];
+        for (int q = 0; q < 4; q++) for (int k = 0; k < 8; k++) yc.constraint(is_in * (io[8 * q + k] - a32[q][k]));
+        for (int q = 0; q < 4; q++) for (int k = 0; k < 8; k++) yc.constraint(is_in * (io[32 + 8 * q + k] - b32[q][k]));
+        for (int q = 0; q < 4; q++) for (int k = 0; k < 8; k++) yc.constraint(is_out * (io[72 + 8 * q + k] - b32[q][k]));
+        for (int k = 0; k < 8; k++) yc.constraint(is_in * (io[64 + k] - limbs[k]));
+      }
+    }
+    cur = 0;
+    Fq2Limbs<P> n_a_x = read_fq2(nv, cur), n_a_y = read_fq2(nv, cur), n_b_x = read_fq2(nv, cur), n_b_y = read_fq2(nv, cur);
+    auto eqt = [&](P filter, const Fq2Limbs<P>& x, const Fq2Limbs<P>& y) { for (int c = 0; c < 2; c++) for (int i = 0; i < 16; i++) yc.constraint_transition(filter * (x[c][i] - y[c][i])); };
+    P fd = is_not_final * is_double;
+    eqt(fd, n_a_x, output.new_x); eqt(fd, n_a_y, output.new_y); eqt(fd, n_b_x, b_x); eqt(fd, n_b_y, b_y);
+    P fa = is_not_final * is_add;
+    eqt(fa, n_a_x, a_x); eqt(fa, n_a_y, a_y); eqt(fa, n_b_x, output.new_x); eqt(fa, n_b_y, output.new_y);
+    P fn = is_not_final * (one - is_double - is_add);
+    eqt(fn, n_a_x, a_x); eqt(fn, n_a_y, a_y); eqt(fn, n_b_x, b_x); eqt(fn, n_b_y, b_y);
+    eval_flags(yc, lv, nv, start_flags_col);                      // :474
+    eval_g2_add(yc, is_add, a_x, a_y, b_x, b_y, output);          // :475
+    eval_g2_double(yc, is_double, a_x, a_y, output);              // :476
+    eval_flags(yc, lv, nv, start_flags_col);                      // :479 (duplicate, kept)
+    eval_periodic_pulse(yc, lv, nv, start_flags_col + 1, start_periodic_pulse_col, 2 * INPUT_LIMB_BITS, 2 * INPUT_LIMB_BITS - 2);
+    eval_pulse(yc, lv, nv, start_io_pulses_col, pulse_positions);
+    eval_u16_range_check(yc, lv, nv, start_lookups_col, (size_t)num_range_check_cols);
+  }
+  void generate_block(const G2ExpIONative& in, std::vector<std::vector<GF>>& cols, size_t row0, G2Affine& out) const {  // :271-305
+    size_t num_rows = 2 * INPUT_LIMB_BITS * NUM_INPUT_LIMBS;
+    std::vector<GF> lv(num_main_cols, GF()), nvv(num_main_cols, GF());
+    int sf = start_flags_col;
+    auto put2 = [&](GF* r, int off, const U256x2& v) { auto l0 = u256_to_limbs16(v.c0), l1 = u256_to_limbs16(v.c1); for (int i = 0; i < 16; i++) { r[off + i] = GF((u64)l0[i]); r[off + 16 + i] = GF((u64)l1[i]); } };
+    generate_flags_first_row(lv.data(), sf, in.exp_val);
+    U256x2 ax = in.x.x, ay = in.x.y, bx = in.offset.x, by = in.offset.y, nx, ny;
+    put2(lv.data(), 0, ax); put2(lv.data(), 32, ay); put2(lv.data(), 64, bx); put2(lv.data(), 96, by);
+    if (lv[sf + 4] == GF::one()) generate_g2_op(false, ax, ay, bx, by, lv.data() + 128, nx, ny); else write_g2_output_default(lv.data() + 128);
+    for (int c = 0; c < num_main_cols; c++) cols[c][row0] = lv[c];
+    for (size_t i = 0; i + 1 < num_rows; i++) {
+      std::fill(nvv.begin(), nvv.end(), GF());
+      generate_flags_next_row(lv.data(), nvv.data(), i, sf);
+      if (lv[sf + 2] == GF::one()) { ax = nx; ay = ny; } else if (lv[sf + 4] == GF::one()) { bx = nx; by = ny; }
+      put2(nvv.data(), 0, ax); put2(nvv.data(), 32, ay); put2(nvv.data(), 64, bx); put2(nvv.data(), 96, by);
+      if (nvv[sf + 2] == GF::one()) generate_g2_op(true, ax, ay, ax, ay, nvv.data() + 128, nx, ny);
+      else if (nvv[sf + 4] == GF::one()) generate_g2_op(false, ax, ay, bx, by, nvv.data() + 128, nx, ny);
+      else write_g2_output_default(nvv.data() + 128);
+      for (int c = 0; c < num_main_cols; c++) cols[c][row0 + i + 1] = nvv[c];
+      lv.swap(nvv);
+    }
+    out.x = bx; out.y = by;
+  }
+  std::vector<std::vector<GF>> generate_trace(std::vector<G2ExpIONative>& inputs) const {  // :307-335
+    assert(inputs.size() == num_io);
+    size_t rpb = 2 * INPUT_LIMB_BITS * NUM_INPUT_LIMBS, rows = rpb * num_io;
+    std::vector<std::vector<GF>> cols(num_main_cols, std::vector<GF>(rows));
+#pragma omp parallel for schedule(dynamic, 1)
+    for (size_t k = 0; k < num_io; k++) generate_block(inputs[k], cols, k * rpb, inputs[k].output);
+    generate_periodic_pulse_witness(cols, start_flags_col + 1, 2 * INPUT_LIMB_BITS, 2 * INPUT_LIMB_BITS - 2);
+    generate_pulse(cols, pulse_positions);
+    generate_u16_range_check(0, (size_t)num_range_check_cols, cols);
+    assert(cols.size() == ncols);
+    return cols;
+  }
+  std::vector<GF> generate_public_inputs(const std::vector<G2ExpIONative>& inputs) const {  // :139-156, :337-342
+    std::vector<GF> pi;
+    auto put = [&](const U256& v) { for (int i = 0; i < 8; i++) pi.push_back(GF((v.l[i / 2] >> (32 * (i % 2))) & 0xffffffffULL)); };
+    auto put2 = [&](const U256x2& v) { put(v.c0); put(v.c1); };
+    for (auto& in : inputs) {
+      put2(in.x.x); put2(in.x.y); put2(in.offset.x); put2(in.offset.y);
+      for (int i = 0; i < 8; i++) pi.push_back(GF(in.exp_val[i]));
+      put2(in.output.x); put2(in.output.y);
     }
     return pi;
   }

@@ -19,7 +19,7 @@
 #include "gl.cuh"
 
 static constexpr int SBN_NCH = 2;              // StarkConfig.num_challenges (standard_fast_config)
-static constexpr int APOW_MAX = 7169;          // alpha^k table length (k <= 56*128)
+static constexpr int APOW_MAX = 13 * 8 * 128 + 1;  // alpha^k table length (k <= 104*128, G2ExpStark)
 static constexpr int G1EXP_MAX_IO = 128;
 
 // BN254 base-field modulus in 16-bit limbs (src/modular/modular.rs:298-309).
@@ -245,16 +245,114 @@ GL_HD void g1op_eval(Cons<P>& cs, const Row& row) {
   cs.merge(h_dbl, row.l(S::MAIN_COLS - 1), G1_GADGET_CONSTRAINTS);  // is_double
 }
 
-// ---- G1ExpStark (src/curves/g1/exp.rs) ------------------------------------------------------------
-struct G1ExpShape {  // constants(num_io), exp.rs:6-34
-  int num_io, start_flags, num_main, start_periodic, start_io_pulses, start_lookups, num_rc, num_cols, num_pi;
-  GL_HD explicit G1ExpShape(int n) {
-    num_io = n; start_flags = 24 * 16; num_main = start_flags + 14; start_periodic = num_main;
+// ---- G2 add/double gadget (src/curves/g2/muladd.rs:56-80 column order; 640 columns) --------------------
+namespace g2c {
+static constexpr int AX = 0, AY = 32, BX = 64, BY = 96, GB = 128;  // each Fq2 = c0[16] c1[16]
+static constexpr int LAM = GB, NX = GB + 32, NY = GB + 64;
+GL_HD int z_qa(int c) { return GB + 96 + 79 * c; }    // aux_zeros[c]: quot_abs(17) lo(31) hi(31)
+GL_HD int x_base(int c) { return GB + 254 + 95 * c; } // auxs[c]   : out_aux_red(16) quot_abs(17) lo(31) hi(31)
+GL_HD int y_base(int c) { return GB + 444 + 95 * c; } // auxs[2+c]
+static constexpr int SGN_Z = GB + 634, SGN_X = GB + 636, SGN_Y = GB + 638;
+}  // namespace g2c
+
+// eval_g2_add (muladd.rs:416-472) and eval_g2_double (:203-261) on one row: 330-constraint local sums.
+// Fq2 limb products (fq2.rs:41-58): (X*Y).c0 = X0*Y0 - X1*Y1, (X*Y).c1 = X0*Y1 + X1*Y0.
+template <class P, class Row>
+GL_HD void g2_gadget(const Cons<P>& cs, const Row& row, P* h_add, P* h_dbl) {
+  using namespace g2c;
+  const P one = lift<P>(1), base = lift<P>(65536), off = lift<P>(1ULL << 29), zero = lift<P>(0);
+  const P two = lift<P>(2), three = lift<P>(3);
+  Horner2<P> hza[2], hzd[2], hxa[2], hxd[2], hy[2];
+  P sz[2], sx[2], sy[2];
+  for (int c = 0; c < 2; c++) {
+    sz[c] = row.l(SGN_Z + c); sx[c] = row.l(SGN_X + c); sy[c] = row.l(SGN_Y + c);
+#pragma unroll
+    for (int j = 0; j < SBN_NCH; j++) { hza[c].h[j] = sz[c] * sz[c] - one; hxa[c].h[j] = zero; hy[c].h[j] = zero; }
+    modop_prefix(cs, row, x_base(c), NX + 16 * c, SGN_X + c, hxa[c]);
+    modop_prefix(cs, row, y_base(c), NY + 16 * c, SGN_Y + c, hy[c]);
+    hzd[c] = hza[c]; hxd[c] = hxa[c];
+  }
+  P pz[2] = {zero, zero}, px[2] = {zero, zero}, py[2] = {zero, zero};
+  for (int k = 0; k < 32; k++) {
+    P c1[2] = {zero, zero}, c2[2] = {zero, zero}, c3[2] = {zero, zero}, c4[2] = {zero, zero}, c5[2] = {zero, zero};
+    if (k < 31) {
+      int i0 = k > 15 ? k - 15 : 0, i1 = k < 15 ? k : 15;
+      for (int i = i0; i <= i1; i++) {
+        int j = k - i;
+        P l0 = row.l(LAM + i), l1 = row.l(LAM + 16 + i);
+        P ax0 = row.l(AX + j), ax1 = row.l(AX + 16 + j);
+        P d0 = row.l(BX + j) - ax0, d1 = row.l(BX + 16 + j) - ax1;        // delta_x
+        P y0 = row.l(AY + j), y1 = row.l(AY + 16 + j);
+        P m0 = row.l(LAM + j), m1 = row.l(LAM + 16 + j);
+        P e0 = ax0 - row.l(NX + j), e1 = ax1 - row.l(NX + 16 + j);         // x1 - new_x
+        P xi0 = row.l(AX + i), xi1 = row.l(AX + 16 + i);
+        c1[0] += l0 * d0 - l1 * d1;  c1[1] += l0 * d1 + l1 * d0;
+        c2[0] += l0 * y0 - l1 * y1;  c2[1] += l0 * y1 + l1 * y0;
+        c3[0] += xi0 * ax0 - xi1 * ax1;  c3[1] += xi0 * ax1 + xi1 * ax0;
+        c4[0] += l0 * m0 - l1 * m1;  c4[1] += l0 * m1 + l1 * m0;
+        c5[0] += l0 * e0 - l1 * e1;  c5[1] += l0 * e1 + l1 * e0;
+      }
+    }
+    P qz[2] = {zero, zero}, qx[2] = {zero, zero}, qy[2] = {zero, zero};
+    {
+      int i0 = k > 15 ? k - 15 : 0, i1 = k < 16 ? k : 16;
+      for (int i = i0; i <= i1; i++) {
+        P m = lift<P>(bn254_modulus_limb(k - i));
+        for (int c = 0; c < 2; c++) {
+          qz[c] += row.l(z_qa(c) + i) * m;
+          qx[c] += row.l(x_base(c) + 16 + i) * m;
+          qy[c] += row.l(y_base(c) + 16 + i) * m;
+        }
+      }
+    }
+    for (int c = 0; c < 2; c++) {
+      P az = zero, ax_ = zero, ay_ = zero;
+      if (k < 31) {
+        az = row.l(z_qa(c) + 17 + k) - off + base * row.l(z_qa(c) + 48 + k);
+        ax_ = row.l(x_base(c) + 33 + k) - off + base * row.l(x_base(c) + 64 + k);
+        ay_ = row.l(y_base(c) + 33 + k) - off + base * row.l(y_base(c) + 64 + k);
+      }
+      P adjz = pz[c] - base * az, adjx = px[c] - base * ax_, adjy = py[c] - base * ay_;
+      pz[c] = az; px[c] = ax_; py[c] = ay_;
+      P zk = sz[c] * qz[c] + adjz;
+      P xk = sx[c] * qx[c] + adjx;
+      P yk = sy[c] * qy[c] + adjy - c5[c];
+      P za = zk - c1[c], zd = zk - (two * c2[c] - three * c3[c]);
+      P xa = xk - c4[c], xd = xa;
+      if (k < 16) {
+        P axk = row.l(AX + 16 * c + k), ayk = row.l(AY + 16 * c + k), bxk = row.l(BX + 16 * c + k), nxk = row.l(NX + 16 * c + k);
+        za = za + (row.l(BY + 16 * c + k) - ayk);
+        xa = xa + nxk + (axk + bxk);
+        xd = xd + nxk + (axk + axk);
+        yk = yk + row.l(NY + 16 * c + k) + ayk;
+      }
+      hza[c].push(cs, za); hzd[c].push(cs, zd);
+      hxa[c].push(cs, xa); hxd[c].push(cs, xd);
+      hy[c].push(cs, yk);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < SBN_NCH; j++) {
+    const P* ap = cs.apow[j];
+    h_add[j] = hza[0].h[j] * ap[297] + hza[1].h[j] * ap[264] + hxa[0].h[j] * ap[198] + hxa[1].h[j] * ap[132] + hy[0].h[j] * ap[66] + hy[1].h[j];
+    h_dbl[j] = hzd[0].h[j] * ap[297] + hzd[1].h[j] * ap[264] + hxd[0].h[j] * ap[198] + hxd[1].h[j] * ap[132] + hy[0].h[j] * ap[66] + hy[1].h[j];
+  }
+}
+
+// ---- G1ExpStark / G2ExpStark (src/curves/g1/exp.rs, src/curves/g2/exp.rs) --------------------------------
+// Both tables are the same double-and-add machine; E = 1 (Fq coordinates) or 2 (Fq2 coordinates) scales
+// the point columns (32E per point), the gadget (320E columns, 165E constraints) and the public inputs.
+struct ExpShape {  // constants(num_io): g1/exp.rs:6-34, g2/exp.rs:6-34
+  int E, num_io, L, pi_per_io, b_col, gadget_col, nx_col, start_flags, num_main, start_periodic, start_io_pulses, start_lookups, num_rc, num_cols, num_pi;
+  GL_HD ExpShape(int e, int n) {
+    E = e; num_io = n; L = 16 * e; pi_per_io = 3 * L + 8; b_col = 32 * e; gadget_col = 64 * e; nx_col = gadget_col + 16 * e;
+    start_flags = 384 * e; num_main = start_flags + 14; start_periodic = num_main;
     start_io_pulses = start_periodic + 2; start_lookups = start_io_pulses + 1 + 4 * n;
-    num_rc = 24 * 16 - 3; num_cols = start_lookups + 1 + 2 * num_rc; num_pi = 56 * n;
+    num_rc = 381 * e; num_cols = start_lookups + 1 + 2 * num_rc; num_pi = pi_per_io * n;
   }
   GL_HD int num_pairs() const { return 2 * num_rc; }
-  GL_HD int num_constraints() const { return 1 + num_pi + 192 + 26 + 165 + 165 + 26 + 5 + 2 + 4 * num_io + 2 * num_rc + 3; }
+  GL_HD int gadget_constraints() const { return 165 * E; }
+  GL_HD int num_constraints() const { return 1 + num_pi + 3 * 64 * E + 26 + 2 * 165 * E + 26 + 5 + 2 + 4 * num_io + 2 * num_rc + 3; }
   // u16_range_check_pairs (range_check.rs:96-113)
   GL_HD void pair(int z, int& lhs, int& rhs) const {
     if (z & 1) { lhs = z >> 1; rhs = start_lookups + z; }
@@ -262,61 +360,63 @@ struct G1ExpShape {  // constants(num_io), exp.rs:6-34
   }
   GL_HD int witness_col(int i) const { return start_io_pulses + 1 + 2 * i; }  // pulse.rs:14
   GL_HD int pulse_col(int i) const { return start_io_pulses + 2 + 2 * i; }    // pulse.rs:10
+  // Emission slot m (0..pi_per_io) of one instance's vec_equal calls (g1/exp.rs:381-391, g2/exp.rs:391-414):
+  // x (L, input pulse), offset (L, input), output (L, output pulse), exp_val (8, input).
+  // Public inputs are stored x, offset, exp_val, output (g1_exp_io_to_columns / g2_exp_io_to_columns).
+  GL_HD int pi_index(int m) const { return m < 2 * L ? m : (m < 3 * L ? 2 * L + 8 + (m - 2 * L) : 2 * L + (m - 3 * L)); }
+  GL_HD bool slot_is_out(int m) const { return m >= 2 * L && m < 3 * L; }
+  // first of the two u16 columns forming u32 limb `m` of the compared value; -1 for the exponent limbs
+  GL_HD int slot_col(int m) const { return m < L ? 2 * m : (m < 2 * L ? b_col + 2 * (m - L) : (m < 3 * L ? b_col + 2 * (m - 2 * L) : -1)); }
 };
 
 // Per-proof constants of the regrouped public-input block: for challenge j and instance i,
-//   W = alpha_j^(56*(num_io-1-i)), WA = W * sum_{m in IN} alpha_j^(55-m) pi[i][..], WO likewise for OUT.
+//   W = alpha_j^(pi_per_io*(num_io-1-i)), WA = W * sum_{m in IN} alpha_j^(pi_per_io-1-m) pi[i][..], WO likewise for OUT.
 template <class P>
-struct G1ExpPiConsts {
+struct ExpPiConsts {
   P W[SBN_NCH][G1EXP_MAX_IO], WA[SBN_NCH][G1EXP_MAX_IO], WO[SBN_NCH][G1EXP_MAX_IO];
 };
-// Emission slot m (0..55) of one instance's vec_equal calls (exp.rs:381-391) -> public-input index
-// inside the instance's 56 values (g1_exp_io_to_columns order, exp.rs:124-135).
-GL_HD int g1exp_pi_index(int m) { return m < 32 ? m : (m < 48 ? 40 + (m - 32) : 32 + (m - 48)); }
-GL_HD bool g1exp_slot_is_out(int m) { return m >= 32 && m < 48; }
-
 template <class P>
-static inline void g1exp_pi_consts(const G1ExpShape& sh, const P* const apow[SBN_NCH], const P* pi, G1ExpPiConsts<P>& out) {
+static inline void exp_pi_consts(const ExpShape& sh, const P* const apow[SBN_NCH], const P* pi, ExpPiConsts<P>& out) {
+  const int S = sh.pi_per_io;
   for (int j = 0; j < SBN_NCH; j++)
     for (int i = 0; i < sh.num_io; i++) {
       P a = lift<P>(0), o = lift<P>(0);
-      for (int m = 0; m < 56; m++) {
-        P t = apow[j][55 - m] * pi[56 * i + g1exp_pi_index(m)];
-        if (g1exp_slot_is_out(m)) o = o + t; else a = a + t;
+      for (int m = 0; m < S; m++) {
+        P t = apow[j][S - 1 - m] * pi[S * i + sh.pi_index(m)];
+        if (sh.slot_is_out(m)) o = o + t; else a = a + t;
       }
-      P w = apow[j][56 * (sh.num_io - 1 - i)];
+      P w = apow[j][S * (sh.num_io - 1 - i)];
       out.W[j][i] = w; out.WA[j][i] = w * a; out.WO[j][i] = w * o;
     }
 }
 
-template <class P, class Row>
-GL_HD void g1exp_eval(Cons<P>& cs, const Row& row, const G1ExpShape& sh, const G1ExpPiConsts<P>* pic) {
-  using namespace g1c;
+template <int E, class P, class Row>
+GL_HD void exp_eval(Cons<P>& cs, const Row& row, const ExpShape& sh, const ExpPiConsts<P>* pic) {
   const P one = lift<P>(1), base = lift<P>(65536);
-  const int sf = sh.start_flags;
+  const int sf = sh.start_flags, S = sh.pi_per_io;
   P is_final = row.l(sf), is_double = row.l(sf + 2), is_add = row.l(sf + 4);
   P is_not_final = one - is_final;
-  // [1] is_final - sum(output pulses)                                         exp.rs:359-365
-  // [2] public-input binding, regrouped                                       exp.rs:368-392
+  // [1] is_final - sum(output pulses)                                         g1/exp.rs:359-365
+  // [2] public-input binding, regrouped                                       g1/exp.rs:368-392, g2/exp.rs:382-414
   {
     P vin[SBN_NCH], vout[SBN_NCH];
 #pragma unroll
     for (int j = 0; j < SBN_NCH; j++) { vin[j] = lift<P>(0); vout[j] = lift<P>(0); }
-    for (int m = 0; m < 56; m++) {
+    for (int m = 0; m < S; m++) {
       P v;
-      if (m < 48) {
-        int grp = m >> 3, k = m & 7;  // 0:a_x 1:a_y 2:b_x 3:b_y (input pulse) 4:b_x 5:b_y (output pulse)
-        int col = grp == 0 ? AX : grp == 1 ? AY : (grp == 2 || grp == 4) ? BX : BY;
-        v = row.l(col + 2 * k) + base * row.l(col + 2 * k + 1);  // u16_columns_to_u32_columns, utils.rs:56
+      int col = sh.slot_col(m);
+      if (col >= 0) {
+        v = row.l(col) + base * row.l(col + 1);  // u16_columns_to_u32_columns, utils.rs:56
       } else {
-        int k = m - 48;
+        int k = m - 3 * sh.L;
         v = row.l(sf + 6 + k);
-        if (k == 0) v = v + v + is_add;  // limbs[0]*2 + bit  (exp.rs:389)
+        if (k == 0) v = v + v + is_add;  // limbs[0]*2 + bit  (g1/exp.rs:389)
       }
+      bool is_out = sh.slot_is_out(m);
 #pragma unroll
       for (int j = 0; j < SBN_NCH; j++) {
-        P t = cs.apow[j][55 - m] * v;
-        if (g1exp_slot_is_out(m)) vout[j] = vout[j] + t; else vin[j] = vin[j] + t;
+        P t = cs.apow[j][S - 1 - m] * v;
+        if (is_out) vout[j] = vout[j] + t; else vin[j] = vin[j] + t;
       }
     }
     P sum_out = lift<P>(0);
@@ -341,32 +441,33 @@ GL_HD void g1exp_eval(Cons<P>& cs, const Row& row, const G1ExpShape& sh, const G
       cs.acc[j] = cs.acc[j] * cs.apow[j][sh.num_pi] + b;
     }
   }
-  // [3] state transitions (fq_equal_transition x12)                             exp.rs:395-461
+  // [3] state transitions (fq_equal_transition / fq2_equal_transition x12)      g1/exp.rs:395-461, g2/exp.rs:416-473
   {
-    Horner2<P> d_na_a, d_nb_b, d_na_new, d_nb_new;  // 32-term sums: (next_a - a), (next_b - b), (next_a - new), (next_b - new)
+    constexpr int W = 32 * E;  // columns of one point
+    Horner2<P> d_na_a, d_nb_b, d_na_new, d_nb_new;  // (next_a - a), (next_b - b), (next_a - new), (next_b - new)
 #pragma unroll
     for (int j = 0; j < SBN_NCH; j++) d_na_a.h[j] = d_nb_b.h[j] = d_na_new.h[j] = d_nb_new.h[j] = lift<P>(0);
-    for (int k = 0; k < 32; k++) {
-      P na = row.n(AX + k), nb = row.n(BX + k), nw = row.l(NX + k);  // AX..AY and NX..NY are contiguous
-      d_na_a.push(cs, na - row.l(AX + k));
-      d_nb_b.push(cs, nb - row.l(BX + k));
+    for (int k = 0; k < W; k++) {
+      P na = row.n(k), nb = row.n(W + k), nw = row.l(sh.nx_col + k);  // a, b and (new_x, new_y) are contiguous blocks
+      d_na_a.push(cs, na - row.l(k));
+      d_nb_b.push(cs, nb - row.l(W + k));
       d_na_new.push(cs, na - nw);
       d_nb_new.push(cs, nb - nw);
     }
     P hd[SBN_NCH], ha[SBN_NCH], hn[SBN_NCH];
 #pragma unroll
     for (int j = 0; j < SBN_NCH; j++) {
-      P a32 = cs.apow[j][32];
-      hd[j] = d_na_new.h[j] * a32 + d_nb_b.h[j];
-      ha[j] = d_na_a.h[j] * a32 + d_nb_new.h[j];
-      hn[j] = d_na_a.h[j] * a32 + d_nb_b.h[j];
+      P aw = cs.apow[j][W];
+      hd[j] = d_na_new.h[j] * aw + d_nb_b.h[j];
+      ha[j] = d_na_a.h[j] * aw + d_nb_new.h[j];
+      hn[j] = d_na_a.h[j] * aw + d_nb_b.h[j];
     }
     P zl = cs.z_last * is_not_final;
-    cs.merge(hd, zl * is_double, 64);
-    cs.merge(ha, zl * is_add, 64);
-    cs.merge(hn, zl * (one - is_double - is_add), 64);
+    cs.merge(hd, zl * is_double, 2 * W);
+    cs.merge(ha, zl * is_add, 2 * W);
+    cs.merge(hn, zl * (one - is_double - is_add), 2 * W);
   }
-  // [4] eval_flags, [5] eval_g1_add, [6] eval_g1_double, [7] eval_flags again   exp.rs:462-472
+  // [4] eval_flags, [5] eval_g*_add, [6] eval_g*_double, [7] eval_flags again   g1/exp.rs:462-472, g2/exp.rs:474-484
   Horner2<P> hf;
 #pragma unroll
   for (int j = 0; j < SBN_NCH; j++) hf.h[j] = lift<P>(0);
@@ -374,12 +475,12 @@ GL_HD void g1exp_eval(Cons<P>& cs, const Row& row, const G1ExpShape& sh, const G
   cs.merge(hf.h, one, FLAGS_CONSTRAINTS);
   {
     P h_add[SBN_NCH], h_dbl[SBN_NCH];
-    g1_gadget(cs, row, h_add, h_dbl);
-    cs.merge(h_add, is_add, G1_GADGET_CONSTRAINTS);
-    cs.merge(h_dbl, is_double, G1_GADGET_CONSTRAINTS);
+    if (E == 1) g1_gadget(cs, row, h_add, h_dbl); else g2_gadget(cs, row, h_add, h_dbl);
+    cs.merge(h_add, is_add, 165 * E);
+    cs.merge(h_dbl, is_double, 165 * E);
   }
   cs.merge(hf.h, one, FLAGS_CONSTRAINTS);
-  // [8] eval_periodic_pulse(pulse_col = is_rotate, period 64, first_pulse 62)   exp.rs:473-481, pulse.rs:146-170
+  // [8] eval_periodic_pulse(pulse_col = is_rotate, period 64, first_pulse 62)   pulse.rs:146-170
   {
     const int st = sh.start_periodic;
     P counter = row.l(st), witness = row.l(st + 1), is_reset = row.l(sf + 1), next_counter = row.n(st);
@@ -390,21 +491,21 @@ GL_HD void g1exp_eval(Cons<P>& cs, const Row& row, const G1ExpShape& sh, const G
     cs.c(delta * witness + is_reset - one);
     cs.c(delta * is_reset);
   }
-  // [9] eval_pulse over 2*num_io positions                                      exp.rs:482-488, pulse.rs:45-63
+  // [9] eval_pulse over 2*num_io positions                                      pulse.rs:45-63
   {
     const int st = sh.start_io_pulses;
     P counter = row.l(st);
     cs.cf(counter);
     cs.ct(row.n(st) - counter - one);
     for (int i = 0; i < 2 * sh.num_io; i++) {
-      u64 pos = (u64)(i >> 1) * 512 + ((i & 1) ? 511 : 0);  // get_pulse_positions, exp.rs:153-163
+      u64 pos = (u64)(i >> 1) * 512 + ((i & 1) ? 511 : 0);  // get_pulse_positions, g1/exp.rs:153-163
       P cmp = counter - lift<P>(pos);
       P pulse = row.l(sh.pulse_col(i));
       cs.c(cmp * row.l(sh.witness_col(i)) + pulse - one);
       cs.c(cmp * pulse);
     }
   }
-  // [10] eval_u16_range_check                                                   exp.rs:489-494, range_check.rs:49-68
+  // [10] eval_u16_range_check                                                   range_check.rs:49-68
   for (int k = 0; k < sh.num_rc; k++) lookup_pair(cs, row, sh.start_lookups + 1 + 2 * k, sh.start_lookups + 2 + 2 * k);
   range_table_block(cs, row, sh.start_lookups, 65535);
 }

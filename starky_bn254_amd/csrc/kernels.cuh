@@ -360,7 +360,7 @@ struct QuotientParams {
   const u64* apow[SBN_NCH];
   u64 gamma0, gamma1;
   int num_zs, num_io;
-  const void* pic;  // G1ExpPiConsts<F>*
+  const void* pic;  // ExpPiConsts<F>*
   u64* qout;        // [SBN_NCH][m]
 };
 
@@ -381,8 +381,9 @@ __global__ __launch_bounds__(256) void quotient_kernel(QuotientParams p) {
     g1op_eval(cs, row);
     permutation_checks(cs, row, zrow, G1OpShape(), p.num_zs, F(p.gamma0), F(p.gamma1));
   } else {
-    G1ExpShape sh(p.num_io);
-    g1exp_eval(cs, row, sh, (const G1ExpPiConsts<F>*)p.pic);
+    constexpr int E = KIND == 3 ? 2 : 1;
+    ExpShape sh(E, p.num_io);
+    exp_eval<E>(cs, row, sh, (const ExpPiConsts<F>*)p.pic);
     permutation_checks(cs, row, zrow, sh, p.num_zs, F(p.gamma0), F(p.gamma1));
   }
   F dinv(p.zh_inv[i & 1]);

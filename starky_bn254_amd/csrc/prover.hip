@@ -53,7 +53,7 @@ struct sbn_prover {
   u64 *d_tw_f = nullptr, *d_tw_i = nullptr, *d_shift = nullptr, *d_shift_inv = nullptr;
   u64 *d_xs = nullptr, *d_lag_first = nullptr, *d_lag_last = nullptr;
   u64 *d_apow = nullptr;  // [2][APOW_MAX]
-  void* d_pic = nullptr;  // G1ExpPiConsts<F>
+  void* d_pic = nullptr;  // ExpPiConsts<F>
   PairCols* d_pairs = nullptr;
   // openings / FRI
   u64 *d_zpow = nullptr;        // 4 planes [n]: z^i (a,b), (g z)^i (a,b)
@@ -237,9 +237,9 @@ extern "C" int sbn_prover_create(const sbn_air_desc* air, const sbn_config* cfg,
   AirShape as;
   if (!air_shape(air, cfg, as)) return fail(SBN_ERR_BAD_ARG, "unknown air kind / num_io");
   if (degree_bits < 9 || degree_bits > 22) return fail(SBN_ERR_UNSUPPORTED, "degree_bits out of range");
-  if (as.kind == SBN_AIR_G1_EXP) {
-    if (((size_t)512 * as.num_io) != ((size_t)1 << degree_bits)) return fail(SBN_ERR_BAD_ARG, "G1_EXP needs 512*num_io rows");
-    if (degree_bits < 16) return fail(SBN_ERR_UNSUPPORTED, "G1_EXP needs >= 2^16 rows (u16 range check, range_check.rs:26)");
+  if (is_exp_air(as.kind)) {
+    if (((size_t)512 * as.num_io) != ((size_t)1 << degree_bits)) return fail(SBN_ERR_BAD_ARG, "G1_EXP / G2_EXP need 512*num_io rows");
+    if (degree_bits < 16) return fail(SBN_ERR_UNSUPPORTED, "G1_EXP / G2_EXP need >= 2^16 rows (u16 range check, range_check.rs:26)");
   }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(SBN_ERR_NO_DEVICE, "no HIP device available: the prover path has no CPU fallback");
@@ -276,7 +276,7 @@ extern "C" int sbn_prover_create(const sbn_air_desc* air, const sbn_config* cfg,
   rc |= dmalloc(&P->d_pow, 1);
   if (rc) { sbn_prover_destroy(P); return rc; }
   P->d_fb = P->d_fa + 2 * n;
-  HIPC(hipMalloc((void**)&P->d_pic, sizeof(G1ExpPiConsts<F>)));
+  HIPC(hipMalloc((void**)&P->d_pic, sizeof(ExpPiConsts<F>)));
   HIPC(hipMalloc((void**)&P->d_idx, cfg->num_query_rounds * sizeof(u32)));
   // FRI layer buffers
   {
@@ -311,7 +311,7 @@ extern "C" int sbn_prover_create(const sbn_air_desc* air, const sbn_config* cfg,
     std::vector<PairCols> pairs(Z);
     for (size_t z = 0; z < Z; z++) {
       int l, r;
-      if (as.kind == SBN_AIR_G1_OP) G1OpShape::pair((int)z, l, r); else G1ExpShape((int)as.num_io).pair((int)z, l, r);
+      if (as.kind == SBN_AIR_G1_OP) G1OpShape::pair((int)z, l, r); else exp_shape(as).pair((int)z, l, r);
       pairs[z].lhs = l; pairs[z].rhs = r;
     }
     HIPC(hipMalloc((void**)&P->d_pairs, Z * sizeof(PairCols)));
@@ -429,12 +429,12 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
       for (int k = 0; k < APOW_MAX; k++) { ap[j][k] = a; apow[(size_t)j * APOW_MAX + k] = a.v; a = a * alphas[j]; }
     }
     HIPC(hipMemcpyAsync(P->d_apow, apow.data(), apow.size() * sizeof(u64), hipMemcpyHostToDevice, st));
-    if (P->air.kind == SBN_AIR_G1_EXP) {
-      static thread_local G1ExpPiConsts<F> pic;
+    if (is_exp_air(P->air.kind)) {
+      static thread_local ExpPiConsts<F> pic;
       const F* app[SBN_NCH] = {ap[0].data(), ap[1].data()};
       std::vector<F> pif(P->pi.size());
       for (size_t i = 0; i < pif.size(); i++) pif[i] = F(P->pi[i]);
-      g1exp_pi_consts<F>(G1ExpShape((int)P->air.num_io), app, pif.data(), pic);
+      exp_pi_consts<F>(exp_shape(P->air), app, pif.data(), pic);
       HIPC(hipMemcpyAsync(P->d_pic, &pic, sizeof(pic), hipMemcpyHostToDevice, st));
     }
     HIPC(hipStreamSynchronize(st));
@@ -449,7 +449,8 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
     for (int j = 0; j < SBN_NCH; j++) { qp.alpha[j] = alphas[j].v; qp.apow[j] = P->d_apow + (size_t)j * APOW_MAX; }
     qp.gamma0 = gamma0.v; qp.gamma1 = gamma1.v; qp.num_zs = (int)Z; qp.num_io = (int)P->air.num_io; qp.pic = P->d_pic; qp.qout = P->d_q;
     if (P->air.kind == SBN_AIR_G1_OP) hipLaunchKernelGGL(quotient_kernel<1>, blocks(m), dim3(256), 0, st, qp);
-    else hipLaunchKernelGGL(quotient_kernel<2>, blocks(m), dim3(256), 0, st, qp);
+    else if (P->air.kind == SBN_AIR_G1_EXP) hipLaunchKernelGGL(quotient_kernel<2>, blocks(m), dim3(256), 0, st, qp);
+    else hipLaunchKernelGGL(quotient_kernel<3>, blocks(m), dim3(256), 0, st, qp);
     HIPC(hipGetLastError());
   }
   HIPC(hipEventRecord(P->ev[ST_QUOTIENT_COMMIT], st));

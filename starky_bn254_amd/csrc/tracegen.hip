@@ -1,4 +1,5 @@
-// Host witness generation for the G1 tables: replaces G1ExpStark::generate_trace /
+// Host witness generation for the G1 / G2 tables: replaces G1ExpStark::generate_trace (and G2ExpStark's,
+// src/curves/g2/exp.rs:271-342) /
 // generate_public_inputs (src/curves/g1/exp.rs:255-327) and G1Stark::generate_trace
 // (src/curves/g1/muladd.rs:481-546), which the reference runs serially with arkworks + num-bigint.
 //
@@ -214,6 +215,79 @@ bool g1_output_row(bool is_double, const u64* ax, const u64* ay, const u64* bx, 
   return cur == 320;
 }
 
+// Fq2 limb product (src/fields/fq2.rs:41-58): c0 = x0*y0 - x1*y1, c1 = x0*y1 + x1*y0.
+inline void conv16_fq2(const int64_t x[2][16], const int64_t y[2][16], int64_t out[2][31]) {
+  int64_t t[31];
+  conv16(x[0], y[0], out[0]); conv16(x[1], y[1], t); for (int k = 0; k < 31; k++) out[0][k] -= t[k];
+  conv16(x[0], y[1], out[1]); conv16(x[1], y[0], t); for (int k = 0; k < 31; k++) out[1][k] += t[k];
+}
+// Writes the 640 G2Output columns (src/curves/g2/muladd.rs:56-80) for one add / double.
+// Each value is an Fq2 given as two standard-form Fq (c0 = v, c1 = v + 4).
+bool g2_output_row(bool is_double, const u64* ax, const u64* ay, const u64* bx, const u64* by, const u64* lam, const u64* nx, const u64* ny, u64* lv) {
+  int64_t l[2][16], axl[2][16], ayl[2][16], bxl[2][16], byl[2][16], nxl[2][16], nyl[2][16], t16[2][16];
+  int64_t zero_pol[2][31], inx[2][31], iny[2][31], c[2][31];
+  for (int q = 0; q < 2; q++) {
+    limbs16(lam + 4 * q, l[q]); limbs16(ax + 4 * q, axl[q]); limbs16(ay + 4 * q, ayl[q]); limbs16(nx + 4 * q, nxl[q]); limbs16(ny + 4 * q, nyl[q]);
+    if (is_double) { memcpy(bxl[q], axl[q], sizeof axl[q]); memcpy(byl[q], ayl[q], sizeof ayl[q]); } else { limbs16(bx + 4 * q, bxl[q]); limbs16(by + 4 * q, byl[q]); }
+  }
+  if (is_double) {
+    conv16_fq2(l, ayl, zero_pol); conv16_fq2(axl, axl, c);
+    for (int q = 0; q < 2; q++) for (int k = 0; k < 31; k++) zero_pol[q][k] = 2 * zero_pol[q][k] - 3 * c[q][k];
+  } else {
+    for (int q = 0; q < 2; q++) for (int i = 0; i < 16; i++) t16[q][i] = bxl[q][i] - axl[q][i];
+    conv16_fq2(l, t16, zero_pol);
+    for (int q = 0; q < 2; q++) for (int i = 0; i < 16; i++) zero_pol[q][i] -= byl[q][i] - ayl[q][i];
+  }
+  conv16_fq2(l, l, inx);
+  for (int q = 0; q < 2; q++) for (int i = 0; i < 16; i++) inx[q][i] -= axl[q][i] + bxl[q][i];
+  for (int q = 0; q < 2; q++) for (int i = 0; i < 16; i++) t16[q][i] = axl[q][i] - nxl[q][i];
+  conv16_fq2(l, t16, iny);
+  for (int q = 0; q < 2; q++) for (int i = 0; i < 16; i++) iny[q][i] -= ayl[q][i];
+  ModW wz[2], wx[2], wy[2];
+  for (int q = 0; q < 2; q++)
+    if (!mod_witness(zero_pol[q], nullptr, false, wz[q]) || !mod_witness(inx[q], nx + 4 * q, true, wx[q]) || !mod_witness(iny[q], ny + 4 * q, true, wy[q])) return false;
+  int cur = 0;
+  auto put16 = [&](const int64_t* v) { for (int i = 0; i < 16; i++) lv[cur++] = (u64)v[i]; };
+  for (int q = 0; q < 2; q++) put16(l[q]);
+  for (int q = 0; q < 2; q++) put16(nxl[q]);
+  for (int q = 0; q < 2; q++) put16(nyl[q]);
+  auto put_aux = [&](const ModW& w, bool oar) {
+    if (oar) put16(w.out_aux_red);
+    for (int i = 0; i < 17; i++) lv[cur++] = (u64)w.quot_abs[i];
+    for (int i = 0; i < 31; i++) lv[cur++] = (u64)w.aux_lo[i];
+    for (int i = 0; i < 31; i++) lv[cur++] = (u64)w.aux_hi[i];
+  };
+  for (int q = 0; q < 2; q++) put_aux(wz[q], false);
+  for (int q = 0; q < 2; q++) put_aux(wx[q], true);
+  for (int q = 0; q < 2; q++) put_aux(wy[q], true);
+  for (int q = 0; q < 2; q++) lv[cur++] = wz[q].sign > 0 ? 1 : GLP - 1;
+  for (int q = 0; q < 2; q++) lv[cur++] = wx[q].sign > 0 ? 1 : GLP - 1;
+  for (int q = 0; q < 2; q++) lv[cur++] = wy[q].sign > 0 ? 1 : GLP - 1;
+  return cur == 640;
+}
+
+// Coordinate arithmetic for the lockstep curve loop: E = 1 -> Fq, E = 2 -> Fq2 = Fq[i]/(i^2+1).
+template <int E> struct Co { Fq c[E]; };
+template <int E> inline Co<E> cadd(const Co<E>& a, const Co<E>& b) { Co<E> r; for (int q = 0; q < E; q++) r.c[q] = fadd(a.c[q], b.c[q]); return r; }
+template <int E> inline Co<E> csub(const Co<E>& a, const Co<E>& b) { Co<E> r; for (int q = 0; q < E; q++) r.c[q] = fsub(a.c[q], b.c[q]); return r; }
+inline Co<1> cmul(const Co<1>& a, const Co<1>& b) { Co<1> r; r.c[0] = mmul(a.c[0], b.c[0]); return r; }
+inline Co<2> cmul(const Co<2>& a, const Co<2>& b) {
+  Co<2> r;
+  r.c[0] = fsub(mmul(a.c[0], b.c[0]), mmul(a.c[1], b.c[1]));
+  r.c[1] = fadd(mmul(a.c[0], b.c[1]), mmul(a.c[1], b.c[0]));
+  return r;
+}
+template <int E> inline bool czero(const Co<E>& a) { for (int q = 0; q < E; q++) if (!fzero(a.c[q])) return false; return true; }
+// batch inversion: E = 1 directly; E = 2 through the norms a^2 + b^2 (one Fq inversion for the whole batch)
+inline void cbatch_inv(std::vector<Co<1>>& v) { std::vector<Fq> t(v.size()); for (size_t i = 0; i < v.size(); i++) t[i] = v[i].c[0]; batch_inv(t); for (size_t i = 0; i < v.size(); i++) v[i].c[0] = t[i]; }
+inline void cbatch_inv(std::vector<Co<2>>& v) {
+  std::vector<Fq> nrm(v.size());
+  for (size_t i = 0; i < v.size(); i++) nrm[i] = fadd(mmul(v[i].c[0], v[i].c[0]), mmul(v[i].c[1], v[i].c[1]));
+  batch_inv(nrm);
+  Fq z = {{0, 0, 0, 0}};
+  for (size_t i = 0; i < v.size(); i++) { Fq a = mmul(v[i].c[0], nrm[i]), b = fsub(z, mmul(v[i].c[1], nrm[i])); v[i].c[0] = a; v[i].c[1] = b; }
+}
+
 void parallel_for(size_t n, const std::function<void(size_t)>& f) {
   unsigned nt = std::thread::hardware_concurrency(); if (nt == 0) nt = 4; if (nt > 32) nt = 32;
   if (nt > n) nt = (unsigned)n;
@@ -259,17 +333,19 @@ std::vector<u64> small_inverses(size_t n) {
 
 }  // namespace
 
-extern "C" int sbn_generate_trace_g1_exp(const uint32_t* ios, size_t num_io, uint64_t* trace, uint64_t* pi_out) {
+template <int E>
+static int generate_exp_trace(const uint32_t* ios, size_t num_io, uint64_t* trace, uint64_t* pi_out) {
   if (!ios || !trace || !pi_out || num_io == 0 || num_io > (size_t)G1EXP_MAX_IO) return fail(SBN_ERR_BAD_ARG, "bad arguments");
-  const G1ExpShape sh((int)num_io);
+  const ExpShape sh(E, (int)num_io);
   const size_t RPB = 512, n = RPB * num_io;
-  if (n < 65536) return fail(SBN_ERR_UNSUPPORTED, "G1_EXP needs >= 2^16 rows (u16 range check, range_check.rs:26)");
-  const int sf = sh.start_flags;
+  const size_t IOW = 8 * (4 * E + 1);  // u32 words per instance: x and offset (2E Fq each) + exp_val
+  if (n < 65536) return fail(SBN_ERR_UNSUPPORTED, "the table needs >= 2^16 rows (u16 range check, range_check.rs:26)");
+  const int sf = sh.start_flags, GC = sh.gadget_col, GW = 320 * E;
   auto col = [&](int c) { return trace + (size_t)c * n; };
   memset(trace, 0, (size_t)sh.num_cols * n * sizeof(u64));
   // --- flags columns (flags.rs:46-134), per instance, closed form per row
   for (size_t k = 0; k < num_io; k++) {
-    const uint32_t* e = ios + 40 * k + 32;
+    const uint32_t* e = ios + IOW * k + 32 * E;
     u64 limbs[8]; for (int i = 0; i < 8; i++) limbs[i] = e[i];
     u64 bit = limbs[0] & 1; limbs[0] >>= 1;  // first row
     for (size_t r = 0; r < RPB; r++) {
@@ -278,73 +354,79 @@ extern "C" int sbn_generate_trace_g1_exp(const uint32_t* ios, size_t num_io, uin
       col(sf)[row] = r == RPB - 1; col(sf + 1)[row] = (r % 64) == 62;
       col(sf + 2)[row] = a; col(sf + 3)[row] = b; col(sf + 4)[row] = bit * b; col(sf + 5)[row] = bit;
       for (int i = 0; i < 8; i++) col(sf + 6 + i)[row] = limbs[i];
-      // transition to row r+1
       bool split = a == 1, rotate = (r % 64) == 62;
       if (split) { bit = limbs[0] & 1; limbs[0] >>= 1; }
       if (rotate) { for (int i = 0; i < 7; i++) limbs[i] = limbs[i + 1]; limbs[7] = 0; }
     }
   }
-  // --- curve state in lockstep over the instances (exp.rs:165-230)
-  std::vector<Fq> ax(num_io), ay(num_io), bx(num_io), by(num_io), lam(num_io), nx(num_io), ny(num_io);
+  // --- curve state in lockstep over the instances (g1/exp.rs:165-230, g2/exp.rs:180-246)
+  typedef Co<E> C;
+  std::vector<C> ax(num_io), ay(num_io), bx(num_io), by(num_io), lam(num_io), nx(num_io), ny(num_io);
   std::vector<char> active(num_io), was_double(num_io, 0), had_op(num_io, 0);
   for (size_t k = 0; k < num_io; k++) {
-    u64 t[4];
-    from_u32(ios + 40 * k, t); if (geq_p(t)) return fail(SBN_ERR_BAD_ARG, "x.x >= p"); ax[k] = to_m(t);
-    from_u32(ios + 40 * k + 8, t); if (geq_p(t)) return fail(SBN_ERR_BAD_ARG, "x.y >= p"); ay[k] = to_m(t);
-    from_u32(ios + 40 * k + 16, t); if (geq_p(t)) return fail(SBN_ERR_BAD_ARG, "offset.x >= p"); bx[k] = to_m(t);
-    from_u32(ios + 40 * k + 24, t); if (geq_p(t)) return fail(SBN_ERR_BAD_ARG, "offset.y >= p"); by[k] = to_m(t);
+    C* dst[4] = {&ax[k], &ay[k], &bx[k], &by[k]};
+    for (int v = 0; v < 4; v++) for (int q = 0; q < E; q++) {
+      u64 t[4]; from_u32(ios + IOW * k + 8 * (v * E + q), t);
+      if (geq_p(t)) return fail(SBN_ERR_BAD_ARG, "coordinate >= p (instance %zu)", k);
+      dst[v]->c[q] = to_m(t);
+    }
   }
   std::atomic<int> bad(0);
-  std::vector<Fq> den;
-  std::vector<u64> std_vals(num_io * 28);  // per instance: ax ay bx by lam nx ny (standard form)
+  std::vector<C> den;
+  const size_t SV = 28 * E;  // per instance: ax ay bx by lam nx ny, standard form, E Fq each
+  std::vector<u64> std_vals(num_io * SV);
   for (size_t r = 0; r < RPB; r++) {
     const bool dbl = r & 1;
-    // apply the previous row's result to the state
     if (r > 0) for (size_t k = 0; k < num_io; k++) if (had_op[k]) { if (was_double[k]) { ax[k] = nx[k]; ay[k] = ny[k]; } else { bx[k] = nx[k]; by[k] = ny[k]; } }
     den.clear();
     for (size_t k = 0; k < num_io; k++) {
       active[k] = dbl ? 1 : (char)col(sf + 4)[k * RPB + r];
-      if (active[k]) { Fq d = dbl ? fadd(ay[k], ay[k]) : fsub(bx[k], ax[k]); if (fzero(d)) return fail(SBN_ERR_WITNESS, "degenerate affine operation (instance %zu, row %zu)", k, r); den.push_back(d); }
+      if (active[k]) { C d = dbl ? cadd(ay[k], ay[k]) : csub(bx[k], ax[k]); if (czero(d)) return fail(SBN_ERR_WITNESS, "degenerate affine operation (instance %zu, row %zu)", k, r); den.push_back(d); }
     }
-    batch_inv(den);
+    cbatch_inv(den);
     size_t di = 0;
     for (size_t k = 0; k < num_io; k++) {
       had_op[k] = active[k]; was_double[k] = dbl;
       if (!active[k]) continue;
-      Fq num;
-      if (dbl) { Fq x2 = mmul(ax[k], ax[k]); num = fadd(fadd(x2, x2), x2); } else num = fsub(by[k], ay[k]);
-      lam[k] = mmul(num, den[di++]);
-      Fq l2 = mmul(lam[k], lam[k]);
-      nx[k] = dbl ? fsub(fsub(l2, ax[k]), ax[k]) : fsub(fsub(l2, ax[k]), bx[k]);
-      ny[k] = fsub(mmul(lam[k], fsub(ax[k], nx[k])), ay[k]);
+      C num;
+      if (dbl) { C x2 = cmul(ax[k], ax[k]); num = cadd(cadd(x2, x2), x2); } else num = csub(by[k], ay[k]);
+      lam[k] = cmul(num, den[di++]);
+      C l2 = cmul(lam[k], lam[k]);
+      nx[k] = dbl ? csub(csub(l2, ax[k]), ax[k]) : csub(csub(l2, ax[k]), bx[k]);
+      ny[k] = csub(cmul(lam[k], csub(ax[k], nx[k])), ay[k]);
     }
     for (size_t k = 0; k < num_io; k++) {
-      u64* s = &std_vals[k * 28];
-      from_m(ax[k], s); from_m(ay[k], s + 4); from_m(bx[k], s + 8); from_m(by[k], s + 12);
-      if (active[k]) { from_m(lam[k], s + 16); from_m(nx[k], s + 20); from_m(ny[k], s + 24); }
+      u64* s = &std_vals[k * SV];
+      const C* src[7] = {&ax[k], &ay[k], &bx[k], &by[k], &lam[k], &nx[k], &ny[k]};
+      for (int v = 0; v < (active[k] ? 7 : 4); v++) for (int q = 0; q < E; q++) from_m(src[v]->c[q], s + 4 * (v * E + q));
     }
     parallel_for(num_io, [&](size_t k) {
       size_t row = k * RPB + r;
-      const u64* s = &std_vals[k * 28];
-      put_limbs(col(0) + row, n, s); put_limbs(col(16) + row, n, s + 4); put_limbs(col(32) + row, n, s + 8); put_limbs(col(48) + row, n, s + 12);
-      u64 lv[320];
+      const u64* s = &std_vals[k * SV];
+      for (int v = 0; v < 4; v++) for (int q = 0; q < E; q++) put_limbs(col(16 * (v * E + q)) + row, n, s + 4 * (v * E + q));
+      u64 lv[640];
       if (active[k]) {
-        if (!g1_output_row(dbl, s, s + 4, s + 8, s + 12, s + 16, s + 20, s + 24, lv)) { bad = 1; return; }
-      } else {  // G1Output::default (muladd.rs:61-75)
-        for (int i = 0; i < 317; i++) lv[i] = 0;
-        lv[317] = lv[318] = lv[319] = 1;
+        bool ok = E == 1 ? g1_output_row(dbl, s, s + 4, s + 8, s + 12, s + 16, s + 20, s + 24, lv)
+                         : g2_output_row(dbl, s, s + 8, s + 16, s + 24, s + 32, s + 40, s + 48, lv);
+        if (!ok) { bad = 1; return; }
+      } else {  // G1Output::default / G2Output::default: zeros, quot signs = 1
+        for (int i = 0; i < GW - 3 * E; i++) lv[i] = 0;
+        for (int i = GW - 3 * E; i < GW; i++) lv[i] = 1;
       }
-      for (int c = 0; c < 320; c++) col(64 + c)[row] = lv[c];
+      for (int c = 0; c < GW; c++) col(GC + c)[row] = lv[c];
     });
     if (bad) return fail(SBN_ERR_WITNESS, "modular witness generation failed at row step %zu", r);
   }
-  // --- public inputs (exp.rs:124-135, 320-327): x.x x.y off.x off.y exp_val out.x out.y as u32 limbs
+  // --- public inputs: x, offset, exp_val, output as u32 limbs (g1/exp.rs:124-135, g2/exp.rs:139-156)
   for (size_t k = 0; k < num_io; k++) {
-    u64* p = pi_out + 56 * k;
-    for (int i = 0; i < 32; i++) p[i] = ios[40 * k + i];
-    for (int i = 0; i < 8; i++) p[32 + i] = ios[40 * k + 32 + i];
-    u64 ox[4], oy[4]; from_m(bx[k], ox); from_m(by[k], oy);  // b at the last row
-    for (int i = 0; i < 8; i++) { p[40 + i] = (ox[i / 2] >> (32 * (i % 2))) & 0xffffffffULL; p[48 + i] = (oy[i / 2] >> (32 * (i % 2))) & 0xffffffffULL; }
+    u64* p = pi_out + (size_t)sh.pi_per_io * k;
+    const int L = sh.L;
+    for (int i = 0; i < 2 * L + 8; i++) p[i] = ios[IOW * k + i];
+    const C* o[2] = {&bx[k], &by[k]};  // b at the last row
+    for (int v = 0; v < 2; v++) for (int q = 0; q < E; q++) {
+      u64 t[4]; from_m(o[v]->c[q], t);
+      for (int i = 0; i < 8; i++) p[2 * L + 8 + 8 * (v * E + q) + i] = (t[i / 2] >> (32 * (i % 2))) & 0xffffffffULL;
+    }
   }
   // --- periodic pulse (pulse.rs:100-144): counter starts at 1, period 64; witness = 1/(counter-63)
   std::vector<u64> inv = small_inverses(n);
@@ -375,6 +457,13 @@ extern "C" int sbn_generate_trace_g1_exp(const uint32_t* ios, size_t num_io, uin
     if (bad) return fail(SBN_ERR_WITNESS, "range-checked column holds a value >= 2^16");
   }
   return SBN_OK;
+}
+
+extern "C" int sbn_generate_trace_g1_exp(const uint32_t* ios, size_t num_io, uint64_t* trace, uint64_t* pi_out) {
+  return generate_exp_trace<1>(ios, num_io, trace, pi_out);
+}
+extern "C" int sbn_generate_trace_g2_exp(const uint32_t* ios, size_t num_io, uint64_t* trace, uint64_t* pi_out) {
+  return generate_exp_trace<2>(ios, num_io, trace, pi_out);
 }
 
 extern "C" int sbn_generate_trace_g1_op(const uint32_t* pts, size_t rows, uint64_t* trace) {

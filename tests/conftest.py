@@ -54,3 +54,11 @@ def g1exp_case(O):
     ios, native = O.g1exp_inputs(128, 1)
     trace, pi = O.g1exp_trace(ios)
     return {"ios": ios, "native": native, "trace": trace, "pi": pi}
+
+
+@pytest.fixture(scope="session")
+def g2exp_case(O):
+    """Seeded G2ExpStark(128) trace (2^16 rows x 2822 columns); ~1.5 GB."""
+    ios, native = O.g2exp_inputs(128, 2)
+    trace, pi = O.g2exp_trace(ios)
+    return {"ios": ios, "native": native, "trace": trace, "pi": pi}

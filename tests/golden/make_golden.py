@@ -12,7 +12,7 @@ What pins what (the reference itself has NO golden vectors -- SURVEY.md section 
   flags_native.json      the reference's test_flag_native property inputs (flags.rs:334-369) for one exponent.
   proof_digests.json     sha256 of the ORACLE's canonical proof words for seeded G1Stark-512 / G1ExpStark-2^16
                          traces: pins GPU == oracle without re-running the 100 s CPU prover.
-Run from the repo root:  python3 tests/golden/make_golden.py [--with-g1exp]
+Run from the repo root:  python3 tests/golden/make_golden.py [--with-g1exp] [--with-g2exp]
 """
 import hashlib, json, os, sys
 import numpy as np
@@ -124,6 +124,14 @@ def main():
         cases.append({"seed": seed, "ios": ios.tolist(), "outputs": outs})
     dump("g1_scalar_mult.json", {"source": "python-int affine BN254 arithmetic: x*s + offset", "cases": cases})
 
+    ios, native = O.g2exp_inputs(3, 2)
+    outs = []
+    for (x, off, sc) in native:
+        r = O.g2_add(O.g2_mul(x, sc), off)
+        outs.append([hex(r[0][0]), hex(r[0][1]), hex(r[1][0]), hex(r[1][1])])
+    dump("g2_scalar_mult.json", {"source": "python-int affine arithmetic on the BN254 twist over Fq2: x*s + offset",
+                                 "seed": 2, "ios": ios.tolist(), "outputs": outs})
+
     # lookup.rs:154-161 fixed input; expected columns from a python restatement of lookup.rs:60-111
     inputs = [6, 3, 1, 1, 0, 0, 0, 0]
     table = list(range(8))
@@ -173,6 +181,15 @@ def main():
         w, secs = O.prove(O.AIR_G1_EXP, 128, tr, pi)
         assert O.verify(O.AIR_G1_EXP, 128, w)[0] == 0
         digests["g1exp_io128_seed1"] = {
+            "trace_sha256": hashlib.sha256(tr.tobytes()).hexdigest(), "pi_sha256": hashlib.sha256(pi.tobytes()).hexdigest(),
+            "proof_words": int(len(w)), "proof_sha256": hashlib.sha256(w.astype("<u8").tobytes()).hexdigest(),
+            "trace_cap0": [int(x) for x in w[12:16]], "pow_witness": int(w[-1 - len(pi)]), "oracle_prove_seconds_8core": secs}
+    if "--with-g2exp" in sys.argv:          # ~3 minutes on 8 cores
+        ios, _ = O.g2exp_inputs(128, 2)
+        tr, pi = O.g2exp_trace(ios)
+        w, secs = O.prove(O.AIR_G2_EXP, 128, tr, pi)
+        assert O.verify(O.AIR_G2_EXP, 128, w)[0] == 0
+        digests["g2exp_io128_seed2"] = {
             "trace_sha256": hashlib.sha256(tr.tobytes()).hexdigest(), "pi_sha256": hashlib.sha256(pi.tobytes()).hexdigest(),
             "proof_words": int(len(w)), "proof_sha256": hashlib.sha256(w.astype("<u8").tobytes()).hexdigest(),
             "trace_cap0": [int(x) for x in w[12:16]], "pow_witness": int(w[-1 - len(pi)]), "oracle_prove_seconds_8core": secs}

@@ -269,3 +269,122 @@ def challenger_probe(inputs, m):
 
 def gf_pow(b, e):
     return pow(b, e, GL_P)
+
+
+# ---------------------------------------------------------------- G2 (BN254 twist over Fq2 = Fq[i]/(i^2+1)) in Python ints
+AIR_G2_EXP = 3
+
+
+def fq2_mul(a, b):
+    return ((a[0] * b[0] - a[1] * b[1]) % BN_P, (a[0] * b[1] + a[1] * b[0]) % BN_P)
+
+
+def fq2_add(a, b):
+    return ((a[0] + b[0]) % BN_P, (a[1] + b[1]) % BN_P)
+
+
+def fq2_sub(a, b):
+    return ((a[0] - b[0]) % BN_P, (a[1] - b[1]) % BN_P)
+
+
+def fq2_inv(a):
+    n = pow(a[0] * a[0] + a[1] * a[1], -1, BN_P)
+    return (a[0] * n % BN_P, (-a[1]) * n % BN_P)
+
+
+def fq2_pow(a, e):
+    r = (1, 0)
+    while e:
+        if e & 1:
+            r = fq2_mul(r, a)
+        a = fq2_mul(a, a)
+        e >>= 1
+    return r
+
+
+def fq2_sqrt(a):
+    """Square root in Fq2 for p = 3 mod 4 (Adj-Rodriguez-Henriquez); None if `a` is not a square."""
+    if a == (0, 0):
+        return (0, 0)
+    a1 = fq2_pow(a, (BN_P - 3) // 4)
+    alpha = fq2_mul(fq2_mul(a1, a1), a)
+    a0 = fq2_mul(fq2_pow(alpha, BN_P), alpha)
+    if a0 == (BN_P - 1, 0):
+        return None
+    x0 = fq2_mul(a1, a)
+    if alpha == (BN_P - 1, 0):
+        return fq2_mul((0, 1), x0)
+    b = fq2_pow(fq2_add((1, 0), alpha), (BN_P - 1) // 2)
+    return fq2_mul(b, x0)
+
+
+G2_B = fq2_mul((3, 0), fq2_inv((9, 1)))     # twist y^2 = x^3 + 3/(9+i)
+
+
+def g2_add(p, q):
+    if p is None:
+        return q
+    if q is None:
+        return p
+    (x1, y1), (x2, y2) = p, q
+    if x1 == x2:
+        if fq2_add(y1, y2) == (0, 0):
+            return None
+        lam = fq2_mul(fq2_mul((3, 0), fq2_mul(x1, x1)), fq2_inv(fq2_add(y1, y1)))
+    else:
+        lam = fq2_mul(fq2_sub(y2, y1), fq2_inv(fq2_sub(x2, x1)))
+    x3 = fq2_sub(fq2_sub(fq2_mul(lam, lam), x1), x2)
+    y3 = fq2_sub(fq2_mul(lam, fq2_sub(x1, x3)), y1)
+    return (x3, y3)
+
+
+def g2_mul(p, k):
+    r = None
+    while k:
+        if k & 1:
+            r = g2_add(r, p)
+        p = g2_add(p, p)
+        k >>= 1
+    return r
+
+
+def g2_random(rng):
+    """Random affine point on the twist curve (not cofactor-cleared: the table only checks the group law)."""
+    while True:
+        x = (int.from_bytes(rng.bytes(32), "little") % BN_P, int.from_bytes(rng.bytes(32), "little") % BN_P)
+        rhs = fq2_add(fq2_mul(fq2_mul(x, x), x), G2_B)
+        y = fq2_sqrt(rhs)
+        if y is not None and fq2_mul(y, y) == rhs:
+            if int(rng.integers(0, 2)):
+                y = ((-y[0]) % BN_P, (-y[1]) % BN_P)
+            return (x, y)
+
+
+def g2exp_inputs(num_io, seed):
+    """Mirror of src/curves/g2/exp.rs:845-860 with seeded randomness."""
+    rng = np.random.default_rng(seed)
+    ios = np.zeros((num_io, 72), dtype=np.uint32)
+    native = []
+    for k in range(num_io):
+        x = g2_random(rng)
+        off = g2_random(rng)
+        exp = [int(v) for v in rng.integers(0, 1 << 32, size=8, dtype=np.uint64)]
+        vals = [x[0][0], x[0][1], x[1][0], x[1][1], off[0][0], off[0][1], off[1][0], off[1][1]]
+        for j, v in enumerate(vals):
+            ios[k, 8 * j:8 * j + 8] = u32_limbs(v)
+        ios[k, 64:72] = exp
+        native.append((x, off, sum(e << (32 * i) for i, e in enumerate(exp))))
+    return ios, native
+
+
+def g2exp_trace(ios):
+    num_io = ios.shape[0]
+    L = lib()
+    ncols = L.orc_air_num_columns(AIR_G2_EXP, num_io)
+    npi = L.orc_air_num_public_inputs(AIR_G2_EXP, num_io)
+    trace = np.zeros((ncols, 512 * num_io), dtype=np.uint64)
+    pi = np.zeros(npi, dtype=np.uint64)
+    ios = np.ascontiguousarray(ios, dtype=np.uint32)
+    L.orc_g2exp_generate_trace.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    L.orc_g2exp_generate_trace(ptr(ios), num_io, ptr(trace), ptr(pi))
+    return trace, pi

@@ -153,3 +153,26 @@ def test_invalid_witness_yields_rejected_proof(gpu, O, g1op_case):
     assert O.verify(O.AIR_G1_OP, 0, proof.words)[0] != 0           # ...and both verifiers reject them
     with pytest.raises(gpu.SbnError):
         gpu.verify_stark_proof(stark, proof, stark.config())
+
+
+def test_g2exp_proof_matches_oracle_digest_and_verifies(gpu, O, g2exp_case, golden):
+    """BASELINE config[3]: G2ExpStark(128), 2^16 rows x 2822 columns: GPU proof bytes == the CPU oracle's
+    (committed sha256; the oracle run takes minutes), accepted by the oracle's and the product's verifier,
+    tampering rejected."""
+    stark = gpu.G2ExpStark(128)
+    cfg = stark.config()
+    prover = gpu.Prover(stark, cfg, 16)
+    prover.load_trace(g2exp_case["trace"], g2exp_case["pi"])
+    proof = prover.prove()
+    prover.close()
+    g = golden["proof_digests"]["g2exp_io128_seed2"]
+    assert len(proof.words) == g["proof_words"]
+    assert [int(x) for x in proof.words[12:16]] == g["trace_cap0"]
+    assert hashlib.sha256(proof.to_bytes()).hexdigest() == g["proof_sha256"]
+    assert O.verify(O.AIR_G2_EXP, 128, proof.words) == (0, "")
+    gpu.verify_stark_proof(stark, proof, cfg)
+    t = proof.words.copy()
+    t[12 + 3 * 64 + 9] = (int(t[12 + 3 * 64 + 9]) + 1) % P
+    assert O.verify(O.AIR_G2_EXP, 128, t)[0] != 0
+    with pytest.raises(gpu.SbnError):
+        gpu.verify_stark_proof(stark, gpu.Proof(t, 16), cfg)

@@ -111,3 +111,26 @@ def test_product_never_loads_the_oracle():
             if f.endswith((".py", ".hip", ".cuh", ".hpp", ".cpp", "Makefile")):
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "liboracle" not in txt and "oracle/" not in txt and "oracle_lib" not in txt, os.path.join(dp, f)
+
+
+def test_g2_shape_tracegen_and_scalar_mult(S, O, g2exp_case, golden):
+    """G2ExpStark (BASELINE config[3]): shape = SURVEY section 8, host witness == oracle witness == golden digest,
+    outputs == python-int x*s+offset on the twist, constraints vanish on sampled rows."""
+    st = S.G2ExpStark(128)
+    assert (st.num_columns, st.num_public_inputs, st.num_permutation_zs(), st.num_constraints) == (2822, 13312, 1524, 16455)
+    tr, pi = st.generate_trace_and_public_inputs(g2exp_case["ios"])
+    assert np.array_equal(pi, g2exp_case["pi"]) and np.array_equal(tr, g2exp_case["trace"])
+    g = golden["proof_digests"]["g2exp_io128_seed2"]
+    assert hashlib.sha256(tr.tobytes()).hexdigest() == g["trace_sha256"]
+    gs = golden["g2_scalar_mult"]
+    assert np.array_equal(np.array(gs["ios"], dtype=np.uint32), g2exp_case["ios"][:3])
+    for k, out in enumerate(gs["outputs"]):
+        got = [sum(int(pi[104 * k + 72 + 8 * q + i]) << (32 * i) for i in range(8)) for q in range(4)]
+        assert got == [int(v, 16) for v in out]
+    n = tr.shape[1]
+    w = pow(1753635133440165772, 1 << (32 - 16), P)
+    for i in (0, 1, 62, 63, 511, 512, 33333, n - 1):
+        x = pow(w, i, P)
+        acc = O.eval_constraints(O.AIR_G2_EXP, 128, tr[:, i], tr[:, (i + 1) % n], pi, [0x1234567, 0x7654321],
+                                 (x - pow(w, n - 1, P)) % P, int(i == 0), int(i == n - 1))
+        assert acc == [0, 0], i
