@@ -33,6 +33,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--seed", type=int, default=1000)
     ap.add_argument("--skip-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL, default) or gloo (rehearsal)")
+    ap.add_argument("--same-device", action="store_true", help="rehearsal only: every rank uses GPU 0 (needs --backend gloo)")
     ap.add_argument("--table", choices=["g1", "g2"], default="g1",
                     help="g1 = G1ExpStark(128), the BASELINE metric (default); g2 = G2ExpStark(128), BASELINE config[3]")
     ap.add_argument("--traffic-bytes", type=float, default=None,
@@ -51,13 +53,18 @@ def main():
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the prover path has no CPU fallback")
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # "nccl" is RCCL on ROCm
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     rc = S.lib().sbn_set_device(local_rank)
     if rc != 0:
@@ -95,7 +102,7 @@ def main():
     elapsed = time.perf_counter() - t0
     barrier()
     if dist is not None:
-        elapsed = sharding.max_over_ranks(elapsed, dist, device=dev)
+        elapsed = sharding.max_over_ranks(elapsed, dist, device=dev if args.backend == "nccl" else None)
 
     # every rank checks its own proof outside the timed region
     S.verify_stark_proof(stark, proof, cfg)
