@@ -53,8 +53,11 @@ typedef enum sbn_status {
 
 /* Table kinds.  G1_OP = reference `G1Stark` (src/curves/g1/muladd.rs:462-624);
  * G1_EXP = reference `G1ExpStark` (src/curves/g1/exp.rs:232-742). */
-typedef enum sbn_air_kind { SBN_AIR_G1_OP = 1, SBN_AIR_G1_EXP = 2, SBN_AIR_G2_EXP = 3 } sbn_air_kind;
-/* G2_EXP = reference `G2ExpStark` (src/curves/g2/exp.rs:248-807): the same machine over Fq2 coordinates. */
+typedef enum sbn_air_kind { SBN_AIR_G1_OP = 1, SBN_AIR_G1_EXP = 2, SBN_AIR_G2_EXP = 3, SBN_AIR_FQ12_EXP = 4 } sbn_air_kind;
+/* G2_EXP = reference `G2ExpStark` (src/curves/g2/exp.rs:248-807): the same machine over Fq2 coordinates.
+ * FQ12_EXP = reference `Fq12ExpStark` (src/fields/fq12/exp.rs:223-605): offset * x^e in Fq12 (flat basis of
+ * plonky2-bn254 `MyFq12`: coefficient of w^k is c[k] + c[k+6]*i, w^6 = 9 + i), 512 rows per instance, num_io a
+ * power of two between 1 and 512. */
 
 typedef struct sbn_air_desc {
   int32_t kind;    /* sbn_air_kind */
@@ -99,6 +102,10 @@ int sbn_generate_trace_g1_exp(const uint32_t* ios, size_t num_io, uint64_t* trac
  * ios: num_io x 72 u32 = x.x.c0 x.x.c1 x.y.c0 x.y.c1 offset.x.c0 offset.x.c1 offset.y.c0 offset.y.c1 exp_val
  * (8 u32 limbs each); trace_out: [num_columns][512*num_io]; pi_out: [104*num_io]. */
 int sbn_generate_trace_g2_exp(const uint32_t* ios, size_t num_io, uint64_t* trace_out, uint64_t* pi_out);
+/* Fq12ExpStark::generate_trace / generate_public_inputs (src/fields/fq12/exp.rs:283-319).
+ * ios: num_io x 200 u32 = x[12] offset[12] (flat-basis coefficients, 8 u32 limbs each) exp_val[8];
+ * trace_out: [num_columns][512*num_io]; pi_out: [584*num_io]. */
+int sbn_generate_trace_fq12_exp(const uint32_t* ios, size_t num_io, uint64_t* trace_out, uint64_t* pi_out);
 /* pts: rows x 32 u32 = a.x[8] a.y[8] b.x[8] b.y[8]; trace_out: [num_columns][rows]. */
 int sbn_generate_trace_g1_op(const uint32_t* pts, size_t rows, uint64_t* trace_out);
 

@@ -919,4 +919,185 @@ struct G2ExpAir : AirBase<G2ExpAir> {
   }
 };
 
+// ---- src/fields/fq12/mul.rs --------------------------------------------------------------------------------------
+// Fq12 in the reference's FLAT basis: sum_k (r_k + s_k i) w^k, k < 6, w^6 = xi = 9 + i; coefficients
+// [0..6) = r_k, [6..12) = s_k (the order `MyFq12.coeffs` has, plonky2-bn254; utils.rs:174-183).
+template <class T> using Fq12Limbs = Arr<Arr<T, 16>, 12>;
+template <class T> using Fq12Wide = Arr<Arr<T, 31>, 12>;
+// pol_mul_fq12 :24-87
+template <class T> static inline Fq12Wide<T> pol_mul_fq12(const Fq12Limbs<T>& a, const Fq12Limbs<T>& b, T xi) {
+  Arr<Arr<T, 31>, 11> d, s;  // a0b0 - a1b1, a0b1 + a1b0 by power of w
+  for (auto& x : d) for (auto& y : x) y = T();
+  for (auto& x : s) for (auto& y : x) y = T();
+  for (int i = 0; i < 6; i++)
+    for (int j = 0; j < 6; j++) {
+      Arr<T, 31> c00 = pol_mul_wide(a[i], b[j]), c01 = pol_mul_wide(a[i], b[j + 6]), c10 = pol_mul_wide(a[i + 6], b[j]), c11 = pol_mul_wide(a[i + 6], b[j + 6]);
+      for (int k = 0; k < 31; k++) { d[i + j][k] = d[i + j][k] + c00[k] - c11[k]; s[i + j][k] = s[i + j][k] + c01[k] + c10[k]; }
+    }
+  Fq12Wide<T> out;
+  for (int i = 0; i < 6; i++)
+    for (int k = 0; k < 31; k++) {
+      if (i < 5) { out[i][k] = d[i][k] + xi * d[i + 6][k] - s[i + 6][k]; out[i + 6][k] = s[i][k] + d[i + 6][k] + xi * s[i + 6][k]; }
+      else { out[i][k] = d[i][k]; out[i + 6][k] = s[i][k]; }
+    }
+  return out;
+}
+template <class T> struct Fq12Output {  // :173-177 ; 84*N_LIMBS columns (:217-231)
+  Fq12Limbs<T> output; ModulusAux<T> auxs[12]; T quot_signs[12];
+};
+static const int FQ12_OUTPUT_COLS = 84 * N_LIMBS;
+template <class T> static inline Fq12Limbs<T> read_fq12(const T* lv, int& cur) { Fq12Limbs<T> r; for (int i = 0; i < 12; i++) r[i] = read16(lv, cur); return r; }
+template <class T> static inline Fq12Output<T> read_fq12_output(const T* lv, int& cur) {  // :233-252
+  Fq12Output<T> o;
+  o.output = read_fq12(lv, cur);
+  for (int i = 0; i < 12; i++) { o.auxs[i].out_aux_red = read16(lv, cur); o.auxs[i].quot_abs = readn<T, 17>(lv, cur); o.auxs[i].aux_input_lo = readn<T, 31>(lv, cur); o.auxs[i].aux_input_hi = readn<T, 31>(lv, cur); }
+  for (int i = 0; i < 12; i++) o.quot_signs[i] = lv[cur++];
+  return o;
+}
+// eval_fq12_mul :254-275
+template <class P>
+static inline void eval_fq12_mul(Consumer<P>& yc, P filter, const Fq12Limbs<P>& x, const Fq12Limbs<P>& y, const Fq12Output<P>& o) {
+  Fq12Wide<P> input = pol_mul_fq12(x, y, cst<P>(9));
+  Arr<P, 16> modulus = bn254_modulus_p<P>();
+  for (int i = 0; i < 12; i++) eval_modular_op(yc, filter, modulus, input[i], o.output[i], o.quot_signs[i], o.auxs[i]);
+}
+// generate_fq12_mul :192-215 : writes lv[0..1344), returns the product limbs
+static inline void generate_fq12_mul(const Fq12Limbs<int64_t>& x, const Fq12Limbs<int64_t>& y, GF* lv, Fq12Limbs<int64_t>& out) {
+  Fq12Wide<int64_t> pol_input = pol_mul_fq12<int64_t>(x, y, 9);
+  ModWitness w[12];
+  for (int i = 0; i < 12; i++) { w[i] = generate_modular_witness(pol_input[i], false); out[i] = w[i].output; }
+  int cur = 0;
+  for (int i = 0; i < 12; i++) for (int k = 0; k < 16; k++) lv[cur++] = GF((u64)w[i].output[k]);
+  for (int i = 0; i < 12; i++) write_mod_aux(lv, cur, w[i], true);
+  for (int i = 0; i < 12; i++) lv[cur++] = GF::from_i64(w[i].quot_sign);
+  assert(cur == FQ12_OUTPUT_COLS);
+}
+static inline void write_fq12_output_default(GF* lv) {  // Fq12Output::default :179-187
+  for (int i = 0; i < FQ12_OUTPUT_COLS - 12; i++) lv[i] = GF();
+  for (int i = FQ12_OUTPUT_COLS - 12; i < FQ12_OUTPUT_COLS; i++) lv[i] = GF::one();
+}
+
+// Fq12ExpStark: src/fields/fq12/exp.rs  (offset * x^e by square-and-multiply; split range check).
+struct Fq12ExpIONative { U256 x[12], offset[12]; uint32_t exp_val[NUM_INPUT_LIMBS]; U256 output[12]; };  // :86-91
+struct Fq12ExpAir : AirBase<Fq12ExpAir> {
+  size_t num_io;
+  int start_flags_col, num_main_cols, start_periodic_pulse_col, start_io_pulses_col, start_lookups_col, start_range_check_col, num_range_check_cols;  // :6-34
+  size_t ncols, npi;
+  std::vector<size_t> pulse_positions;
+  static const int IO_LEN = 36 * N_LIMBS + NUM_INPUT_LIMBS;  // :93
+  explicit Fq12ExpAir(size_t n) : num_io(n) {
+    start_flags_col = 108 * N_LIMBS;
+    num_main_cols = start_flags_col + NUM_FLAGS_COLS;
+    start_periodic_pulse_col = num_main_cols;
+    start_io_pulses_col = start_periodic_pulse_col + 2;
+    start_lookups_col = start_io_pulses_col + 1 + 4 * (int)num_io;
+    start_range_check_col = 24 * N_LIMBS;
+    num_range_check_cols = 84 * N_LIMBS - 12;
+    ncols = start_lookups_col + 1 + 6 * num_range_check_cols;
+    npi = IO_LEN * num_io;
+    size_t rpb = 2 * INPUT_LIMB_BITS * NUM_INPUT_LIMBS;
+    for (size_t i = 0; i < num_io; i++) { pulse_positions.push_back(i * rpb); pulse_positions.push_back(i * rpb + rpb - 1); }
+  }
+  size_t num_columns() const override { return ncols; }
+  size_t num_public_inputs() const override { return npi; }
+  std::vector<std::pair<size_t, size_t>> permutation_pairs() const override {  // :598-604, range_check.rs:230-246
+    std::vector<std::pair<size_t, size_t>> p;
+    size_t mc = start_lookups_col;
+    for (size_t i = mc + 1; i < mc + 1 + 6 * (size_t)num_range_check_cols; i += 6) {
+      p.push_back({mc, i + 2}); p.push_back({mc, i + 5}); p.push_back({i, i + 1}); p.push_back({i + 3, i + 4});
+    }
+    return p;
+  }
+  template <class P> void eval_t(const P* lv, const P* nv, const P* pi, Consumer<P>& yc) const {  // :323-428
+    int is_final_col = start_flags_col, is_sq_col = start_flags_col + 2, is_mul_col = start_flags_col + 4, start_limbs_col = start_flags_col + 6;
+    P one = cst<P>(1);
+    int cur = 0;
+    Fq12Limbs<P> a = read_fq12(lv, cur), b = read_fq12(lv, cur);
+    Fq12Output<P> output = read_fq12_output(lv, cur);
+    P is_mul = lv[is_mul_col], is_sq = lv[is_sq_col], is_final = lv[is_final_col];
+    P is_not_final = one - is_final;
+    P sum_is_output = P();
+    for (size_t i = 1; i < 2 * num_io; i += 2) sum_is_output = sum_is_output + lv[get_pulse_col(start_io_pulses_col, (int)i)];
+    yc.constraint(is_final - sum_is_output);
+    {  // public inputs :358-373 ; layout x[12][16] offset[12][16] exp_val[8] output[12][16] (read_fq12_exp_io :119-131)
+      Arr<P, 8> limbs; for (int k = 0; k < 8; k++) limbs[k] = lv[start_limbs_col + k];
+      limbs[0] = limbs[0] * cst<P>(2) + is_mul;
+      size_t pc = 0;
+      for (size_t i = 0; i < 2 * num_io; i += 2) {
+        const P* io = pi + pc; pc += IO_LEN;
+        P is_in = lv[get_pulse_col(start_io_pulses_col, (int)i)], is_out = lv[get_pulse_col(start_io_pulses_col, (int)i + 1)];
+        for (int c = 0; c < 12; c++) {
+          for (int k = 0; k < 16; k++) yc.constraint(is_in * (io[16 * c + k] - a[c][k]));
+          for (int k = 0; k < 16; k++) yc.constraint(is_in * (io[192 + 16 * c + k] - b[c][k]));
+          for (int k = 0; k < 16; k++) yc.constraint(is_out * (io[392 + 16 * c + k] - b[c][k]));
+        }
+        for (int k = 0; k < 8; k++) yc.constraint(is_in * (io[384 + k] - limbs[k]));
+      }
+    }
+    cur = 0;
+    Fq12Limbs<P> next_a = read_fq12(nv, cur), next_b = read_fq12(nv, cur);
+    auto eqt = [&](P filter, const Fq12Limbs<P>& x, const Fq12Limbs<P>& y) { for (int c = 0; c < 12; c++) for (int k = 0; k < 16; k++) yc.constraint_transition(filter * (x[c][k] - y[c][k])); };
+    P fs = is_not_final * is_sq;
+    eqt(fs, next_a, output.output); eqt(fs, next_b, b);
+    P fm = is_not_final * is_mul;
+    eqt(fm, next_a, a); eqt(fm, next_b, output.output);
+    P fn = is_not_final * (one - is_sq - is_mul);
+    eqt(fn, next_a, a); eqt(fn, next_b, b);
+    eval_flags(yc, lv, nv, start_flags_col);           // :395
+    eval_fq12_mul(yc, is_sq, a, a, output);            // :396
+    eval_fq12_mul(yc, is_mul, a, b, output);           // :397
+    eval_flags(yc, lv, nv, start_flags_col);           // :400 (duplicate, kept)
+    eval_periodic_pulse(yc, lv, nv, start_flags_col + 1, start_periodic_pulse_col, 2 * INPUT_LIMB_BITS, 2 * INPUT_LIMB_BITS - 2);
+    eval_pulse(yc, lv, nv, start_io_pulses_col, pulse_positions);
+    eval_split_u16_range_check(yc, lv, nv, start_lookups_col, (size_t)start_range_check_col, (size_t)(start_range_check_col + num_range_check_cols));
+  }
+  void generate_block(const Fq12ExpIONative& in, std::vector<std::vector<GF>>& cols, size_t row0, U256* out) const {  // :229-268
+    size_t num_rows = 2 * INPUT_LIMB_BITS * NUM_INPUT_LIMBS;
+    std::vector<GF> lv(num_main_cols, GF()), nvv(num_main_cols, GF());
+    int sf = start_flags_col;
+    Fq12Limbs<int64_t> a, b, prod;
+    for (int c = 0; c < 12; c++) { a[c] = u256_to_limbs16(in.x[c]); b[c] = u256_to_limbs16(in.offset[c]); }
+    auto put = [&](GF* r, int off, const Fq12Limbs<int64_t>& v) { for (int c = 0; c < 12; c++) for (int k = 0; k < 16; k++) r[off + 16 * c + k] = GF((u64)v[c][k]); };
+    generate_flags_first_row(lv.data(), sf, in.exp_val);
+    put(lv.data(), 0, a); put(lv.data(), 192, b);
+    if (lv[sf + 4] == GF::one()) generate_fq12_mul(a, b, lv.data() + 384, prod); else write_fq12_output_default(lv.data() + 384);
+    for (int c = 0; c < num_main_cols; c++) cols[c][row0] = lv[c];
+    for (size_t i = 0; i + 1 < num_rows; i++) {
+      std::fill(nvv.begin(), nvv.end(), GF());
+      generate_flags_next_row(lv.data(), nvv.data(), i, sf);
+      if (lv[sf + 2] == GF::one()) a = prod; else if (lv[sf + 4] == GF::one()) b = prod;
+      put(nvv.data(), 0, a); put(nvv.data(), 192, b);
+      if (nvv[sf + 2] == GF::one()) generate_fq12_mul(a, a, nvv.data() + 384, prod);
+      else if (nvv[sf + 4] == GF::one()) generate_fq12_mul(a, b, nvv.data() + 384, prod);
+      else write_fq12_output_default(nvv.data() + 384);
+      for (int c = 0; c < num_main_cols; c++) cols[c][row0 + i + 1] = nvv[c];
+      lv.swap(nvv);
+    }
+    for (int c = 0; c < 12; c++) out[c] = limbs16_to_u256(b[c].data());
+  }
+  std::vector<std::vector<GF>> generate_trace(std::vector<Fq12ExpIONative>& inputs) const {  // :283-312
+    assert(inputs.size() == num_io);
+    size_t rpb = 2 * INPUT_LIMB_BITS * NUM_INPUT_LIMBS, rows = rpb * num_io;
+    std::vector<std::vector<GF>> cols(num_main_cols, std::vector<GF>(rows));
+#pragma omp parallel for schedule(dynamic, 1)
+    for (size_t k = 0; k < num_io; k++) generate_block(inputs[k], cols, k * rpb, inputs[k].output);
+    generate_periodic_pulse_witness(cols, start_flags_col + 1, 2 * INPUT_LIMB_BITS, 2 * INPUT_LIMB_BITS - 2);
+    generate_pulse(cols, pulse_positions);
+    generate_split_u16_range_check((size_t)start_range_check_col, (size_t)(start_range_check_col + num_range_check_cols), cols);
+    assert(cols.size() == ncols);
+    return cols;
+  }
+  std::vector<GF> generate_public_inputs(const std::vector<Fq12ExpIONative>& inputs) const {  // :95-117, :314-319
+    std::vector<GF> pi;
+    auto put = [&](const U256& v) { auto l = u256_to_limbs16(v); for (int k = 0; k < 16; k++) pi.push_back(GF((u64)l[k])); };
+    for (auto& in : inputs) {
+      for (int c = 0; c < 12; c++) put(in.x[c]);
+      for (int c = 0; c < 12; c++) put(in.offset[c]);
+      for (int i = 0; i < 8; i++) pi.push_back(GF(in.exp_val[i]));
+      for (int c = 0; c < 12; c++) put(in.output[c]);
+    }
+    return pi;
+  }
+};
+
 }  // namespace orc

@@ -19,8 +19,9 @@
 #include "gl.cuh"
 
 static constexpr int SBN_NCH = 2;              // StarkConfig.num_challenges (standard_fast_config)
-static constexpr int APOW_MAX = 13 * 8 * 128 + 1;  // alpha^k table length (k <= 104*128, G2ExpStark)
-static constexpr int G1EXP_MAX_IO = 128;
+// alpha^k tables are sized per table at run time: max(num_public_inputs, num_zs, 1024) + 1 entries.
+GL_HD size_t apow_len(size_t npi, size_t nzs) { size_t m = npi > nzs ? npi : nzs; return (m > 1024 ? m : 1024) + 1; }
+static constexpr int G1EXP_MAX_IO = 512;        // largest num_io of any Exp table (Fq12ExpStark(512) = 2^18 rows)
 
 // BN254 base-field modulus in 16-bit limbs (src/modular/modular.rs:298-309).
 GL_HD u64 bn254_modulus_limb(int j) {
@@ -33,7 +34,7 @@ template <class P>
 struct Cons {
   P alpha[SBN_NCH];
   P acc[SBN_NCH];
-  const P* apow[SBN_NCH];  // apow[j][k] = alpha_j^k, k < APOW_MAX
+  const P* apow[SBN_NCH];  // apow[j][k] = alpha_j^k, k < apow_len(...)
   P z_last, l_first, l_last;
   GL_HD void c(P x) {
 #pragma unroll
@@ -339,34 +340,145 @@ GL_HD void g2_gadget(const Cons<P>& cs, const Row& row, P* h_add, P* h_dbl) {
   }
 }
 
+// ---- Fq12 multiplication gadget (src/fields/fq12/mul.rs) ------------------------------------------------------
+// Columns relative to the row: a[12][16] at 0, b[12][16] at 192, Fq12Output at 384 = output[12][16],
+// auxs[12] (out_aux_red 16, quot_abs 17, lo 31, hi 31), quot_signs[12]   (mul.rs:217-231).
+namespace f12c {
+static constexpr int A = 0, B = 192, OUT = 384, AUX = 576, SGN = 576 + 12 * 95;
+}
+// eval_fq12_mul(is_sq, a, a) and eval_fq12_mul(is_mul, a, b) on one row (fq12/exp.rs:396-397): two
+// 792-constraint local sums.  pol_mul_fq12 (mul.rs:24-87): with D[m] = sum_{i+j=m} (a_i b_j - a_{i+6} b_{j+6}),
+// S[m] = sum_{i+j=m} (a_i b_{j+6} + a_{i+6} b_j):  real[m] = D[m] + 9 D[m+6] - S[m+6],
+// imag[m] = S[m] + D[m+6] + 9 S[m+6]  (m < 5; the m = 5 terms have no wrap-around part).
+// Coefficients m and m+6 are processed together so that every limb product is formed exactly once.
+template <class P, class Row>
+GL_HD void fq12_gadget(const Cons<P>& cs, const Row& row, P* h_sq, P* h_mul) {
+  using namespace f12c;
+  const P base = lift<P>(65536), off = lift<P>(1ULL << 29), zero = lift<P>(0), nine = lift<P>(9);
+#pragma unroll
+  for (int j = 0; j < SBN_NCH; j++) { h_sq[j] = zero; h_mul[j] = zero; }
+  for (int m = 0; m < 6; m++) {
+    Horner2<P> hs[2], hm[2];
+    P sgn[2], pa[2] = {zero, zero};
+    for (int q = 0; q < 2; q++) {
+      int c = m + 6 * q;
+#pragma unroll
+      for (int j = 0; j < SBN_NCH; j++) hs[q].h[j] = zero;
+      modop_prefix(cs, row, AUX + 95 * c, OUT + 16 * c, SGN + c, hs[q]);
+      hm[q] = hs[q];
+      sgn[q] = row.l(SGN + c);
+    }
+    for (int k = 0; k < 32; k++) {
+      P ds = zero, ss = zero, ds6 = zero, ss6 = zero, dm = zero, sm = zero, dm6 = zero, sm6 = zero;
+      if (k < 31) {
+        int u0 = k > 15 ? k - 15 : 0, u1 = k < 15 ? k : 15;
+        for (int i = 0; i < 6; i++) {
+          int j = i <= m ? m - i : m + 6 - i;      // i + j = m  or  i + j = m + 6
+          bool wrap = i > m;
+          if (wrap && m == 5) continue;            // j would be 6: no such term
+          for (int u = u0; u <= u1; u++) {
+            int v = k - u;
+            P ai = row.l(A + 16 * i + u), ai6 = row.l(A + 16 * (i + 6) + u);
+            P aj = row.l(A + 16 * j + v), aj6 = row.l(A + 16 * (j + 6) + v);
+            P bj = row.l(B + 16 * j + v), bj6 = row.l(B + 16 * (j + 6) + v);
+            P d_s = ai * aj - ai6 * aj6, s_s = ai * aj6 + ai6 * aj;
+            P d_m = ai * bj - ai6 * bj6, s_m = ai * bj6 + ai6 * bj;
+            if (wrap) { ds6 += d_s; ss6 += s_s; dm6 += d_m; sm6 += s_m; }
+            else { ds += d_s; ss += s_s; dm += d_m; sm += s_m; }
+          }
+        }
+      }
+      P in_s[2] = {ds + nine * ds6 - ss6, ss + ds6 + nine * ss6};
+      P in_m[2] = {dm + nine * dm6 - sm6, sm + dm6 + nine * sm6};
+      for (int q = 0; q < 2; q++) {
+        int c = m + 6 * q, ab = AUX + 95 * c;
+        P qv = zero;
+        int i0 = k > 15 ? k - 15 : 0, i1 = k < 16 ? k : 16;
+        for (int i = i0; i <= i1; i++) qv += row.l(ab + 16 + i) * lift<P>(bn254_modulus_limb(k - i));
+        P ax = zero;
+        if (k < 31) ax = row.l(ab + 33 + k) - off + base * row.l(ab + 64 + k);
+        P adj = pa[q] - base * ax;
+        pa[q] = ax;
+        P xk = sgn[q] * qv + adj;
+        if (k < 16) xk = xk + row.l(OUT + 16 * c + k);
+        hs[q].push(cs, xk - in_s[q]);
+        hm[q].push(cs, xk - in_m[q]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < SBN_NCH; j++) {
+      P w0 = cs.apow[j][66 * (11 - m)], w1 = cs.apow[j][66 * (5 - m)];
+      h_sq[j] = h_sq[j] + hs[0].h[j] * w0 + hs[1].h[j] * w1;
+      h_mul[j] = h_mul[j] + hm[0].h[j] * w0 + hm[1].h[j] * w1;
+    }
+  }
+}
+
 // ---- G1ExpStark / G2ExpStark (src/curves/g1/exp.rs, src/curves/g2/exp.rs) --------------------------------
 // Both tables are the same double-and-add machine; E = 1 (Fq coordinates) or 2 (Fq2 coordinates) scales
 // the point columns (32E per point), the gadget (320E columns, 165E constraints) and the public inputs.
-struct ExpShape {  // constants(num_io): g1/exp.rs:6-34, g2/exp.rs:6-34
-  int E, num_io, L, pi_per_io, b_col, gadget_col, nx_col, start_flags, num_main, start_periodic, start_io_pulses, start_lookups, num_rc, num_cols, num_pi;
+struct ExpShape {  // constants(num_io): g1/exp.rs:6-34, g2/exp.rs:6-34, fq12/exp.rs:6-34
+  // E = 1: G1ExpStark, 2: G2ExpStark (curve tables), 12: Fq12ExpStark (offset * x^e, square-and-multiply)
+  int E, num_io, W, L, pi_per_io, b_col, gadget_col, nx_col, gadget_cons, start_flags, num_main, start_periodic, start_io_pulses, start_lookups;
+  int rc_start, num_rc, split_rc, num_cols, num_pi;
   GL_HD ExpShape(int e, int n) {
-    E = e; num_io = n; L = 16 * e; pi_per_io = 3 * L + 8; b_col = 32 * e; gadget_col = 64 * e; nx_col = gadget_col + 16 * e;
-    start_flags = 384 * e; num_main = start_flags + 14; start_periodic = num_main;
+    E = e; num_io = n;
+    if (e == 12) {
+      W = 192; L = 192; gadget_col = 384; nx_col = 384; gadget_cons = 792; start_flags = 108 * 16;
+      rc_start = 384; num_rc = 84 * 16 - 12; split_rc = 1;
+    } else {
+      W = 32 * e; L = 16 * e; gadget_col = 64 * e; nx_col = gadget_col + 16 * e; gadget_cons = 165 * e; start_flags = 384 * e;
+      rc_start = 0; num_rc = 381 * e; split_rc = 0;
+    }
+    pi_per_io = 3 * L + 8; b_col = W;
+    num_main = start_flags + 14; start_periodic = num_main;
     start_io_pulses = start_periodic + 2; start_lookups = start_io_pulses + 1 + 4 * n;
-    num_rc = 381 * e; num_cols = start_lookups + 1 + 2 * num_rc; num_pi = pi_per_io * n;
+    num_cols = start_lookups + 1 + (split_rc ? 6 : 2) * num_rc; num_pi = pi_per_io * n;
   }
-  GL_HD int num_pairs() const { return 2 * num_rc; }
-  GL_HD int gadget_constraints() const { return 165 * E; }
-  GL_HD int num_constraints() const { return 1 + num_pi + 3 * 64 * E + 26 + 2 * 165 * E + 26 + 5 + 2 + 4 * num_io + 2 * num_rc + 3; }
-  // u16_range_check_pairs (range_check.rs:96-113)
+  GL_HD int num_pairs() const { return (split_rc ? 4 : 2) * num_rc; }
+  GL_HD int num_constraints() const {
+    return 1 + num_pi + 3 * 2 * W + 26 + 2 * gadget_cons + 26 + 5 + 2 + 4 * num_io + (split_rc ? 5 * num_rc + 3 : 2 * num_rc + 3);
+  }
+  // u16_range_check_pairs (range_check.rs:96-113) / split_u16_range_check_pairs (:230-246)
   GL_HD void pair(int z, int& lhs, int& rhs) const {
-    if (z & 1) { lhs = z >> 1; rhs = start_lookups + z; }
+    if (split_rc) {
+      int t = z >> 2, w = z & 3, i = start_lookups + 1 + 6 * t;
+      if (w == 0) { lhs = start_lookups; rhs = i + 2; }
+      else if (w == 1) { lhs = start_lookups; rhs = i + 5; }
+      else if (w == 2) { lhs = i; rhs = i + 1; }
+      else { lhs = i + 3; rhs = i + 4; }
+    } else if (z & 1) { lhs = z >> 1; rhs = start_lookups + z; }
     else { lhs = start_lookups; rhs = start_lookups + 2 + z; }
   }
   GL_HD int witness_col(int i) const { return start_io_pulses + 1 + 2 * i; }  // pulse.rs:14
   GL_HD int pulse_col(int i) const { return start_io_pulses + 2 + 2 * i; }    // pulse.rs:10
-  // Emission slot m (0..pi_per_io) of one instance's vec_equal calls (g1/exp.rs:381-391, g2/exp.rs:391-414):
-  // x (L, input pulse), offset (L, input), output (L, output pulse), exp_val (8, input).
-  // Public inputs are stored x, offset, exp_val, output (g1_exp_io_to_columns / g2_exp_io_to_columns).
-  GL_HD int pi_index(int m) const { return m < 2 * L ? m : (m < 3 * L ? 2 * L + 8 + (m - 2 * L) : 2 * L + (m - 3 * L)); }
-  GL_HD bool slot_is_out(int m) const { return m >= 2 * L && m < 3 * L; }
-  // first of the two u16 columns forming u32 limb `m` of the compared value; -1 for the exponent limbs
-  GL_HD int slot_col(int m) const { return m < L ? 2 * m : (m < 2 * L ? b_col + 2 * (m - L) : (m < 3 * L ? b_col + 2 * (m - 2 * L) : -1)); }
+  // Emission slot m (0..pi_per_io) of one instance's vec_equal calls.
+  //  curves (g1/exp.rs:381-391, g2/exp.rs:391-414): x (L u32 limbs, input pulse), offset (L, input), output (L, output
+  //    pulse), exp_val (8, input); a u32 limb is formed from two u16 columns.
+  //  fq12 (fq12/exp.rs:362-372): per coefficient c: x[c] (16 u16 limbs, input), offset[c] (16, input), output[c] (16,
+  //    output); then exp_val (8, input).
+  // Public inputs are stored x, offset, exp_val, output in every table.
+  GL_HD int pi_index(int m) const {
+    if (E == 12) {
+      if (m >= 576) return 384 + (m - 576);
+      int c = m / 48, w = m % 48;
+      return w < 16 ? 16 * c + w : (w < 32 ? 192 + 16 * c + (w - 16) : 392 + 16 * c + (w - 32));
+    }
+    return m < 2 * L ? m : (m < 3 * L ? 2 * L + 8 + (m - 2 * L) : 2 * L + (m - 3 * L));
+  }
+  GL_HD bool slot_is_out(int m) const {
+    if (E == 12) return m < 576 && (m % 48) >= 32;
+    return m >= 2 * L && m < 3 * L;
+  }
+  // first column of the compared value (a u16 pair for curves, one u16 column for fq12); -1 for the exponent limbs
+  GL_HD int slot_col(int m) const {
+    if (E == 12) {
+      if (m >= 576) return -1;
+      int c = m / 48, w = m % 48;
+      return w < 16 ? 16 * c + w : (w < 32 ? 192 + 16 * c + (w - 16) : 192 + 16 * c + (w - 32));
+    }
+    return m < L ? 2 * m : (m < 2 * L ? b_col + 2 * (m - L) : (m < 3 * L ? b_col + 2 * (m - 2 * L) : -1));
+  }
 };
 
 // Per-proof constants of the regrouped public-input block: for challenge j and instance i,
@@ -406,7 +518,8 @@ GL_HD void exp_eval(Cons<P>& cs, const Row& row, const ExpShape& sh, const ExpPi
       P v;
       int col = sh.slot_col(m);
       if (col >= 0) {
-        v = row.l(col) + base * row.l(col + 1);  // u16_columns_to_u32_columns, utils.rs:56
+        v = row.l(col);
+        if (E != 12) v = v + base * row.l(col + 1);  // u16_columns_to_u32_columns, utils.rs:56 (curve tables)
       } else {
         int k = m - 3 * sh.L;
         v = row.l(sf + 6 + k);
@@ -443,7 +556,7 @@ GL_HD void exp_eval(Cons<P>& cs, const Row& row, const ExpShape& sh, const ExpPi
   }
   // [3] state transitions (fq_equal_transition / fq2_equal_transition x12)      g1/exp.rs:395-461, g2/exp.rs:416-473
   {
-    constexpr int W = 32 * E;  // columns of one point
+    constexpr int W = E == 12 ? 192 : 32 * E;  // columns of one operand (point / Fq12 element)
     Horner2<P> d_na_a, d_nb_b, d_na_new, d_nb_new;  // (next_a - a), (next_b - b), (next_a - new), (next_b - new)
 #pragma unroll
     for (int j = 0; j < SBN_NCH; j++) d_na_a.h[j] = d_nb_b.h[j] = d_na_new.h[j] = d_nb_new.h[j] = lift<P>(0);
@@ -475,9 +588,11 @@ GL_HD void exp_eval(Cons<P>& cs, const Row& row, const ExpShape& sh, const ExpPi
   cs.merge(hf.h, one, FLAGS_CONSTRAINTS);
   {
     P h_add[SBN_NCH], h_dbl[SBN_NCH];
-    if (E == 1) g1_gadget(cs, row, h_add, h_dbl); else g2_gadget(cs, row, h_add, h_dbl);
-    cs.merge(h_add, is_add, 165 * E);
-    cs.merge(h_dbl, is_double, 165 * E);
+    // curve tables: eval_g*_add (filter is_add) then eval_g*_double (is_double); fq12: eval_fq12_mul(is_sq, a, a)
+    // then eval_fq12_mul(is_mul, a, b) -- is_sq shares the column of is_double, is_mul that of is_add.
+    if (E == 1) g1_gadget(cs, row, h_add, h_dbl); else if (E == 2) g2_gadget(cs, row, h_add, h_dbl); else fq12_gadget(cs, row, h_dbl, h_add);
+    if (E == 12) { cs.merge(h_dbl, is_double, sh.gadget_cons); cs.merge(h_add, is_add, sh.gadget_cons); }
+    else { cs.merge(h_add, is_add, sh.gadget_cons); cs.merge(h_dbl, is_double, sh.gadget_cons); }
   }
   cs.merge(hf.h, one, FLAGS_CONSTRAINTS);
   // [8] eval_periodic_pulse(pulse_col = is_rotate, period 64, first_pulse 62)   pulse.rs:146-170
@@ -505,9 +620,17 @@ GL_HD void exp_eval(Cons<P>& cs, const Row& row, const ExpShape& sh, const ExpPi
       cs.c(cmp * pulse);
     }
   }
-  // [10] eval_u16_range_check                                                   range_check.rs:49-68
-  for (int k = 0; k < sh.num_rc; k++) lookup_pair(cs, row, sh.start_lookups + 1 + 2 * k, sh.start_lookups + 2 + 2 * k);
-  range_table_block(cs, row, sh.start_lookups, 65535);
+  // [10] eval_u16_range_check (range_check.rs:49-68) / eval_split_u16_range_check (:162-192)
+  if (E == 12) {
+    const P c256 = lift<P>(256);
+    const int mc = sh.start_lookups;
+    for (int i = 0; i < sh.num_rc; i++) cs.c(row.l(sh.rc_start + i) - (row.l(mc + 1 + 6 * i) + row.l(mc + 4 + 6 * i) * c256));
+    for (int i = mc + 1; i < mc + 1 + 6 * sh.num_rc; i += 6) { lookup_pair(cs, row, i + 1, i + 2); lookup_pair(cs, row, i + 4, i + 5); }
+    range_table_block(cs, row, mc, 255);
+  } else {
+    for (int k = 0; k < sh.num_rc; k++) lookup_pair(cs, row, sh.start_lookups + 1 + 2 * k, sh.start_lookups + 2 + 2 * k);
+    range_table_block(cs, row, sh.start_lookups, 65535);
+  }
 }
 
 // starky permutation.rs `eval_permutation_checks` for singleton pairs with batch size 2:

@@ -60,23 +60,24 @@ struct AirShape {
   int kind; u32 num_io;
   size_t ncols, npi, npairs, nzs, nconstraints;
 };
+static inline int exp_e(int kind) { return kind == SBN_AIR_FQ12_EXP ? 12 : (kind == SBN_AIR_G2_EXP ? 2 : 1); }
 static inline bool air_shape(const sbn_air_desc* air, const sbn_config* cfg, AirShape& s) {
   if (!air) return false;
   s.kind = air->kind; s.num_io = air->num_io;
   u32 nch = cfg ? cfg->num_challenges : 2;
   if (air->kind == SBN_AIR_G1_OP) {
     s.ncols = G1OpShape::NUM_COLS; s.npi = 0; s.npairs = G1OpShape::NUM_PAIRS; s.nconstraints = G1OpShape::NUM_CONSTRAINTS;
-  } else if (air->kind == SBN_AIR_G1_EXP || air->kind == SBN_AIR_G2_EXP) {
-    if (air->num_io == 0 || air->num_io > (u32)G1EXP_MAX_IO) return false;
-    ExpShape sh(air->kind == SBN_AIR_G2_EXP ? 2 : 1, (int)air->num_io);
+  } else if (air->kind == SBN_AIR_G1_EXP || air->kind == SBN_AIR_G2_EXP || air->kind == SBN_AIR_FQ12_EXP) {
+    if (air->num_io == 0 || air->num_io > (u32)G1EXP_MAX_IO || (air->num_io & (air->num_io - 1))) return false;
+    ExpShape sh(exp_e(air->kind), (int)air->num_io);
     s.ncols = sh.num_cols; s.npi = sh.num_pi; s.npairs = sh.num_pairs(); s.nconstraints = sh.num_constraints();
   } else return false;
   // num_permutation_batches = ceil(pairs*num_challenges / (constraint_degree-1)), constraint_degree = 3
   s.nzs = (s.npairs * nch + 1) / 2;
   return true;
 }
-static inline bool is_exp_air(int kind) { return kind == SBN_AIR_G1_EXP || kind == SBN_AIR_G2_EXP; }
-static inline ExpShape exp_shape(const AirShape& a) { return ExpShape(a.kind == SBN_AIR_G2_EXP ? 2 : 1, (int)a.num_io); }
+static inline bool is_exp_air(int kind) { return kind == SBN_AIR_G1_EXP || kind == SBN_AIR_G2_EXP || kind == SBN_AIR_FQ12_EXP; }
+static inline ExpShape exp_shape(const AirShape& a) { return ExpShape(exp_e(a.kind), (int)a.num_io); }
 static inline bool config_supported(const sbn_config* c) {
   return c && c->num_challenges == SBN_NCH && c->rate_bits == 1 && c->cap_height >= 1 && c->cap_height <= 8 &&
          c->fri_arity_bits >= 1 && c->fri_arity_bits <= 4 && c->num_query_rounds >= 1 && c->num_query_rounds <= 512 &&

@@ -52,7 +52,8 @@ struct sbn_prover {
   // tables
   u64 *d_tw_f = nullptr, *d_tw_i = nullptr, *d_shift = nullptr, *d_shift_inv = nullptr;
   u64 *d_xs = nullptr, *d_lag_first = nullptr, *d_lag_last = nullptr;
-  u64 *d_apow = nullptr;  // [2][APOW_MAX]
+  u64 *d_apow = nullptr;  // [2][apow_n]
+  size_t apow_n = 0;
   void* d_pic = nullptr;  // ExpPiConsts<F>
   PairCols* d_pairs = nullptr;
   // openings / FRI
@@ -239,7 +240,8 @@ extern "C" int sbn_prover_create(const sbn_air_desc* air, const sbn_config* cfg,
   if (degree_bits < 9 || degree_bits > 22) return fail(SBN_ERR_UNSUPPORTED, "degree_bits out of range");
   if (is_exp_air(as.kind)) {
     if (((size_t)512 * as.num_io) != ((size_t)1 << degree_bits)) return fail(SBN_ERR_BAD_ARG, "G1_EXP / G2_EXP need 512*num_io rows");
-    if (degree_bits < 16) return fail(SBN_ERR_UNSUPPORTED, "G1_EXP / G2_EXP need >= 2^16 rows (u16 range check, range_check.rs:26)");
+    if (as.kind != SBN_AIR_FQ12_EXP && degree_bits < 16)
+      return fail(SBN_ERR_UNSUPPORTED, "G1_EXP / G2_EXP need >= 2^16 rows (u16 range check, range_check.rs:26)");
   }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(SBN_ERR_NO_DEVICE, "no HIP device available: the prover path has no CPU fallback");
@@ -269,7 +271,8 @@ extern "C" int sbn_prover_create(const sbn_air_desc* air, const sbn_config* cfg,
   rc |= tree_alloc(P->tree_t, m, cfg->cap_height); rc |= tree_alloc(P->tree_z, m, cfg->cap_height); rc |= tree_alloc(P->tree_q, m, cfg->cap_height);
   rc |= dmalloc(&P->d_tw_f, m / 2); rc |= dmalloc(&P->d_tw_i, m / 2); rc |= dmalloc(&P->d_shift, m); rc |= dmalloc(&P->d_shift_inv, m);
   rc |= dmalloc(&P->d_xs, m); rc |= dmalloc(&P->d_lag_first, m); rc |= dmalloc(&P->d_lag_last, m);
-  rc |= dmalloc(&P->d_apow, (size_t)SBN_NCH * APOW_MAX);
+  P->apow_n = apow_len(as.npi, as.nzs);
+  rc |= dmalloc(&P->d_apow, (size_t)SBN_NCH * P->apow_n);
   rc |= dmalloc(&P->d_zpow, 4 * n); rc |= dmalloc(&P->d_open, (C + Z + 4) * 4);
   rc |= dmalloc(&P->d_part, 2 * 32 * n); rc |= dmalloc(&P->d_w, 4096); rc |= dmalloc(&P->d_sponge, 12 * m);
   rc |= dmalloc(&P->d_fa, 4 * n); rc |= dmalloc(&P->d_fcoef, 2 * m); rc |= dmalloc(&P->d_fcoef2, 2 * m);
@@ -421,16 +424,17 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
   F alphas[SBN_NCH];
   for (int j = 0; j < SBN_NCH; j++) alphas[j] = ch.challenge();
   {
-    std::vector<u64> apow((size_t)SBN_NCH * APOW_MAX);
+    const size_t APN = P->apow_n;
+    std::vector<u64> apow((size_t)SBN_NCH * APN);
     std::vector<F> ap[SBN_NCH];
     for (int j = 0; j < SBN_NCH; j++) {
-      ap[j].resize(APOW_MAX);
+      ap[j].resize(APN);
       F a(1);
-      for (int k = 0; k < APOW_MAX; k++) { ap[j][k] = a; apow[(size_t)j * APOW_MAX + k] = a.v; a = a * alphas[j]; }
+      for (size_t k = 0; k < APN; k++) { ap[j][k] = a; apow[(size_t)j * APN + k] = a.v; a = a * alphas[j]; }
     }
     HIPC(hipMemcpyAsync(P->d_apow, apow.data(), apow.size() * sizeof(u64), hipMemcpyHostToDevice, st));
     if (is_exp_air(P->air.kind)) {
-      static thread_local ExpPiConsts<F> pic;
+      static thread_local ExpPiConsts<F> pic;  // 3 x 2 x 512 field elements
       const F* app[SBN_NCH] = {ap[0].data(), ap[1].data()};
       std::vector<F> pif(P->pi.size());
       for (size_t i = 0; i < pif.size(); i++) pif[i] = F(P->pi[i]);
@@ -446,11 +450,12 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
     F gn = f_exp_pow2(F(GL_GEN), P->degree_bits);
     qp.zh_inv[0] = f_inv(gn - F(1)).v; qp.zh_inv[1] = f_inv(-gn - F(1)).v;  // Z_H(7 w^i) = 7^N (-1)^i - 1
     qp.last = f_inv(f_root_of_unity(P->degree_bits)).v;
-    for (int j = 0; j < SBN_NCH; j++) { qp.alpha[j] = alphas[j].v; qp.apow[j] = P->d_apow + (size_t)j * APOW_MAX; }
+    for (int j = 0; j < SBN_NCH; j++) { qp.alpha[j] = alphas[j].v; qp.apow[j] = P->d_apow + (size_t)j * P->apow_n; }
     qp.gamma0 = gamma0.v; qp.gamma1 = gamma1.v; qp.num_zs = (int)Z; qp.num_io = (int)P->air.num_io; qp.pic = P->d_pic; qp.qout = P->d_q;
     if (P->air.kind == SBN_AIR_G1_OP) hipLaunchKernelGGL(quotient_kernel<1>, blocks(m), dim3(256), 0, st, qp);
     else if (P->air.kind == SBN_AIR_G1_EXP) hipLaunchKernelGGL(quotient_kernel<2>, blocks(m), dim3(256), 0, st, qp);
-    else hipLaunchKernelGGL(quotient_kernel<3>, blocks(m), dim3(256), 0, st, qp);
+    else if (P->air.kind == SBN_AIR_G2_EXP) hipLaunchKernelGGL(quotient_kernel<3>, blocks(m), dim3(256), 0, st, qp);
+    else hipLaunchKernelGGL(quotient_kernel<4>, blocks(m), dim3(256), 0, st, qp);
     HIPC(hipGetLastError());
   }
   HIPC(hipEventRecord(P->ev[ST_QUOTIENT_COMMIT], st));

@@ -333,19 +333,12 @@ std::vector<u64> small_inverses(size_t n) {
 
 }  // namespace
 
-template <int E>
-static int generate_exp_trace(const uint32_t* ios, size_t num_io, uint64_t* trace, uint64_t* pi_out) {
-  if (!ios || !trace || !pi_out || num_io == 0 || num_io > (size_t)G1EXP_MAX_IO) return fail(SBN_ERR_BAD_ARG, "bad arguments");
-  const ExpShape sh(E, (int)num_io);
-  const size_t RPB = 512, n = RPB * num_io;
-  const size_t IOW = 8 * (4 * E + 1);  // u32 words per instance: x and offset (2E Fq each) + exp_val
-  if (n < 65536) return fail(SBN_ERR_UNSUPPORTED, "the table needs >= 2^16 rows (u16 range check, range_check.rs:26)");
-  const int sf = sh.start_flags, GC = sh.gadget_col, GW = 320 * E;
+// flags columns (flags.rs:46-134) for every instance: closed form per row.  exp(k) = the 8 u32 limbs.
+static void fill_flags(uint64_t* trace, size_t n, int sf, size_t num_io, const std::function<const uint32_t*(size_t)>& exp) {
   auto col = [&](int c) { return trace + (size_t)c * n; };
-  memset(trace, 0, (size_t)sh.num_cols * n * sizeof(u64));
-  // --- flags columns (flags.rs:46-134), per instance, closed form per row
+  const size_t RPB = 512;
   for (size_t k = 0; k < num_io; k++) {
-    const uint32_t* e = ios + IOW * k + 32 * E;
+    const uint32_t* e = exp(k);
     u64 limbs[8]; for (int i = 0; i < 8; i++) limbs[i] = e[i];
     u64 bit = limbs[0] & 1; limbs[0] >>= 1;  // first row
     for (size_t r = 0; r < RPB; r++) {
@@ -359,6 +352,50 @@ static int generate_exp_trace(const uint32_t* ios, size_t num_io, uint64_t* trac
       if (rotate) { for (int i = 0; i < 7; i++) limbs[i] = limbs[i + 1]; limbs[7] = 0; }
     }
   }
+}
+// periodic pulse (pulse.rs:100-144: counter starts at 1, period 64, witness 1/(counter-63)) and io pulses (pulse.rs:20-43)
+static void fill_pulses(uint64_t* trace, size_t n, const ExpShape& sh) {
+  auto col = [&](int c) { return trace + (size_t)c * n; };
+  const size_t RPB = 512;
+  std::vector<u64> inv = small_inverses(n);
+  u64* cnt = col(sh.start_periodic); u64* wit = col(sh.start_periodic + 1);
+  for (size_t i = 0; i < n; i++) { u64 c = (i + 1) % 64; cnt[i] = c; wit[i] = c == 63 ? 0 : (-F(inv[63 - c])).v; }
+  u64* cnt2 = col(sh.start_io_pulses);
+  for (size_t i = 0; i < n; i++) cnt2[i] = i;
+  parallel_for(2 * (size_t)sh.num_io, [&](size_t q) {
+    size_t pos = (q >> 1) * RPB + ((q & 1) ? RPB - 1 : 0);
+    u64* w = col(sh.witness_col((int)q)); u64* pul = col(sh.pulse_col((int)q));
+    for (size_t i = 0; i < n; i++) w[i] = i > pos ? inv[i - pos] : (i < pos ? (-F(inv[pos - i])).v : 0);
+    pul[pos] = 1;
+  });
+}
+// split range check (range_check.rs:116-160): table 0..255 then 255; per target: lo, perm(lo), table', hi, perm(hi), table'
+static bool fill_split_range_check(uint64_t* trace, size_t n, int table_col, int first_target, int num_targets) {
+  auto col = [&](int c) { return trace + (size_t)c * n; };
+  std::atomic<int> bad(0);
+  u64* table = col(table_col);
+  for (size_t i = 0; i < n; i++) table[i] = i < 256 ? i : 255;
+  parallel_for((size_t)num_targets, [&](size_t k) {
+    const u64* c = col(first_target + (int)k);
+    int o = table_col + 1 + 6 * (int)k;
+    for (size_t i = 0; i < n; i++) { if (c[i] >= 65536) { bad = 1; return; } col(o)[i] = c[i] & 0xff; col(o + 3)[i] = c[i] >> 8; }
+    permuted_cols_u(col(o), n, 256, col(o + 1), col(o + 2));
+    permuted_cols_u(col(o + 3), n, 256, col(o + 4), col(o + 5));
+  });
+  return !bad;
+}
+
+template <int E>
+static int generate_exp_trace(const uint32_t* ios, size_t num_io, uint64_t* trace, uint64_t* pi_out) {
+  if (!ios || !trace || !pi_out || num_io == 0 || num_io > (size_t)G1EXP_MAX_IO) return fail(SBN_ERR_BAD_ARG, "bad arguments");
+  const ExpShape sh(E, (int)num_io);
+  const size_t RPB = 512, n = RPB * num_io;
+  const size_t IOW = 8 * (4 * E + 1);  // u32 words per instance: x and offset (2E Fq each) + exp_val
+  if (n < 65536) return fail(SBN_ERR_UNSUPPORTED, "the table needs >= 2^16 rows (u16 range check, range_check.rs:26)");
+  const int sf = sh.start_flags, GC = sh.gadget_col, GW = 320 * E;
+  auto col = [&](int c) { return trace + (size_t)c * n; };
+  memset(trace, 0, (size_t)sh.num_cols * n * sizeof(u64));
+  fill_flags(trace, n, sf, num_io, [&](size_t k) { return ios + IOW * k + 32 * E; });
   // --- curve state in lockstep over the instances (g1/exp.rs:165-230, g2/exp.rs:180-246)
   typedef Co<E> C;
   std::vector<C> ax(num_io), ay(num_io), bx(num_io), by(num_io), lam(num_io), nx(num_io), ny(num_io);
@@ -428,23 +465,7 @@ static int generate_exp_trace(const uint32_t* ios, size_t num_io, uint64_t* trac
       for (int i = 0; i < 8; i++) p[2 * L + 8 + 8 * (v * E + q) + i] = (t[i / 2] >> (32 * (i % 2))) & 0xffffffffULL;
     }
   }
-  // --- periodic pulse (pulse.rs:100-144): counter starts at 1, period 64; witness = 1/(counter-63)
-  std::vector<u64> inv = small_inverses(n);
-  {
-    u64* cnt = col(sh.start_periodic); u64* wit = col(sh.start_periodic + 1);
-    for (size_t i = 0; i < n; i++) { u64 c = (i + 1) % 64; cnt[i] = c; wit[i] = c == 63 ? 0 : (-F(inv[63 - c])).v; }
-  }
-  // --- io pulses (pulse.rs:20-43): counter, then (witness, pulse) per position
-  {
-    u64* cnt = col(sh.start_io_pulses);
-    for (size_t i = 0; i < n; i++) cnt[i] = i;
-    parallel_for(2 * num_io, [&](size_t q) {
-      size_t pos = (q >> 1) * RPB + ((q & 1) ? RPB - 1 : 0);
-      u64* wit = col(sh.witness_col((int)q)); u64* pul = col(sh.pulse_col((int)q));
-      for (size_t i = 0; i < n; i++) wit[i] = i > pos ? inv[i - pos] : (i < pos ? (-F(inv[pos - i])).v : 0);
-      pul[pos] = 1;
-    });
-  }
+  fill_pulses(trace, n, sh);
   // --- u16 range check (range_check.rs:20-47)
   {
     u64* table = col(sh.start_lookups);
@@ -494,16 +515,101 @@ extern "C" int sbn_generate_trace_g1_op(const uint32_t* pts, size_t rows, uint64
     col(S::MAIN_COLS - 2)[r] = 1;  // is_add ; is_double = 0
   });
   if (bad) return fail(SBN_ERR_WITNESS, "modular witness generation failed");
-  // split range check (range_check.rs:116-160): table 0..255 then 255; per target lo, perm(lo), table', hi, perm(hi), table'
-  u64* table = col(S::MAIN_COLS);
-  for (size_t i = 0; i < n; i++) table[i] = i < 256 ? i : 255;
-  parallel_for((size_t)S::NUM_RC, [&](size_t k) {
-    const u64* c = col(S::START_RC + (int)k);
-    int o = S::MAIN_COLS + 1 + 6 * (int)k;
-    for (size_t i = 0; i < n; i++) { if (c[i] >= 65536) { bad = 1; return; } col(o)[i] = c[i] & 0xff; col(o + 3)[i] = c[i] >> 8; }
-    permuted_cols_u(col(o), n, 256, col(o + 1), col(o + 2));
-    permuted_cols_u(col(o + 3), n, 256, col(o + 4), col(o + 5));
-  });
+  if (!fill_split_range_check(trace, n, S::MAIN_COLS, S::START_RC, S::NUM_RC)) bad = 1;
   if (bad) return fail(SBN_ERR_WITNESS, "range-checked column holds a value >= 2^16");
+  return SBN_OK;
+}
+
+// ---- Fq12ExpStark (src/fields/fq12/exp.rs:229-319) --------------------------------------------------------------
+namespace {
+// flat-basis product (src/fields/fq12/mul.rs:24-87) in Montgomery Fq
+void fq12_mul_m(const Fq* a, const Fq* b, Fq* out) {
+  Fq z = {{0, 0, 0, 0}}, d[11], s[11];
+  for (int m = 0; m < 11; m++) { d[m] = z; s[m] = z; }
+  for (int i = 0; i < 6; i++)
+    for (int j = 0; j < 6; j++) {
+      d[i + j] = fadd(d[i + j], fsub(mmul(a[i], b[j]), mmul(a[i + 6], b[j + 6])));
+      s[i + j] = fadd(s[i + j], fadd(mmul(a[i], b[j + 6]), mmul(a[i + 6], b[j])));
+    }
+  auto x9 = [&](const Fq& v) { Fq t = fadd(v, v); t = fadd(t, t); t = fadd(t, t); return fadd(t, v); };
+  for (int m = 0; m < 6; m++) {
+    if (m < 5) { out[m] = fsub(fadd(d[m], x9(d[m + 6])), s[m + 6]); out[m + 6] = fadd(fadd(s[m], d[m + 6]), x9(s[m + 6])); }
+    else { out[m] = d[m]; out[m + 6] = s[m]; }
+  }
+}
+// Fq12Output columns (mul.rs:217-231) of x*y given the product `out` (standard form): 1344 words
+bool fq12_output_row(const u64 x[12][4], const u64 y[12][4], const u64 out[12][4], u64* lv) {
+  static thread_local int64_t xl[12][16], yl[12][16], d[11][31], s[11][31], t[31], in[12][31];
+  for (int c = 0; c < 12; c++) { limbs16(x[c], xl[c]); limbs16(y[c], yl[c]); }
+  memset(d, 0, sizeof d); memset(s, 0, sizeof s);
+  for (int i = 0; i < 6; i++)
+    for (int j = 0; j < 6; j++) {
+      conv16(xl[i], yl[j], t); for (int k = 0; k < 31; k++) d[i + j][k] += t[k];
+      conv16(xl[i + 6], yl[j + 6], t); for (int k = 0; k < 31; k++) d[i + j][k] -= t[k];
+      conv16(xl[i], yl[j + 6], t); for (int k = 0; k < 31; k++) s[i + j][k] += t[k];
+      conv16(xl[i + 6], yl[j], t); for (int k = 0; k < 31; k++) s[i + j][k] += t[k];
+    }
+  for (int m = 0; m < 6; m++)
+    for (int k = 0; k < 31; k++) {
+      if (m < 5) { in[m][k] = d[m][k] + 9 * d[m + 6][k] - s[m + 6][k]; in[m + 6][k] = s[m][k] + d[m + 6][k] + 9 * s[m + 6][k]; }
+      else { in[m][k] = d[m][k]; in[m + 6][k] = s[m][k]; }
+    }
+  ModW w[12];
+  for (int c = 0; c < 12; c++) if (!mod_witness(in[c], out[c], true, w[c])) return false;
+  int cur = 0;
+  for (int c = 0; c < 12; c++) { int64_t ol[16]; limbs16(out[c], ol); for (int i = 0; i < 16; i++) lv[cur++] = (u64)ol[i]; }
+  for (int c = 0; c < 12; c++) {
+    for (int i = 0; i < 16; i++) lv[cur++] = (u64)w[c].out_aux_red[i];
+    for (int i = 0; i < 17; i++) lv[cur++] = (u64)w[c].quot_abs[i];
+    for (int i = 0; i < 31; i++) lv[cur++] = (u64)w[c].aux_lo[i];
+    for (int i = 0; i < 31; i++) lv[cur++] = (u64)w[c].aux_hi[i];
+  }
+  for (int c = 0; c < 12; c++) lv[cur++] = w[c].sign > 0 ? 1 : GLP - 1;
+  return cur == 1344;
+}
+}  // namespace
+
+extern "C" int sbn_generate_trace_fq12_exp(const uint32_t* ios, size_t num_io, uint64_t* trace, uint64_t* pi_out) {
+  if (!ios || !trace || !pi_out || num_io == 0 || num_io > (size_t)G1EXP_MAX_IO || (num_io & (num_io - 1))) return fail(SBN_ERR_BAD_ARG, "bad arguments");
+  const ExpShape sh(12, (int)num_io);
+  const size_t RPB = 512, n = RPB * num_io, IOW = 200;
+  const int sf = sh.start_flags;
+  auto col = [&](int c) { return trace + (size_t)c * n; };
+  memset(trace, 0, (size_t)sh.num_cols * n * sizeof(u64));
+  for (size_t k = 0; k < num_io; k++)
+    for (int c = 0; c < 24; c++) { u64 t[4]; from_u32(ios + IOW * k + 8 * c, t); if (geq_p(t)) return fail(SBN_ERR_BAD_ARG, "coefficient >= p (instance %zu)", k); }
+  fill_flags(trace, n, sf, num_io, [&](size_t k) { return ios + IOW * k + 192; });
+  std::atomic<int> bad(0);
+  parallel_for(num_io, [&](size_t k) {
+    Fq a[12], b[12], prod[12];
+    u64 as[12][4], bs[12][4], ps[12][4];
+    for (int c = 0; c < 12; c++) { u64 t[4]; from_u32(ios + IOW * k + 8 * c, t); a[c] = to_m(t); from_u32(ios + IOW * k + 96 + 8 * c, t); b[c] = to_m(t); }
+    int prev_op = 0;  // 0 none, 1 square (a <- prod), 2 multiply (b <- prod)
+    std::vector<u64> lv(1344);
+    for (size_t r = 0; r < RPB; r++) {
+      size_t row = k * RPB + r;
+      if (prev_op == 1) memcpy(a, prod, sizeof a); else if (prev_op == 2) memcpy(b, prod, sizeof b);
+      for (int c = 0; c < 12; c++) { from_m(a[c], as[c]); from_m(b[c], bs[c]); put_limbs(col(16 * c) + row, n, as[c]); put_limbs(col(192 + 16 * c) + row, n, bs[c]); }
+      int op = (r & 1) ? 1 : (col(sf + 4)[row] ? 2 : 0);  // odd rows square, even rows multiply when the bit is set
+      if (op) {
+        fq12_mul_m(a, op == 1 ? a : b, prod);
+        for (int c = 0; c < 12; c++) from_m(prod[c], ps[c]);
+        if (!fq12_output_row(as, op == 1 ? as : bs, ps, lv.data())) { bad = 1; return; }
+      } else {  // Fq12Output::default (mul.rs:179-187)
+        for (int i = 0; i < 1332; i++) lv[i] = 0;
+        for (int i = 1332; i < 1344; i++) lv[i] = 1;
+      }
+      for (int c = 0; c < 1344; c++) col(384 + c)[row] = lv[c];
+      prev_op = op;
+    }
+    // public inputs: x, offset as 16-bit limbs, exp_val, output = b at the last row (fq12/exp.rs:95-117)
+    u64* p = pi_out + (size_t)sh.pi_per_io * k;
+    for (int c = 0; c < 24; c++) { u64 t[4]; from_u32(ios + IOW * k + 8 * c, t); for (int i = 0; i < 16; i++) p[16 * c + i] = (t[i / 4] >> (16 * (i % 4))) & 0xffff; }
+    for (int i = 0; i < 8; i++) p[384 + i] = ios[IOW * k + 192 + i];
+    for (int c = 0; c < 12; c++) for (int i = 0; i < 16; i++) p[392 + 16 * c + i] = (bs[c][i / 4] >> (16 * (i % 4))) & 0xffff;
+  });
+  if (bad) return fail(SBN_ERR_WITNESS, "modular witness generation failed");
+  fill_pulses(trace, n, sh);
+  if (!fill_split_range_check(trace, n, sh.start_lookups, sh.rc_start, sh.num_rc)) return fail(SBN_ERR_WITNESS, "range-checked column holds a value >= 2^16");
   return SBN_OK;
 }

@@ -161,9 +161,9 @@ extern "C" int sbn_verify(const sbn_air_desc* air, const sbn_config* cfg, const 
   Cons<E2> cs;
   std::vector<E2> apow[SBN_NCH];
   for (int j = 0; j < SBN_NCH; j++) {
-    apow[j].resize(APOW_MAX);
+    apow[j].resize(apow_len(as.npi, as.nzs));
     E2 a{F(1), F(0)}, al(alphas[j]);
-    for (int k = 0; k < APOW_MAX; k++) { apow[j][k] = a; a = a * al; }
+    for (size_t k = 0; k < apow[j].size(); k++) { apow[j][k] = a; a = a * al; }
     cs.alpha[j] = al; cs.acc[j] = E2(F(0), F(0)); cs.apow[j] = apow[j].data();
   }
   cs.z_last = zeta - f_inv(g);
@@ -181,7 +181,7 @@ extern "C" int sbn_verify(const sbn_air_desc* air, const sbn_config* cfg, const 
     static thread_local ExpPiConsts<E2> pic;
     const E2* app[SBN_NCH] = {apow[0].data(), apow[1].data()};
     exp_pi_consts<E2>(sh, app, epi.data(), pic);
-    if (sh.E == 1) exp_eval<1>(cs, row, sh, &pic); else exp_eval<2>(cs, row, sh, &pic);
+    if (sh.E == 1) exp_eval<1>(cs, row, sh, &pic); else if (sh.E == 2) exp_eval<2>(cs, row, sh, &pic); else exp_eval<12>(cs, row, sh, &pic);
     permutation_checks(cs, row, zrow, sh, (int)nz, g0, g1);
   }
   for (u32 i = 0; i < cfg->num_challenges; i++) {

@@ -62,3 +62,11 @@ def g2exp_case(O):
     ios, native = O.g2exp_inputs(128, 2)
     trace, pi = O.g2exp_trace(ios)
     return {"ios": ios, "native": native, "trace": trace, "pi": pi}
+
+
+@pytest.fixture(scope="session")
+def fq12exp_case(O):
+    """Seeded Fq12ExpStark(16) trace (2^13 rows x 9802 columns), the size of the reference's test_fq12_exp_raw."""
+    ios, native = O.fq12exp_inputs(16, 3)
+    trace, pi = O.fq12exp_trace(ios)
+    return {"ios": ios, "native": native, "trace": trace, "pi": pi}

@@ -388,3 +388,60 @@ def g2exp_trace(ios):
     L.orc_g2exp_generate_trace.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     L.orc_g2exp_generate_trace(ptr(ios), num_io, ptr(trace), ptr(pi))
     return trace, pi
+
+
+# ---------------------------------------------------------------- Fq12 = Fq2[w]/(w^6 - (9+i)), flat basis r_0..r_5, s_0..s_5
+AIR_FQ12_EXP = 4
+
+
+def fq12_mul(a, b):
+    """a, b: 12 ints [r_0..r_5, s_0..s_5] (coefficient of w^k is r_k + s_k i). Tower arithmetic over Fq2."""
+    A = [(a[k], a[k + 6]) for k in range(6)]
+    B = [(b[k], b[k + 6]) for k in range(6)]
+    prod = [(0, 0)] * 11
+    for i in range(6):
+        for j in range(6):
+            prod[i + j] = fq2_add(prod[i + j], fq2_mul(A[i], B[j]))
+    xi = (9, 1)
+    out = [fq2_add(prod[k], fq2_mul(xi, prod[k + 6])) if k < 5 else prod[k] for k in range(6)]
+    return [c[0] for c in out] + [c[1] for c in out]
+
+
+def fq12_pow(a, e):
+    r = [1] + [0] * 11
+    while e:
+        if e & 1:
+            r = fq12_mul(r, a)
+        a = fq12_mul(a, a)
+        e >>= 1
+    return r
+
+
+def fq12exp_inputs(num_io, seed):
+    """Mirror of src/fields/fq12/exp.rs:647-660 with seeded randomness: random Fq12 x, offset; exponent < r."""
+    rng = np.random.default_rng(seed)
+    ios = np.zeros((num_io, 200), dtype=np.uint32)
+    native = []
+    for k in range(num_io):
+        x = [int.from_bytes(rng.bytes(32), "little") % BN_P for _ in range(12)]
+        off = [int.from_bytes(rng.bytes(32), "little") % BN_P for _ in range(12)]
+        e = int.from_bytes(rng.bytes(32), "little") % BN_R
+        for c in range(12):
+            ios[k, 8 * c:8 * c + 8] = u32_limbs(x[c])
+            ios[k, 96 + 8 * c:96 + 8 * c + 8] = u32_limbs(off[c])
+        ios[k, 192:200] = u32_limbs(e)
+        native.append((x, off, e))
+    return ios, native
+
+
+def fq12exp_trace(ios):
+    num_io = ios.shape[0]
+    L = lib()
+    ncols = L.orc_air_num_columns(AIR_FQ12_EXP, num_io)
+    npi = L.orc_air_num_public_inputs(AIR_FQ12_EXP, num_io)
+    trace = np.zeros((ncols, 512 * num_io), dtype=np.uint64)
+    pi = np.zeros(npi, dtype=np.uint64)
+    ios = np.ascontiguousarray(ios, dtype=np.uint32)
+    L.orc_fq12exp_generate_trace.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    L.orc_fq12exp_generate_trace(ptr(ios), num_io, ptr(trace), ptr(pi))
+    return trace, pi

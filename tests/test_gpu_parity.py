@@ -176,3 +176,22 @@ def test_g2exp_proof_matches_oracle_digest_and_verifies(gpu, O, g2exp_case, gold
     assert O.verify(O.AIR_G2_EXP, 128, t)[0] != 0
     with pytest.raises(gpu.SbnError):
         gpu.verify_stark_proof(stark, gpu.Proof(t, 16), cfg)
+
+
+def test_fq12exp_proof_matches_oracle_digest_and_verifies(gpu, O, fq12exp_case, golden):
+    """Fq12ExpStark(16) (the reference's test_fq12_exp_raw size, 2^13 rows x 9802 columns, split range check):
+    GPU proof bytes == the CPU oracle's (committed sha256), both verifiers accept, tampering rejected."""
+    stark = gpu.Fq12ExpStark(16)
+    cfg = stark.config()
+    proof = gpu.prove(stark, cfg, fq12exp_case["trace"], fq12exp_case["pi"])
+    g = golden["proof_digests"]["fq12exp_io16_seed3"]
+    assert len(proof.words) == g["proof_words"]
+    assert [int(x) for x in proof.words[12:16]] == g["trace_cap0"]
+    assert hashlib.sha256(proof.to_bytes()).hexdigest() == g["proof_sha256"]
+    assert O.verify(O.AIR_FQ12_EXP, 16, proof.words) == (0, "")
+    gpu.verify_stark_proof(stark, proof, cfg)
+    t = proof.words.copy()
+    t[12 + 3 * 64 + 11] = (int(t[12 + 3 * 64 + 11]) + 1) % P
+    assert O.verify(O.AIR_FQ12_EXP, 16, t)[0] != 0
+    with pytest.raises(gpu.SbnError):
+        gpu.verify_stark_proof(stark, gpu.Proof(t, 13), cfg)

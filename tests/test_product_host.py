@@ -134,3 +134,29 @@ def test_g2_shape_tracegen_and_scalar_mult(S, O, g2exp_case, golden):
         acc = O.eval_constraints(O.AIR_G2_EXP, 128, tr[:, i], tr[:, (i + 1) % n], pi, [0x1234567, 0x7654321],
                                  (x - pow(w, n - 1, P)) % P, int(i == 0), int(i == n - 1))
         assert acc == [0, 0], i
+
+
+def test_fq12_shape_tracegen_and_power(S, O, fq12exp_case, golden):
+    """Fq12ExpStark: shapes = SURVEY section 8 (9802 cols @16, 11786 cols / 299008 PI / 310515 constraints @512),
+    host witness == oracle witness == golden digest, outputs == offset * x^e by independent tower arithmetic,
+    constraints vanish on sampled rows."""
+    st = S.Fq12ExpStark(16)
+    assert (st.num_columns, st.num_public_inputs, st.num_permutation_zs()) == (9802, 9344, 5328)
+    big = S.Fq12ExpStark(512)
+    assert (big.num_columns, big.num_public_inputs, big.num_permutation_zs(), big.num_constraints) == (11786, 299008, 5328, 310515)
+    tr, pi = st.generate_trace_and_public_inputs(fq12exp_case["ios"])
+    assert np.array_equal(pi, fq12exp_case["pi"]) and np.array_equal(tr, fq12exp_case["trace"])
+    g = golden["proof_digests"]["fq12exp_io16_seed3"]
+    assert hashlib.sha256(tr.tobytes()).hexdigest() == g["trace_sha256"]
+    for k in (0, 7, 15):
+        x, off, e = fq12exp_case["native"][k]
+        expect = O.fq12_mul(off, O.fq12_pow(x, e))
+        got = [sum(int(pi[584 * k + 392 + 16 * c + i]) << (16 * i) for i in range(16)) for c in range(12)]
+        assert got == expect
+    n = tr.shape[1]
+    w = pow(1753635133440165772, 1 << (32 - 13), P)
+    for i in (0, 1, 62, 63, 511, 512, 4097, n - 1):
+        x = pow(w, i, P)
+        acc = O.eval_constraints(O.AIR_FQ12_EXP, 16, tr[:, i], tr[:, (i + 1) % n], pi, [0x1234567, 0x7654321],
+                                 (x - pow(w, n - 1, P)) % P, int(i == 0), int(i == n - 1))
+        assert acc == [0, 0], i
