@@ -195,3 +195,24 @@ def test_fq12exp_proof_matches_oracle_digest_and_verifies(gpu, O, fq12exp_case, 
     assert O.verify(O.AIR_FQ12_EXP, 16, t)[0] != 0
     with pytest.raises(gpu.SbnError):
         gpu.verify_stark_proof(stark, gpu.Proof(t, 13), cfg)
+
+
+def test_fq12exp_2pow16_independent_verifier(gpu, O):
+    """Size-independent property at 2^16 rows (Fq12ExpStark(128), 10250 columns, 74752 public inputs): the CPU
+    oracle's VERIFIER (independent code) accepts the GPU proof, outputs equal offset * x^e computed with python
+    tower arithmetic, and a flipped opening is rejected.  (The oracle's prover would need ~10 minutes here.)"""
+    num_io = 128
+    ios, native = O.fq12exp_inputs(num_io, 11)
+    stark = gpu.Fq12ExpStark(num_io)
+    cfg = stark.config()
+    trace, pi = stark.generate_trace_and_public_inputs(ios)
+    for k in (0, 127):
+        x, off, e = native[k]
+        got = [sum(int(pi[584 * k + 392 + 16 * c + i]) << (16 * i) for i in range(16)) for c in range(12)]
+        assert got == O.fq12_mul(off, O.fq12_pow(x, e))
+    proof = gpu.prove(stark, cfg, trace, pi)
+    assert O.verify(O.AIR_FQ12_EXP, num_io, proof.words) == (0, "")
+    gpu.verify_stark_proof(stark, proof, cfg)
+    t = proof.words.copy()
+    t[12 + 3 * 64 + 5] = (int(t[12 + 3 * 64 + 5]) + 1) % P
+    assert O.verify(O.AIR_FQ12_EXP, num_io, t)[0] != 0
