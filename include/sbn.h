@@ -1,7 +1,7 @@
 /*
  * sbn.h -- C ABI of the MI355X-native Starky/BN254 prover path (libsbn254.so).
  *
- * Drop-in boundary for the reference's prove()/verify_stark_proof() calls on the G1 tables:
+ * Drop-in boundary for the reference's prove()/verify_stark_proof() calls on the G1 / G2 / Fq12 tables:
  *   reference call sites   src/curves/g1/exp.rs:811-826      (G1ExpStark: trace, pi, prove, verify)
  *                          src/curves/g1/muladd.rs:666-678   (G1Stark)
  *                          src/curves/g1/circuit.rs:187-201  (G1ExpStarkyProofGenerator::run_once)
