@@ -92,6 +92,146 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassParams p) 
   }
 }
 
+// -------------------------------------------------------------------------------------------------------------
+// K1' fast pass for R = 256 / 512 (the sizes the 2^16..2^18-row tables use): a 256-point NTT is two rounds of
+// 16-point DFTs held in REGISTERS.  In Goldilocks 2 has order 192, so rho = 2^12 is a primitive 16th root of unity
+// and every twiddle inside a 16-point DFT is a power of two: the butterflies need only shifts and one 128-bit
+// reduction, no multiplications.  The reference's root is omega_16 = rho^13 (omega_16^-1 = rho^3), so
+// DFT_omega[k] = DFT_rho[13 k mod 16]: the same values in a permuted order, which is absorbed into the store index
+// (k = 5 m for the forward transform, 11 m for the inverse, m = index under rho).  One general twiddle
+// omega_256^(g k1) per element sits between the two rounds, which exchange data through LDS once.  R = 512 adds one
+// leading radix-2 stage (free for the zero-padded LDE, whose upper half is zero).  Values stay "weak" (any u64
+// congruent mod p) until the final store.  ~200 instructions per element per pass instead of ~450.
+// -------------------------------------------------------------------------------------------------------------
+namespace nw {
+__device__ __forceinline__ u64 add(u64 a, u64 b) {
+  u64 s = a + b;
+  u64 c = s < a ? GLEPS : 0;
+  s += c;
+  if (s < c) s += GLEPS;
+  return s;
+}
+__device__ __forceinline__ u64 sub(u64 a, u64 b) {
+  u64 d = a - b;
+  u64 c = a < b ? GLEPS : 0;
+  u64 r = d - c;
+  if (d < c) r -= GLEPS;
+  return r;
+}
+__device__ __forceinline__ u64 red(u64 lo, u64 hi) {  // (hi:lo) mod p, weak
+  u32 hi_hi = (u32)(hi >> 32), hi_lo = (u32)hi;
+  u64 t0 = lo - hi_hi;
+  if (lo < hi_hi) t0 -= GLEPS;
+  u64 t1 = ((u64)hi_lo << 32) - hi_lo;
+  u64 r = t0 + t1;
+  if (r < t1) r += GLEPS;
+  return r;
+}
+template <int E> __device__ __forceinline__ u64 mul_pow2(u64 x) {  // x * 2^E, 0 <= E < 96
+  if constexpr (E == 0) return x;
+  else if constexpr (E < 64) return red(x << E, x >> (64 - E));
+  else return mul_pow2<E - 48>(mul_pow2<48>(x));
+}
+__device__ __forceinline__ u64 mul(u64 a, u64 b) { return red(a * b, __umul64hi(a, b)); }
+__device__ __forceinline__ u64 canon(u64 x) { return x >= GLP ? x - GLP : x; }
+
+#define NW_BF(i, j, E) { u64 a_ = x[i], b_ = x[j]; x[i] = add(a_, b_); x[j] = mul_pow2<E>(sub(a_, b_)); }
+// 16-point DIF DFT with root rho = 2^12; x[p] <- DFT_rho[bitrev4(p)]
+__device__ __forceinline__ void dft16_rho(u64* x) {
+  NW_BF(0, 8, 0) NW_BF(1, 9, 12) NW_BF(2, 10, 24) NW_BF(3, 11, 36) NW_BF(4, 12, 48) NW_BF(5, 13, 60) NW_BF(6, 14, 72) NW_BF(7, 15, 84)
+  NW_BF(0, 4, 0) NW_BF(1, 5, 24) NW_BF(2, 6, 48) NW_BF(3, 7, 72) NW_BF(8, 12, 0) NW_BF(9, 13, 24) NW_BF(10, 14, 48) NW_BF(11, 15, 72)
+  NW_BF(0, 2, 0) NW_BF(1, 3, 48) NW_BF(4, 6, 0) NW_BF(5, 7, 48) NW_BF(8, 10, 0) NW_BF(9, 11, 48) NW_BF(12, 14, 0) NW_BF(13, 15, 48)
+  NW_BF(0, 1, 0) NW_BF(2, 3, 0) NW_BF(4, 5, 0) NW_BF(6, 7, 0) NW_BF(8, 9, 0) NW_BF(10, 11, 0) NW_BF(12, 13, 0) NW_BF(14, 15, 0)
+}
+#undef NW_BF
+}  // namespace nw
+
+// LOG_B = 0: R = 256, LOG_B = 1: R = 512.  Tile width T = 16, 256 threads, LDS = (R/16)*272*8 bytes.
+// `kperm` = 5 (forward) or 11 (inverse): index of DFT_omega given the index under rho.
+template <int LOG_B>
+__global__ __launch_bounds__(256) void ntt_fast_pass_kernel(NttPassParams p, u32 kperm) {
+  extern __shared__ u64 lds[];
+  constexpr u32 NB = 1u << LOG_B;       // 256-point blocks per tile column
+  constexpr u32 R = 256u << LOG_B;
+  const size_t col = blockIdx.y;
+  const size_t t0 = (size_t)blockIdx.x << 4;
+  const u64* in = p.in + col * p.in_col_stride;
+  u64* out = p.out + col * p.out_col_stride;
+  // work item = (g, t): g = residue of r mod 16 within a 256-block, t = tile column.  For pass B (r contiguous in
+  // memory) lanes run over g first so that each group of 16 lanes reads 128 contiguous bytes.
+  u32 g, t;
+  if (p.r_fast_load) { g = threadIdx.x & 15; t = threadIdx.x >> 4; } else { t = threadIdx.x & 15; g = threadIdx.x >> 4; }
+  const size_t tg = t0 + t;
+  // LDS exchange layout, chosen per lane order so that both the round-1 writes and the round-2 reads are
+  // bank-conflict free (8-byte slots, 32 per LDS row): lanes (t fastest): [k1][g][t], row stride 272;
+  // lanes (g fastest): [k1][t][g], row stride 257.
+  const u32 S1 = p.r_fast_load ? 257u : 272u;
+  const u32 lane_off = p.r_fast_load ? (t * 16) : t;   // + g*16 or + g
+  const u32 g_mul = p.r_fast_load ? 1u : 16u;
+  u64 x[NB][16];
+  // ---- load (+ coset pre-scale), natural order r = g + 16 q (+ 256 b)
+#pragma unroll
+  for (u32 b = 0; b < NB; b++)
+#pragma unroll
+    for (u32 q = 0; q < 16; q++) {
+      u32 r = g + 16 * q + 256 * b;
+      size_t gi = (size_t)r * p.in_sr + tg * p.in_st;
+      u64 v = 0;
+      if (gi < p.n_in) {
+        v = in[gi];
+        if (p.pre) v = nw::mul(v, p.pre[gi]);
+      }
+      x[b][q] = v;
+    }
+  // ---- leading radix-2 DIF stage for R = 512: (u, v) = (a + b, (a - b) w_512^r); block 0 -> even, block 1 -> odd outputs
+  if (LOG_B == 1) {
+#pragma unroll
+    for (u32 q = 0; q < 16; q++) {
+      u32 r = g + 16 * q;
+      u64 a = x[0][q], bb = x[NB - 1][q];
+      u64 w = tw_lookup(p.tw, p.tw_log, r, 9).v;
+      x[0][q] = nw::add(a, bb);
+      x[NB - 1][q] = nw::mul(nw::sub(a, bb), w);
+    }
+  }
+  // ---- round 1: DFT-16 over q, twiddle by w_256^(g k1), exchange through LDS
+#pragma unroll
+  for (u32 b = 0; b < NB; b++) {
+    nw::dft16_rho(x[b]);
+#pragma unroll
+    for (u32 pidx = 0; pidx < 16; pidx++) {
+      u32 m = __brev(pidx) >> 28;             // index under rho
+      u32 k1 = (kperm * m) & 15;              // index under omega_16 (or its inverse)
+      u64 v = x[b][pidx];
+      if (g && k1) v = nw::mul(v, tw_lookup(p.tw, p.tw_log, (u64)g * k1, 8).v);
+      lds[(b * 16 + k1) * S1 + lane_off + g * g_mul] = v;
+    }
+  }
+  __syncthreads();
+  // ---- round 2: this thread now owns k1 = its former g index: read Z[g'][k1] for g' = 0..15
+  const u32 k1 = g;
+#pragma unroll
+  for (u32 b = 0; b < NB; b++) {
+#pragma unroll
+    for (u32 gp = 0; gp < 16; gp++) x[b][gp] = lds[(b * 16 + k1) * S1 + lane_off + gp * g_mul];
+    nw::dft16_rho(x[b]);
+#pragma unroll
+    for (u32 pidx = 0; pidx < 16; pidx++) {
+      u32 m = __brev(pidx) >> 28;
+      u32 k2 = (kperm * m) & 15;
+      u32 k256 = k1 + 16 * k2;                       // frequency inside the 256-point block
+      u32 k = LOG_B == 0 ? k256 : (k256 * NB + b);   // DIF: block b holds outputs k = 2 k256 + b
+      u64 v = x[b][pidx];
+      if (p.twiddle) v = nw::mul(v, tw_lookup(p.tw, p.tw_log, (u64)k * tg, p.log_n).v);
+      if (p.scale != 1) v = nw::mul(v, p.scale);
+      size_t go = (size_t)k * p.out_sr + tg * p.out_st;
+      if (p.post) v = nw::mul(v, p.post[go]);
+      out[go] = nw::canon(v);
+    }
+  }
+  (void)R;
+}
+
 // table[i] = base^i (i < n); one thread per entry (square-and-multiply), used once per prover.
 __global__ void pow_table_kernel(u64* out, size_t n, u64 base) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

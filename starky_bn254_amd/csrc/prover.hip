@@ -73,6 +73,7 @@ struct sbn_prover {
   hipEvent_t ev[ST_COUNT + 1];
   float stage_ms[ST_COUNT + EX_COUNT];
   size_t ntt_chunk;
+  bool fast_ntt = true;                      // SBN_FAST_NTT=0 selects the generic radix-2 pass everywhere
   hipStream_t hstream = nullptr;             // sponge absorption / Merkle stream
   hipEvent_t chunk_ready[MAX_CHUNKS];        // main -> hash: LDE chunk k is complete
   hipEvent_t abs_ev[2 * MAX_CHUNKS];         // hash stream: before/after each absorb launch
@@ -116,15 +117,30 @@ static int ntt_columns(sbn_prover* P, const u64* in, size_t in_cs, u64* out, siz
     pb.in = b.in + c0 * tmp_cs; pb.out = b.out + c0 * out_cs;
     dim3 ga((unsigned)(n2 >> pa.log_t), (unsigned)nc), gb((unsigned)(n1 >> pb.log_t), (unsigned)nc);
     size_t la = ((size_t)1 << pa.log_r) * ((1u << pa.log_t) + 1) * 8, lb = ((size_t)1 << pb.log_r) * ((1u << pb.log_t) + 1) * 8;
-    hipLaunchKernelGGL(ntt_pass_kernel, ga, dim3(NTT_THREADS), la, P->stream, pa);
-    if (log_n2 > 0) hipLaunchKernelGGL(ntt_pass_kernel, gb, dim3(NTT_THREADS), lb, P->stream, pb);
-    else HIPC(hipMemcpyAsync(pb.out, pb.in, sizeof(u64), hipMemcpyDeviceToDevice, P->stream));
+    const u32 kperm = inverse ? 11u : 5u;  // omega_16 = (2^12)^13, omega_16^-1 = (2^12)^3: 13^-1 = 5, 3^-1 = 11 (mod 16)
+    auto launch = [&](const NttPassParams& q, dim3 grid, size_t lds_bytes) {
+      if (P->fast_ntt && q.log_t == 4 && q.log_r == 8) hipLaunchKernelGGL(ntt_fast_pass_kernel<0>, grid, dim3(256), 16 * 272 * 8, P->stream, q, kperm);
+      else if (P->fast_ntt && q.log_t == 4 && q.log_r == 9) hipLaunchKernelGGL(ntt_fast_pass_kernel<1>, grid, dim3(256), 32 * 272 * 8, P->stream, q, kperm);
+      else hipLaunchKernelGGL(ntt_pass_kernel, grid, dim3(NTT_THREADS), lds_bytes, P->stream, q);
+    };
+    if (P->fast_ntt && pa.log_r == 9 && log_n2 >= 4) pa.log_t = 4;  // the fast kernel always uses 16-wide tiles
+    if (P->fast_ntt && pb.log_r == 9 && log_n1 >= 4) pb.log_t = 4;
+    ga = dim3((unsigned)(n2 >> pa.log_t), (unsigned)nc); gb = dim3((unsigned)(n1 >> pb.log_t), (unsigned)nc);
+    la = ((size_t)1 << pa.log_r) * ((1u << pa.log_t) + 1) * 8; lb = ((size_t)1 << pb.log_r) * ((1u << pb.log_t) + 1) * 8;
+    launch(pa, ga, la);
+    launch(pb, gb, lb);
   }
   HIPC(hipGetLastError());
   return 0;
 }
 
 static u64 host_inv_pow2(u32 k) { return f_inv(F((u64)1 << k)).v; }
+// the R = 512 fast pass needs 69,632 bytes of dynamic LDS (> the 64 KiB default)
+static int ntt_fast_setup() {
+  static bool done = false;
+  if (!done) { HIPC(hipFuncSetAttribute((const void*)ntt_fast_pass_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 32 * 272 * 8)); done = true; }
+  return 0;
+}
 
 // values [ncols][n] -> coefficients [ncols][n]
 static int intt_values(sbn_prover* P, const u64* vals, u64* coef, size_t ncols) {
@@ -255,6 +271,8 @@ extern "C" int sbn_prover_create(const sbn_air_desc* air, const sbn_config* cfg,
   const char* ce = getenv("SBN_NTT_CHUNK");
   P->ntt_chunk = ce ? (size_t)atol(ce) : 64;
   if (P->ntt_chunk == 0) P->ntt_chunk = 64;
+  { const char* fe = getenv("SBN_FAST_NTT"); P->fast_ntt = !(fe && fe[0] == '0'); }
+  { int rc0 = ntt_fast_setup(); if (rc0) { delete P; return rc0; } }
   HIPC(hipStreamCreate(&P->stream));
   HIPC(hipStreamCreate(&P->hstream));
   for (auto& e : P->ev) HIPC(hipEventCreate(&e));
@@ -670,6 +688,8 @@ extern "C" int sbn_commit_values(const uint64_t* cols, size_t ncols, size_t n, u
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(SBN_ERR_NO_DEVICE, "no HIP device available: no CPU fallback");
   HIPC(hipSetDevice(g_device));
+  { int rc0 = ntt_fast_setup(); if (rc0) return rc0; }
+  { const char* fe = getenv("SBN_FAST_NTT"); P.fast_ntt = !(fe && fe[0] == '0'); }
   HIPC(hipStreamCreate(&P.stream));
   u64 *d_vals = nullptr, *d_coef = nullptr, *d_lde = nullptr;
   int rc = 0;
