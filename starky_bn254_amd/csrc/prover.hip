@@ -7,6 +7,8 @@
 #include <algorithm>
 #include <cstring>
 #include <cstdlib>
+#include <thread>
+#include <atomic>
 
 using namespace sbn;
 
@@ -377,7 +379,19 @@ extern "C" int sbn_prover_load_trace(sbn_prover* P, const uint64_t* trace, const
   if (!P || !trace) return fail(SBN_ERR_BAD_ARG, "null argument");
   int rc = check_pi(P, pi, n_pi); if (rc) return rc;
   size_t words = P->air.ncols * P->n;
-  for (size_t i = 0; i < words; i++) if (trace[i] >= GLP) return fail(SBN_ERR_NON_CANONICAL, "trace word %zu is not canonical", i);
+  {  // canonical-form check on several host threads (the copy below is the PCIe-bound part)
+    unsigned nt = std::thread::hardware_concurrency(); if (nt == 0) nt = 4; if (nt > 16) nt = 16;
+    std::atomic<size_t> bad(words);
+    std::vector<std::thread> th;
+    size_t per = (words + nt - 1) / nt;
+    for (unsigned t = 0; t < nt; t++)
+      th.emplace_back([&, t] {
+        size_t a = t * per, b = std::min(words, a + per);
+        for (size_t i = a; i < b; i++) if (trace[i] >= GLP) { size_t cur = bad.load(); while (i < cur && !bad.compare_exchange_weak(cur, i)) {} break; }
+      });
+    for (auto& x : th) x.join();
+    if (bad.load() < words) return fail(SBN_ERR_NON_CANONICAL, "trace word %zu is not canonical", bad.load());
+  }
   HIPC(hipSetDevice(P->device));
   HIPC(hipMemcpy(P->d_trace, trace, words * sizeof(u64), hipMemcpyHostToDevice));
   P->loaded = true;

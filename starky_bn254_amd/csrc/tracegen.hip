@@ -16,6 +16,7 @@
 #include <atomic>
 #include <cstring>
 #include <functional>
+#include <chrono>
 
 using namespace sbn;
 typedef unsigned __int128 u128;
@@ -289,13 +290,19 @@ inline void cbatch_inv(std::vector<Co<2>>& v) {
 }
 
 void parallel_for(size_t n, const std::function<void(size_t)>& f) {
-  unsigned nt = std::thread::hardware_concurrency(); if (nt == 0) nt = 4; if (nt > 32) nt = 32;
+  unsigned nt = std::thread::hardware_concurrency(); if (nt == 0) nt = 4; if (nt > 64) nt = 64;
   if (nt > n) nt = (unsigned)n;
   if (nt <= 1) { for (size_t i = 0; i < n; i++) f(i); return; }
   std::atomic<size_t> next(0);
   std::vector<std::thread> th;
   for (unsigned t = 0; t < nt; t++) th.emplace_back([&] { for (size_t i; (i = next.fetch_add(1)) < n;) f(i); });
   for (auto& t : th) t.join();
+}
+// contiguous index ranges of `chunk` per task: consecutive rows written by one thread stay cache-friendly
+// in the column-major trace
+void parallel_for_chunks(size_t n, size_t chunk, const std::function<void(size_t, size_t)>& f) {
+  size_t tasks = (n + chunk - 1) / chunk;
+  parallel_for(tasks, [&](size_t t) { size_t a = t * chunk, b = a + chunk < n ? a + chunk : n; f(a, b); });
 }
 
 // permuted_cols (lookup.rs:60-111) for values < range (counting sort); table = 0..range-1 then range-1 repeated.
@@ -366,6 +373,7 @@ static void fill_pulses(uint64_t* trace, size_t n, const ExpShape& sh) {
     size_t pos = (q >> 1) * RPB + ((q & 1) ? RPB - 1 : 0);
     u64* w = col(sh.witness_col((int)q)); u64* pul = col(sh.pulse_col((int)q));
     for (size_t i = 0; i < n; i++) w[i] = i > pos ? inv[i - pos] : (i < pos ? (-F(inv[pos - i])).v : 0);
+    memset(pul, 0, n * sizeof(u64));
     pul[pos] = 1;
   });
 }
@@ -385,6 +393,16 @@ static bool fill_split_range_check(uint64_t* trace, size_t n, int table_col, int
   return !bad;
 }
 
+struct PhaseTimer {  // SBN_TRACE_TIMING=1 prints per-phase wall time to stderr
+  bool on; std::chrono::steady_clock::time_point t;
+  PhaseTimer() : on(getenv("SBN_TRACE_TIMING") != nullptr), t(std::chrono::steady_clock::now()) {}
+  void lap(const char* name) {
+    auto n = std::chrono::steady_clock::now();
+    if (on) fprintf(stderr, "[tracegen] %-18s %8.3f s\n", name, std::chrono::duration<double>(n - t).count());
+    t = n;
+  }
+};
+
 template <int E>
 static int generate_exp_trace(const uint32_t* ios, size_t num_io, uint64_t* trace, uint64_t* pi_out) {
   if (!ios || !trace || !pi_out || num_io == 0 || num_io > (size_t)G1EXP_MAX_IO) return fail(SBN_ERR_BAD_ARG, "bad arguments");
@@ -394,78 +412,85 @@ static int generate_exp_trace(const uint32_t* ios, size_t num_io, uint64_t* trac
   if (n < 65536) return fail(SBN_ERR_UNSUPPORTED, "the table needs >= 2^16 rows (u16 range check, range_check.rs:26)");
   const int sf = sh.start_flags, GC = sh.gadget_col, GW = 320 * E;
   auto col = [&](int c) { return trace + (size_t)c * n; };
-  memset(trace, 0, (size_t)sh.num_cols * n * sizeof(u64));
+  PhaseTimer tm;  // every column is written in full below (pulse columns are zeroed in fill_pulses): no global memset
   fill_flags(trace, n, sf, num_io, [&](size_t k) { return ios + IOW * k + 32 * E; });
-  // --- curve state in lockstep over the instances (g1/exp.rs:165-230, g2/exp.rs:180-246)
+  tm.lap("flags");
+  // --- phase 1: the double-and-add chain of every instance (g1/exp.rs:165-230, g2/exp.rs:180-246), one instance per
+  //     task: 512 sequential steps, each with one field inversion (binary extended GCD; Fq2 through the norm).
+  //     Per row the standard-form values ax ay bx by [lam nx ny] are kept for phase 2.
   typedef Co<E> C;
-  std::vector<C> ax(num_io), ay(num_io), bx(num_io), by(num_io), lam(num_io), nx(num_io), ny(num_io);
-  std::vector<char> active(num_io), was_double(num_io, 0), had_op(num_io, 0);
-  for (size_t k = 0; k < num_io; k++) {
-    C* dst[4] = {&ax[k], &ay[k], &bx[k], &by[k]};
-    for (int v = 0; v < 4; v++) for (int q = 0; q < E; q++) {
-      u64 t[4]; from_u32(ios + IOW * k + 8 * (v * E + q), t);
-      if (geq_p(t)) return fail(SBN_ERR_BAD_ARG, "coordinate >= p (instance %zu)", k);
-      dst[v]->c[q] = to_m(t);
-    }
-  }
+  const size_t SV = 28 * E;
+  std::vector<u64> std_vals(n * SV);
+  std::vector<unsigned char> row_op(n);  // 0 none, 1 add, 2 double
+  std::vector<C> out_x(num_io), out_y(num_io);
   std::atomic<int> bad(0);
-  std::vector<C> den;
-  const size_t SV = 28 * E;  // per instance: ax ay bx by lam nx ny, standard form, E Fq each
-  std::vector<u64> std_vals(num_io * SV);
-  for (size_t r = 0; r < RPB; r++) {
-    const bool dbl = r & 1;
-    if (r > 0) for (size_t k = 0; k < num_io; k++) if (had_op[k]) { if (was_double[k]) { ax[k] = nx[k]; ay[k] = ny[k]; } else { bx[k] = nx[k]; by[k] = ny[k]; } }
-    den.clear();
-    for (size_t k = 0; k < num_io; k++) {
-      active[k] = dbl ? 1 : (char)col(sf + 4)[k * RPB + r];
-      if (active[k]) { C d = dbl ? cadd(ay[k], ay[k]) : csub(bx[k], ax[k]); if (czero(d)) return fail(SBN_ERR_WITNESS, "degenerate affine operation (instance %zu, row %zu)", k, r); den.push_back(d); }
+  for (size_t k = 0; k < num_io; k++)
+    for (int v = 0; v < 4 * E; v++) { u64 t[4]; from_u32(ios + IOW * k + 8 * v, t); if (geq_p(t)) return fail(SBN_ERR_BAD_ARG, "coordinate >= p (instance %zu)", k); }
+  parallel_for(num_io, [&](size_t k) {
+    C ax, ay, bx, by, lam, nx, ny;
+    C* dst[4] = {&ax, &ay, &bx, &by};
+    for (int v = 0; v < 4; v++) for (int q = 0; q < E; q++) { u64 t[4]; from_u32(ios + IOW * k + 8 * (v * E + q), t); dst[v]->c[q] = to_m(t); }
+    int prev = 0;
+    std::vector<C> one(1);
+    for (size_t r = 0; r < RPB; r++) {
+      const size_t row = k * RPB + r;
+      if (prev == 2) { ax = nx; ay = ny; } else if (prev == 1) { bx = nx; by = ny; }
+      const bool dbl = r & 1;
+      const int op = dbl ? 2 : (col(sf + 4)[row] ? 1 : 0);
+      if (op) {
+        C d = dbl ? cadd(ay, ay) : csub(bx, ax);
+        if (czero(d)) { bad = 2; return; }
+        one[0] = d; cbatch_inv(one);
+        C num;
+        if (dbl) { C x2 = cmul(ax, ax); num = cadd(cadd(x2, x2), x2); } else num = csub(by, ay);
+        lam = cmul(num, one[0]);
+        C l2 = cmul(lam, lam);
+        nx = dbl ? csub(csub(l2, ax), ax) : csub(csub(l2, ax), bx);
+        ny = csub(cmul(lam, csub(ax, nx)), ay);
+      }
+      u64* sv = &std_vals[row * SV];
+      const C* src[7] = {&ax, &ay, &bx, &by, &lam, &nx, &ny};
+      for (int v = 0; v < (op ? 7 : 4); v++) for (int q = 0; q < E; q++) from_m(src[v]->c[q], sv + 4 * (v * E + q));
+      row_op[row] = (unsigned char)op;
+      prev = op;
     }
-    cbatch_inv(den);
-    size_t di = 0;
-    for (size_t k = 0; k < num_io; k++) {
-      had_op[k] = active[k]; was_double[k] = dbl;
-      if (!active[k]) continue;
-      C num;
-      if (dbl) { C x2 = cmul(ax[k], ax[k]); num = cadd(cadd(x2, x2), x2); } else num = csub(by[k], ay[k]);
-      lam[k] = cmul(num, den[di++]);
-      C l2 = cmul(lam[k], lam[k]);
-      nx[k] = dbl ? csub(csub(l2, ax[k]), ax[k]) : csub(csub(l2, ax[k]), bx[k]);
-      ny[k] = csub(cmul(lam[k], csub(ax[k], nx[k])), ay[k]);
-    }
-    for (size_t k = 0; k < num_io; k++) {
-      u64* s = &std_vals[k * SV];
-      const C* src[7] = {&ax[k], &ay[k], &bx[k], &by[k], &lam[k], &nx[k], &ny[k]};
-      for (int v = 0; v < (active[k] ? 7 : 4); v++) for (int q = 0; q < E; q++) from_m(src[v]->c[q], s + 4 * (v * E + q));
-    }
-    parallel_for(num_io, [&](size_t k) {
-      size_t row = k * RPB + r;
-      const u64* s = &std_vals[k * SV];
-      for (int v = 0; v < 4; v++) for (int q = 0; q < E; q++) put_limbs(col(16 * (v * E + q)) + row, n, s + 4 * (v * E + q));
-      u64 lv[640];
-      if (active[k]) {
-        bool ok = E == 1 ? g1_output_row(dbl, s, s + 4, s + 8, s + 12, s + 16, s + 20, s + 24, lv)
-                         : g2_output_row(dbl, s, s + 8, s + 16, s + 24, s + 32, s + 40, s + 48, lv);
+    out_x[k] = bx; out_y[k] = by;  // b at the last row
+  });
+  tm.lap("curve chains");
+  if (bad == 2) return fail(SBN_ERR_WITNESS, "degenerate affine operation (x1 == x2 or y == 0)");
+  // --- phase 2: limb columns and the modular-gadget witnesses of every row, rows in contiguous chunks
+  parallel_for_chunks(n, 64, [&](size_t r0, size_t r1) {
+    u64 lv[640];
+    for (size_t row = r0; row < r1; row++) {
+      const u64* sv = &std_vals[row * SV];
+      for (int v = 0; v < 4; v++) for (int q = 0; q < E; q++) put_limbs(col(16 * (v * E + q)) + row, n, sv + 4 * (v * E + q));
+      const int op = row_op[row];
+      if (op) {
+        bool ok = E == 1 ? g1_output_row(op == 2, sv, sv + 4, sv + 8, sv + 12, sv + 16, sv + 20, sv + 24, lv)
+                         : g2_output_row(op == 2, sv, sv + 8, sv + 16, sv + 24, sv + 32, sv + 40, sv + 48, lv);
         if (!ok) { bad = 1; return; }
       } else {  // G1Output::default / G2Output::default: zeros, quot signs = 1
         for (int i = 0; i < GW - 3 * E; i++) lv[i] = 0;
         for (int i = GW - 3 * E; i < GW; i++) lv[i] = 1;
       }
       for (int c = 0; c < GW; c++) col(GC + c)[row] = lv[c];
-    });
-    if (bad) return fail(SBN_ERR_WITNESS, "modular witness generation failed at row step %zu", r);
-  }
+    }
+  });
+  tm.lap("row witnesses");
+  if (bad) return fail(SBN_ERR_WITNESS, "modular witness generation failed");
   // --- public inputs: x, offset, exp_val, output as u32 limbs (g1/exp.rs:124-135, g2/exp.rs:139-156)
   for (size_t k = 0; k < num_io; k++) {
     u64* p = pi_out + (size_t)sh.pi_per_io * k;
     const int L = sh.L;
     for (int i = 0; i < 2 * L + 8; i++) p[i] = ios[IOW * k + i];
-    const C* o[2] = {&bx[k], &by[k]};  // b at the last row
+    const C* o[2] = {&out_x[k], &out_y[k]};  // b at the last row
     for (int v = 0; v < 2; v++) for (int q = 0; q < E; q++) {
       u64 t[4]; from_m(o[v]->c[q], t);
       for (int i = 0; i < 8; i++) p[2 * L + 8 + 8 * (v * E + q) + i] = (t[i / 2] >> (32 * (i % 2))) & 0xffffffffULL;
     }
   }
   fill_pulses(trace, n, sh);
+  tm.lap("pulses");
   // --- u16 range check (range_check.rs:20-47)
   {
     u64* table = col(sh.start_lookups);
@@ -477,6 +502,7 @@ static int generate_exp_trace(const uint32_t* ios, size_t num_io, uint64_t* trac
     });
     if (bad) return fail(SBN_ERR_WITNESS, "range-checked column holds a value >= 2^16");
   }
+  tm.lap("range check");
   return SBN_OK;
 }
 
@@ -492,7 +518,6 @@ extern "C" int sbn_generate_trace_g1_op(const uint32_t* pts, size_t rows, uint64
   if (!pts || !trace || rows < 256 || (rows & (rows - 1))) return fail(SBN_ERR_BAD_ARG, "rows must be a power of two >= 256");
   const size_t n = rows;
   auto col = [&](int c) { return trace + (size_t)c * n; };
-  memset(trace, 0, (size_t)S::NUM_COLS * n * sizeof(u64));
   std::vector<Fq> den(n);
   std::vector<u64> a(n * 16);  // ax ay bx by standard
   for (size_t r = 0; r < n; r++) {
@@ -512,7 +537,8 @@ extern "C" int sbn_generate_trace_g1_op(const uint32_t* pts, size_t rows, uint64
     u64 lv[320];
     if (!g1_output_row(false, s, s + 4, s + 8, s + 12, ls, nxs, nys, lv)) { bad = 1; return; }
     for (int c = 0; c < 320; c++) col(64 + c)[r] = lv[c];
-    col(S::MAIN_COLS - 2)[r] = 1;  // is_add ; is_double = 0
+    col(S::MAIN_COLS - 2)[r] = 1;  // is_add
+    col(S::MAIN_COLS - 1)[r] = 0;  // is_double
   });
   if (bad) return fail(SBN_ERR_WITNESS, "modular witness generation failed");
   if (!fill_split_range_check(trace, n, S::MAIN_COLS, S::START_RC, S::NUM_RC)) bad = 1;
@@ -575,7 +601,6 @@ extern "C" int sbn_generate_trace_fq12_exp(const uint32_t* ios, size_t num_io, u
   const size_t RPB = 512, n = RPB * num_io, IOW = 200;
   const int sf = sh.start_flags;
   auto col = [&](int c) { return trace + (size_t)c * n; };
-  memset(trace, 0, (size_t)sh.num_cols * n * sizeof(u64));
   for (size_t k = 0; k < num_io; k++)
     for (int c = 0; c < 24; c++) { u64 t[4]; from_u32(ios + IOW * k + 8 * c, t); if (geq_p(t)) return fail(SBN_ERR_BAD_ARG, "coefficient >= p (instance %zu)", k); }
   fill_flags(trace, n, sf, num_io, [&](size_t k) { return ios + IOW * k + 192; });
