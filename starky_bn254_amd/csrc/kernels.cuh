@@ -334,32 +334,52 @@ __global__ __launch_bounds__(256) void leaf_absorb_kernel(const u64* __restrict_
 
 // K3' fused Merkle levels: a workgroup owns 2*blockDim consecutive digests of level `l0` and hashes
 // up to `nlev` levels above them through LDS, writing every level to the tree (levels concatenated,
-// level l at word offset 4*(2*nleaf - (2*nleaf >> l))).  Two launches build a 2^17-leaf tree.
-__global__ __launch_bounds__(256) void merkle_subtree_kernel(u64* __restrict__ tree, size_t nleaf, u32 l0, u32 nlev) {
+// level l at word offset 4*(2*nleaf - (2*nleaf >> l))).  Two launches build a 2^17-leaf tree.  Levels with few
+// nodes per workgroup switch to 16 lanes per node (poseidon_permute_coop16): they are latency-bound.
+__global__ __launch_bounds__(256) void merkle_subtree_kernel(u64* __restrict__ tree, size_t nleaf, u32 l0, u32 nlev, u32 nchild) {
   __shared__ u64 buf[2 * 256 * 4];
-  const u32 tid = threadIdx.x, nt = blockDim.x;
+  const u32 tid = threadIdx.x, nt = blockDim.x;   // nchild = digests of level l0 owned by this workgroup (<= 512)
   const u64* child = tree + (2 * nleaf - ((2 * nleaf) >> l0)) * 4;
-  size_t base = (size_t)blockIdx.x * 2 * nt;  // first child digest of this workgroup
-  for (u32 e = tid; e < 2 * nt * 4; e += nt) buf[e] = child[base * 4 + e];
+  size_t base = (size_t)blockIdx.x * nchild;
+  for (u32 e = tid; e < nchild * 4; e += nt) buf[e] = child[base * 4 + e];
   __syncthreads();
-  u32 active = nt;
+  u32 active = nchild / 2;
+  const u32 groups = nt / 16, grp = tid / 16, lane = tid & 15;
   for (u32 lv = 1; lv <= nlev; lv++) {
-    F s[12];
-    if (tid < active) {
+    u64* out = tree + (2 * nleaf - ((2 * nleaf) >> (l0 + lv))) * 4;
+    const size_t idx0 = ((size_t)blockIdx.x * nchild) >> lv;
+    if (active > 4 * groups) {
+      // many nodes: one thread per parent
+      F s[12];
+      if (tid < active) {
 #pragma unroll
-      for (int k = 0; k < 8; k++) s[k] = F(buf[tid * 8 + k]);
+        for (int k = 0; k < 8; k++) s[k] = F(buf[tid * 8 + k]);
 #pragma unroll
-      for (int k = 8; k < 12; k++) s[k] = F(0);
-      poseidon_permute(s);
+        for (int k = 8; k < 12; k++) s[k] = F(0);
+        poseidon_permute(s);
+      }
+      __syncthreads();
+      if (tid < active) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) { buf[tid * 4 + k] = s[k].v; out[(idx0 + tid) * 4 + k] = s[k].v; }
+      }
+      __syncthreads();
+    } else {
+      // few nodes: 16 lanes per parent (latency-bound part of the tree)
+      u64 res[4];  // results of this lane's parents (written after all children have been read)
+      u32 nit = (active + groups - 1) / groups;
+      for (u32 it = 0; it < nit; it++) {
+        u32 parent = it * groups + grp;
+        u64 v = (parent < active && lane < 8) ? buf[parent * 8 + lane] : 0;
+        res[it] = poseidon_permute_coop16(v, lane);
+      }
+      __syncthreads();
+      for (u32 it = 0; it < nit; it++) {
+        u32 parent = it * groups + grp;
+        if (parent < active && lane < 4) { buf[parent * 4 + lane] = res[it]; out[(idx0 + parent) * 4 + lane] = res[it]; }
+      }
+      __syncthreads();
     }
-    __syncthreads();
-    if (tid < active) {
-      u64* out = tree + (2 * nleaf - ((2 * nleaf) >> (l0 + lv))) * 4;
-      size_t idx = ((size_t)blockIdx.x * 2 * nt >> lv) + tid;
-#pragma unroll
-      for (int k = 0; k < 4; k++) { buf[tid * 4 + k] = s[k].v; out[idx * 4 + k] = s[k].v; }
-    }
-    __syncthreads();
     active >>= 1;
   }
 }

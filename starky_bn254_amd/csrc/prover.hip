@@ -193,10 +193,10 @@ static int tree_build_inner(sbn_prover* P, DevTree& t, hipStream_t st) {
   u32 l0 = 0;
   while (l0 < t.nlevels) {
     size_t nodes = t.nleaf >> l0;
-    u32 nt = (u32)std::min<size_t>(256, nodes / 2);
-    u32 lg = 0; while ((1u << lg) < nt) lg++;
+    u32 nchild = (u32)std::min<size_t>(512, nodes);   // children per workgroup
+    u32 lg = 0; while ((2u << lg) < nchild) lg++;       // nchild = 2^(lg+1)
     u32 nlev = std::min(t.nlevels - l0, lg + 1);
-    hipLaunchKernelGGL(merkle_subtree_kernel, dim3((unsigned)(nodes / (2 * nt))), dim3(nt), 0, st, t.d, t.nleaf, l0, nlev);
+    hipLaunchKernelGGL(merkle_subtree_kernel, dim3((unsigned)(nodes / nchild)), dim3(256), 0, st, t.d, t.nleaf, l0, nlev, nchild);
     l0 += nlev;
   }
   HIPC(hipGetLastError());
