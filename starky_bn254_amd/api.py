@@ -25,6 +25,7 @@ EXPORTS = [
     "sbn_generate_trace_g1_exp", "sbn_generate_trace_g2_exp", "sbn_generate_trace_fq12_exp", "sbn_generate_trace_g1_op",
     "sbn_prover_create", "sbn_prover_destroy", "sbn_prover_load_trace", "sbn_prover_load_trace_device",
     "sbn_prover_prove", "sbn_prover_stage_times", "sbn_prover_stage_name", "sbn_prover_trace_device_ptr",
+    "sbn_prover_generate_trace", "sbn_prover_read_trace",
     "sbn_prove", "sbn_proof_num_words", "sbn_proof_words", "sbn_proof_serialize", "sbn_proof_degree_bits",
     "sbn_proof_free", "sbn_verify", "sbn_commit_values", "sbn_poseidon_permute_batch",
 ]
@@ -80,6 +81,8 @@ def lib():
         L.sbn_prover_stage_times.argtypes = [vp, C.POINTER(C.c_float), C.c_int]
         L.sbn_prover_trace_device_ptr.restype = vp
         L.sbn_prover_trace_device_ptr.argtypes = [vp]
+        L.sbn_prover_generate_trace.argtypes = [vp, vp, sz, vp]
+        L.sbn_prover_read_trace.argtypes = [vp, vp]
         L.sbn_prove.argtypes = [C.POINTER(_AirDesc), C.POINTER(_Config), vp, u32, vp, sz, C.POINTER(vp)]
         L.sbn_proof_num_words.restype = sz
         L.sbn_proof_num_words.argtypes = [vp]
@@ -255,7 +258,7 @@ class Prover:
     """Device context for one (table, degree_bits): buffers stay allocated across proofs."""
 
     def __init__(self, stark, config, degree_bits):
-        self.stark, self.config = stark, config
+        self.stark, self.config, self.degree_bits = stark, config, degree_bits
         self._h = C.c_void_p()
         _check(lib().sbn_prover_create(C.byref(stark._d), C.byref(config._c), degree_bits, C.byref(self._h)))
 
@@ -270,6 +273,18 @@ class Prover:
 
     def trace_device_ptr(self):
         return lib().sbn_prover_trace_device_ptr(self._h)
+
+    def generate_trace(self, ios):
+        """On-device G1ExpStark::generate_trace + generate_public_inputs; returns the public inputs."""
+        ios = np.ascontiguousarray(ios, dtype=np.uint32)
+        pi = np.zeros(self.stark.num_public_inputs, dtype=np.uint64)
+        _check(lib().sbn_prover_generate_trace(self._h, _ptr(ios), ios.shape[0], _ptr(pi)))
+        return pi
+
+    def read_trace(self):
+        trace = np.zeros((self.stark.num_columns, 1 << self.degree_bits), dtype=np.uint64)
+        _check(lib().sbn_prover_read_trace(self._h, _ptr(trace)))
+        return trace
 
     def prove(self):
         h = C.c_void_p()

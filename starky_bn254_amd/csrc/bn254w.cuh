@@ -185,4 +185,73 @@ GL_HD bool g1_output_row(bool is_double, const u64* ax, const u64* ay, const u64
   return cur == 320;
 }
 
+// ---- curve chains of one G1ExpStark instance ---------------------------------------------------------------------
+// Strided Fq access: limb i of entry idx lives at base[i * stride + idx].
+GL_HD Fq ldq(const u64* base, size_t idx, size_t stride) { Fq r; for (int i = 0; i < 4; i++) r.l[i] = base[i * stride + idx]; return r; }
+GL_HD void stq(u64* base, size_t idx, size_t stride, const Fq& v) { for (int i = 0; i < 4; i++) base[i * stride + idx] = v.l[i]; }
+GL_HD void u32x8_to_u64x4(const uint32_t* w, u64* out) { for (int i = 0; i < 4; i++) out[i] = (u64)w[2 * i] | ((u64)w[2 * i + 1] << 32); }
+enum { TG_ERR_DEGENERATE = 1, TG_ERR_WITNESS = 2, TG_ERR_RANGE = 4 };
+
+struct Jac { Fq X, Y, Z; };
+// dbl-2009-l for y^2 = x^3 + b: 2M + 5S.
+GL_HD Jac jac_double(const Jac& p) {
+  Fq A = mmul(p.X, p.X), B = mmul(p.Y, p.Y), C = mmul(B, B);
+  Fq t = fadd(p.X, B); t = mmul(t, t); t = fsub(fsub(t, A), C);
+  Fq D = fadd(t, t), E = fadd(fadd(A, A), A), F = mmul(E, E);
+  Jac r;
+  r.X = fsub(F, fadd(D, D));
+  Fq C8 = fadd(C, C); C8 = fadd(C8, C8); C8 = fadd(C8, C8);
+  r.Y = fsub(mmul(E, fsub(D, r.X)), C8);
+  Fq yz = mmul(p.Y, p.Z);
+  r.Z = fadd(yz, yz);
+  return r;
+}
+// add-2007-bl (both Jacobian): 11M + 5S.  *degenerate is set when the x coordinates agree (H = 0).
+GL_HD Jac jac_add(const Jac& p, const Jac& q, bool* degenerate) {
+  Fq Z1Z1 = mmul(p.Z, p.Z), Z2Z2 = mmul(q.Z, q.Z);
+  Fq U1 = mmul(p.X, Z2Z2), U2 = mmul(q.X, Z1Z1);
+  Fq S1 = mmul(mmul(p.Y, q.Z), Z2Z2), S2 = mmul(mmul(q.Y, p.Z), Z1Z1);
+  Fq H = fsub(U2, U1);
+  *degenerate = fzero(H);
+  Fq I = fadd(H, H); I = mmul(I, I);
+  Fq J = mmul(H, I);
+  Fq r = fsub(S2, S1); r = fadd(r, r);
+  Fq V = mmul(U1, I);
+  Jac o;
+  o.X = fsub(fsub(mmul(r, r), J), fadd(V, V));
+  Fq sj = mmul(S1, J);
+  o.Y = fsub(mmul(r, fsub(V, o.X)), fadd(sj, sj));
+  Fq zz = fadd(p.Z, q.Z); zz = mmul(zz, zz); zz = fsub(fsub(zz, Z1Z1), Z2Z2);
+  o.Z = mmul(zz, H);
+  return o;
+}
+
+
+// Jacobian chain storage, instance-major (one host thread or one lane writes a contiguous 24 KB run):
+// entry (t, c) of instance k, t = 0..256, c = X,Y,Z -> 4 consecutive words at base + jac_at(k, t, c)
+GL_HD size_t jac_at(size_t k, int t, int c) { return (k * 257 + (size_t)t) * 12 + (size_t)c * 4; }
+// io: x.x x.y offset.x offset.y exp_val (8 u32 each).  A[t] = 2^t x (t = 0..256), B[0] = offset,
+// B[t+1] = bit_t ? B[t] + A[t] : B[t]   (g1/exp.rs:165-230: even rows add-if-bit, odd rows double), all in Jacobian
+// coordinates and Montgomery form, so no step needs an inversion.  Returns TG_ERR_* flags.
+GL_HD int g1_chains(const uint32_t* io, size_t k, u64* ja, u64* jb) {
+  u64 t4[4];
+  Jac a, b;
+  u32x8_to_u64x4(io, t4); a.X = to_m(t4);
+  u32x8_to_u64x4(io + 8, t4); a.Y = to_m(t4);
+  u32x8_to_u64x4(io + 16, t4); b.X = to_m(t4);
+  u32x8_to_u64x4(io + 24, t4); b.Y = to_m(t4);
+  a.Z = fq_one(); b.Z = fq_one();
+  int bad = 0;
+  for (int t = 0;; t++) {
+    stq(ja + jac_at(k, t, 0), 0, 1, a.X); stq(ja + jac_at(k, t, 1), 0, 1, a.Y); stq(ja + jac_at(k, t, 2), 0, 1, a.Z);
+    stq(jb + jac_at(k, t, 0), 0, 1, b.X); stq(jb + jac_at(k, t, 1), 0, 1, b.Y); stq(jb + jac_at(k, t, 2), 0, 1, b.Z);
+    if (t == 256) break;
+    const bool bit = (io[32 + (t >> 5)] >> (t & 31)) & 1;
+    if (bit) { bool deg; b = jac_add(b, a, &deg); if (deg) bad |= TG_ERR_DEGENERATE; }
+    if (fzero(a.Y)) bad |= TG_ERR_DEGENERATE;
+    a = jac_double(a);
+  }
+  return bad;
+}
+
 }  // namespace bnw

@@ -84,6 +84,9 @@ static inline bool config_supported(const sbn_config* c) {
          c->proof_of_work_bits <= 32;
 }
 
+// tracegen.hip: Jacobian curve chains of every G1ExpStark instance on host threads (layout: bn254w.cuh g1_chains)
+int tracegen_host_chains(const uint32_t* ios, size_t K, u64* ja, u64* jb);
+
 }  // namespace sbn
 
 struct sbn_proof {

@@ -1,0 +1,331 @@
+// Device witness generation for G1ExpStark: replaces G1ExpStark::generate_trace / generate_public_inputs
+// (src/curves/g1/exp.rs:255-327) with kernels that fill the column-major trace directly in HBM, so the 0.9 GB
+// trace never crosses PCIe.  The host generator (tracegen.hip) is the bit-exact counterpart; both share bn254w.cuh.
+//
+// The reference's per-instance loop is sequential in two ways: a = 2^t x is a chain of doublings and
+// b += a is a chain of additions, and every affine step needs a field inversion.  Here
+//   * both chains of an instance are walked in Jacobian coordinates (no inversion): bn254w.cuh g1_chains, run on host
+//     threads by default (512 strictly sequential point operations per instance are 0.1% of the arithmetic and
+//     latency-bound on a lane) or by chain_kernel, one lane per instance;
+//   * affine_kernel / lambda_kernel then invert all Z's and all slope denominators at once, one lane per value
+//     (Fermat, a^(p-2)): the inversions of different rows are independent once the chain is known;
+//   * row_witness_kernel computes limb columns and the three modular-gadget witnesses of a row (one lane per row);
+//   * flags / pulse columns are closed forms of the row index;
+//   * range_check_kernel: one workgroup per range-checked column, histogram and prefix counts in LDS, and the
+//     reference's sorted-merge with its LIFO pool of unused table values (src/utils/lookup.rs:60-111) restated as
+//     independent searches over the prefix counts.
+#pragma once
+#include "bn254w.cuh"
+
+namespace tg {
+using namespace bnw;
+
+
+// a^(p-2) with 4-bit fixed windows (252 squarings + <= 64 + 14 products).
+__device__ __noinline__ Fq finv_fermat(const Fq& a) {
+  constexpr u64 PL[4] = BNW_PL;
+  const u64 e[4] = {PL[0] - 2, PL[1], PL[2], PL[3]};
+  Fq tab[16];
+  tab[0] = fq_one(); tab[1] = a;
+  for (int i = 2; i < 16; i++) tab[i] = mmul(tab[i - 1], a);
+  Fq r = tab[(e[3] >> 60) & 15];
+  for (int w = 62; w >= 0; w--) {
+    r = mmul(r, r); r = mmul(r, r); r = mmul(r, r); r = mmul(r, r);
+    const unsigned nib = (unsigned)(e[w >> 4] >> (4 * (w & 15))) & 15;
+    if (nib) r = mmul(r, tab[nib]);
+  }
+  return r;
+}
+
+
+// affine storage: (t, c) with c = x,y
+__device__ __forceinline__ size_t aff_off(int t, int c, size_t K) { return ((size_t)(t * 2 + c) * 4) * K; }
+
+// One lane per instance: g1_chains (bn254w.cuh).  512 strictly sequential point operations per lane: the host
+// threads do this faster (prover.hip picks), the kernel keeps the path host-free when asked (SBN_TRACEGEN_DEVICE_CHAIN=1).
+__global__ void chain_kernel(const uint32_t* __restrict__ ios, size_t K, u64* __restrict__ ja, u64* __restrict__ jb, int* __restrict__ err) {
+  const size_t k = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (k >= K) return;
+  const int bad = g1_chains(ios + 40 * k, k, ja, jb);
+  if (bad) atomicOr(err, bad);
+}
+
+// One lane per (which, t, k): affine x = X / Z^2, y = Y / Z^3 (Montgomery form) for t = 0..256 of both chains.
+__global__ void affine_kernel(const u64* __restrict__ ja, const u64* __restrict__ jb, size_t K, u64* __restrict__ aa, u64* __restrict__ ab, int* __restrict__ err) {
+  const size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  const size_t per = 257 * K;
+  if (g >= 2 * per) return;
+  const bool second = g >= per;
+  const size_t h = second ? g - per : g;
+  const int t = (int)(h / K); const size_t k = h % K;
+  const u64* j = second ? jb : ja; u64* o = second ? ab : aa;
+  Fq X = ldq(j + jac_at(k, t, 0), 0, 1), Y = ldq(j + jac_at(k, t, 1), 0, 1), Z = ldq(j + jac_at(k, t, 2), 0, 1);
+  if (fzero(Z)) { atomicOr(err, TG_ERR_DEGENERATE); return; }
+  Fq zi = finv_fermat(Z), zi2 = mmul(zi, zi);
+  stq(o + aff_off(t, 0, K), k, K, mmul(X, zi2));
+  stq(o + aff_off(t, 1, K), k, K, mmul(Y, mmul(zi2, zi)));
+}
+
+// One lane per row: the standard-form values ax ay bx by lam nx ny of the row (sv[(v*4 + limb) * n + row]) and its
+// operation (0 none, 1 add, 2 double).  Row r of instance k: a = A[r>>1]; even rows: b = B[r>>1], add if bit;
+// odd rows: b = B[(r>>1)+1], double.  Also writes the instance output B[256] (u32 limbs) for the public inputs.
+__global__ void lambda_kernel(const uint32_t* __restrict__ ios, size_t K, const u64* __restrict__ aa, const u64* __restrict__ ab, size_t n,
+                              u64* __restrict__ sv, unsigned char* __restrict__ row_op, u64* __restrict__ pi_out, int* __restrict__ err) {
+  const size_t row = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (row >= n) return;
+  const size_t k = row >> 9; const int r = (int)(row & 511), t = r >> 1; const bool dbl = r & 1;
+  const bool bit = (ios[40 * k + 32 + (t >> 5)] >> (t & 31)) & 1;
+  const int op = dbl ? 2 : (bit ? 1 : 0);
+  const int tb = dbl ? t + 1 : t;
+  Fq v[7];
+  v[0] = ldq(aa + aff_off(t, 0, K), k, K); v[1] = ldq(aa + aff_off(t, 1, K), k, K);
+  v[2] = ldq(ab + aff_off(tb, 0, K), k, K); v[3] = ldq(ab + aff_off(tb, 1, K), k, K);
+  if (op) {
+    Fq den, num;
+    if (dbl) { den = fadd(v[1], v[1]); Fq x2 = mmul(v[0], v[0]); num = fadd(fadd(x2, x2), x2); }
+    else { den = fsub(v[2], v[0]); num = fsub(v[3], v[1]); }
+    if (fzero(den)) atomicOr(err, TG_ERR_DEGENERATE);
+    v[4] = mmul(num, finv_fermat(den));
+    const u64* nsrc = dbl ? aa : ab;
+    v[5] = ldq(nsrc + aff_off(t + 1, 0, K), k, K); v[6] = ldq(nsrc + aff_off(t + 1, 1, K), k, K);
+  }
+  for (int q = 0; q < (op ? 7 : 4); q++) {
+    u64 s[4]; from_m(v[q], s);
+    for (int i = 0; i < 4; i++) sv[(size_t)(q * 4 + i) * n + row] = s[i];
+  }
+  row_op[row] = (unsigned char)op;
+  if (r == 511) {  // b at the last row is the output (g1/exp.rs:124-135)
+    for (int c = 0; c < 2; c++) {
+      u64 s[4]; from_m(v[2 + c], s);
+      for (int i = 0; i < 8; i++) pi_out[16 * k + 8 * c + i] = (s[i >> 1] >> (32 * (i & 1))) & 0xffffffffULL;
+    }
+  }
+}
+
+// One lane per row: limb columns of a and b (columns 0..63) and the 320 G1Output columns at gadget_col.
+__global__ void __launch_bounds__(128) row_witness_kernel(const u64* __restrict__ sv, const unsigned char* __restrict__ row_op, size_t n, int gadget_col,
+                                                          u64* __restrict__ trace, int* __restrict__ err) {
+  const size_t row = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (row >= n) return;
+  u64 s[7][4];
+  const int op = row_op[row];
+  for (int q = 0; q < (op ? 7 : 4); q++) for (int i = 0; i < 4; i++) s[q][i] = sv[(size_t)(q * 4 + i) * n + row];
+  for (int q = 0; q < 4; q++)
+    for (int i = 0; i < 16; i++) trace[(size_t)(16 * q + i) * n + row] = (s[q][i >> 2] >> (16 * (i & 3))) & 0xffff;
+  u64* g = trace + (size_t)gadget_col * n + row;
+  if (op) {
+    u64 lv[320];
+    if (!g1_output_row(op == 2, s[0], s[1], s[2], s[3], s[4], s[5], s[6], lv)) { atomicOr(err, TG_ERR_WITNESS); return; }
+    for (int c = 0; c < 320; c++) g[(size_t)c * n] = lv[c];
+  } else {  // G1Output::default: zeros, quotient signs = 1
+    for (int c = 0; c < 317; c++) g[(size_t)c * n] = 0;
+    for (int c = 317; c < 320; c++) g[(size_t)c * n] = 1;
+  }
+}
+
+// flags columns (flags.rs:46-134) in closed form: within the 64-row block q of an instance the u32 limb e[q] is
+// consumed one bit per two rows; the limb window rotates after row 62 of the block.
+__global__ void flags_kernel(const uint32_t* __restrict__ ios, size_t n, int sf, u64* __restrict__ trace) {
+  const size_t row = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (row >= n) return;
+  const size_t k = row >> 9; const int r = (int)(row & 511), q = r >> 6, s = r & 63, t = s >> 1;
+  const uint32_t* e = ios + 40 * k + 32;
+  auto limb = [&](int i) -> u64 { return i < 8 ? (u64)e[i] : 0; };
+  const u64 a = r & 1, b = 1 - a, bit = (limb(q) >> t) & 1;
+  auto col = [&](int c) -> u64& { return trace[(size_t)(sf + c) * n + row]; };
+  col(0) = r == 511; col(1) = s == 62; col(2) = a; col(3) = b; col(4) = bit * b; col(5) = bit;
+  const int sh = s == 63 ? 1 : 0;
+  col(6) = s == 63 ? limb(q + 1) : (limb(q) >> (t + 1));
+  for (int i = 1; i < 8; i++) col(6 + i) = limb(q + i + sh);
+}
+
+// inv[i] = 1/i in Goldilocks for i = 1..n-1 (inv[0] = 0).
+__global__ void small_inverse_kernel(u64* __restrict__ inv, size_t n) {
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  inv[i] = i == 0 ? 0 : f_inv(F(i)).v;
+}
+
+// periodic pulse (pulse.rs:100-144) + io-pulse counter, and the lookup table column (range_check.rs:20-47).
+__global__ void periodic_kernel(const u64* __restrict__ inv, size_t n, int start_periodic, int start_io_pulses, int start_lookups, u64* __restrict__ trace) {
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u64 c = (i + 1) & 63;
+  trace[(size_t)start_periodic * n + i] = c;
+  trace[(size_t)(start_periodic + 1) * n + i] = c == 63 ? 0 : (-F(inv[63 - c])).v;
+  trace[(size_t)start_io_pulses * n + i] = i;
+  trace[(size_t)start_lookups * n + i] = i < 65536 ? i : 65535;
+}
+// io pulses (pulse.rs:20-43): pulse q sits at row pos(q) = 512*(q/2) + (q odd ? 511 : 0); witness = 1/(i - pos).
+__global__ void io_pulse_kernel(const u64* __restrict__ inv, size_t n, int first_col, u64* __restrict__ trace) {
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int q = blockIdx.y;
+  const size_t pos = (size_t)(q >> 1) * 512 + ((q & 1) ? 511 : 0);
+  u64* w = trace + (size_t)(first_col + 2 * q) * n;  // witness_col(q); pulse_col(q) = witness_col(q) + 1
+  w[i] = i > pos ? inv[i - pos] : (i < pos ? (-F(inv[pos - i])).v : 0);
+  w[n + i] = i == pos;
+}
+
+// ---- u16 range check (range_check.rs:20-47, lookup.rs:60-111), n == 65536 ------------------------------------------
+// One workgroup per range-checked column; everything after the histogram stays in LDS.
+//
+// The reference merges the sorted column against the table 0..65535 (lookup.rs:60-111): a table value missing from
+// the column goes on a LIFO pool; the first occurrence of a present value takes its own table entry; every further
+// occurrence pops the pool or, when the pool is empty, is deferred; deferred slots finally take the remaining pool
+// bottom-up (the repeats of 65535 are always deferred: the loop has run off the table by then).  Replaying that
+// serially costs a lane ~400 cycles per value, so it is restated as independent searches:
+//   c[v] = multiplicity, T[v] = #entries <= v (LDS, u16; 65536 is implied for v >= max value),
+//   S[v] = v + 1 - T[v]  = (#pushes - #pops) after value v, unclamped, for v <= 65534,
+//   a pushed value u is popped by the first x > u with S[x] < S[u], into sorted slot x - S[u] + 1;
+//   if there is no such x it is still pooled at the end, at height h = S[u] - min(0, min S), and fills the deferred
+//   slot of rank h-1, which is slot v + h where v is the first value with S[v] < -(h-1) (or a repeat of 65535).
+// Every lane owns 64 consecutive values; "first x >= from with S[x] < target" walks a two-level min tree (32 / 1024).
+static constexpr int RC_THREADS = 1024;
+static constexpr int RC_HEAVY_MAX = 1024;  // values with more than 64 occurrences are expanded by the whole block
+static constexpr size_t RC_LDS_BYTES = 65536 * 2 + 2 * 2048 * 4 + 64 * 4 + 64 * 4 + RC_HEAVY_MAX * 8;
+
+__global__ void __launch_bounds__(RC_THREADS) range_check_kernel(u64* __restrict__ trace, size_t n, int first_col, int start_lookups, int* __restrict__ err) {
+  extern __shared__ unsigned int lds[];
+  unsigned int* t32 = lds;                                                  // 32768 words = 65536 u16 counters, then T
+  const unsigned short* t16 = reinterpret_cast<const unsigned short*>(lds);
+  int* L1 = reinterpret_cast<int*>(lds + 32768);                            // min S over 32 values
+  int* SM1 = L1 + 2048;                                                     // suffix minima of L1
+  int* L2 = SM1 + 2048;                                                     // min over 32 L1 entries
+  unsigned int* misc = reinterpret_cast<unsigned int*>(L2 + 64);            // [0..15] wave sums, [32] differs, [33] vmax, [34] heavy count
+  uint2* heavy = reinterpret_cast<uint2*>(misc + 64);                       // (value, start) of values with > 64 occurrences
+  const int tid = threadIdx.x, kcol = blockIdx.x;
+  const u64* col = trace + (size_t)(first_col + kcol) * n;
+  u64* sorted_out = trace + (size_t)(start_lookups + 1 + 2 * kcol) * n;
+  u64* perm_out = sorted_out + n;
+  constexpr int INF = 0x3fffffff;
+
+  for (int i = tid; i < 32768; i += RC_THREADS) t32[i] = 0;
+  if (tid < 64) misc[tid] = 0;
+  __syncthreads();
+  const u64 v0 = col[0];
+  bool differs = false, bad = false; unsigned vm = 0;
+  for (size_t i = tid; i < n; i += RC_THREADS) {
+    const u64 v = col[i];
+    if (v >= 65536) { bad = true; continue; }
+    differs |= v != v0; vm = vm > (unsigned)v ? vm : (unsigned)v;
+    atomicAdd(&t32[v >> 1], 1u << (16 * (v & 1)));
+  }
+  if (bad) atomicOr(err, TG_ERR_RANGE);
+  if (differs) misc[32] = 1;
+  atomicMax(&misc[33], vm);
+  __syncthreads();
+  // a constant column wrapped its single u16 counter (65536 occurrences): clear it, T is implied by vmax alone
+  if (misc[32] == 0 && tid == 0) t32[v0 >> 1] = 0;
+  __syncthreads();
+  const int vmax = (int)misc[33];
+
+  // counts -> inclusive prefix counts T (mod 2^16), in place
+  {
+    uint4* p = reinterpret_cast<uint4*>(t32 + 32 * tid);
+    unsigned cw[32];
+    for (int j = 0; j < 8; j++) { uint4 q = p[j]; cw[4 * j] = q.x; cw[4 * j + 1] = q.y; cw[4 * j + 2] = q.z; cw[4 * j + 3] = q.w; }
+    unsigned tot = 0;
+    for (int j = 0; j < 32; j++) tot += (cw[j] & 0xffff) + (cw[j] >> 16);
+    unsigned incl = tot;
+    for (int o = 1; o < 64; o <<= 1) { unsigned t = __shfl_up(incl, o, 64); if ((tid & 63) >= o) incl += t; }
+    if ((tid & 63) == 63) misc[tid >> 6] = incl;
+    __syncthreads();
+    unsigned run = incl - tot;
+    for (int w = 0; w < (tid >> 6); w++) run += misc[w];
+    for (int j = 0; j < 32; j++) { unsigned lo = run + (cw[j] & 0xffff), hi = lo + (cw[j] >> 16); run = hi; cw[j] = (lo & 0xffff) | (hi << 16); }
+    for (int j = 0; j < 8; j++) p[j] = make_uint4(cw[4 * j], cw[4 * j + 1], cw[4 * j + 2], cw[4 * j + 3]);
+  }
+  __syncthreads();
+  auto T = [&](int v) -> int { return v < 0 ? 0 : (v >= vmax ? 65536 : (int)t16[v]); };
+  auto S = [&](int v) -> int { return v >= 65535 ? INF : v + 1 - T(v); };
+  for (int b = 0; b < 2; b++) {
+    int m = INF;
+    for (int j = 0; j < 32; j++) { int s = S(tid * 64 + b * 32 + j); m = s < m ? s : m; }
+    L1[2 * tid + b] = m;
+  }
+  __syncthreads();
+  if (tid < 64) { int m = INF; for (int j = 0; j < 32; j++) { int s = L1[tid * 32 + j]; m = s < m ? s : m; } L2[tid] = m; }
+  __syncthreads();
+  int mfin = 0;
+  for (int j = 0; j < 64; j++) { int s = L2[j]; mfin = s < mfin ? s : mfin; }
+
+  // suffix minima of L1: SM1[b] = min L1[b..2047] (lets a push that is never popped stop after its own 32-block)
+  if (tid < 64) {
+    int m = INF;
+    for (int g = tid + 1; g < 64; g++) { int s = L2[g]; m = s < m ? s : m; }
+    for (int j = 31; j >= 0; j--) { int s = L1[tid * 32 + j]; m = s < m ? s : m; SM1[tid * 32 + j] = m; }
+  }
+  __syncthreads();
+
+  // first x in [from, from | 31] with S(x) < target, or -1 (8 prefix counts per LDS read)
+  auto scan32 = [&](int from, int target) -> int {
+    const int hi = from | 31;
+    for (int a = from & ~7; a <= hi; a += 8) {
+      const uint4 q = *reinterpret_cast<const uint4*>(t16 + a);
+      const unsigned w[4] = {q.x, q.y, q.z, q.w};
+      for (int e = 0; e < 8; e++) {
+        const int x = a + e;
+        const int tv = x >= vmax ? 65536 : (int)((w[e >> 1] >> (16 * (e & 1))) & 0xffff);
+        const int sx = x >= 65535 ? INF : x + 1 - tv;
+        if (x >= from && sx < target) return x;
+      }
+    }
+    return -1;
+  };
+  // first index in [from, hi] with arr[index] < target, or -1 (arr 16-byte aligned, hi + 1 a multiple of 4)
+  auto scan_min = [&](const int* arr, int from, int hi, int target) -> int {
+    for (int a = from & ~3; a <= hi; a += 4) {
+      const int4 q = *reinterpret_cast<const int4*>(arr + a);
+      if (a >= from && q.x < target) return a;
+      if (a + 1 >= from && q.y < target) return a + 1;
+      if (a + 2 >= from && q.z < target) return a + 2;
+      if (a + 3 >= from && q.w < target) return a + 3;
+    }
+    return -1;
+  };
+  // first x in [from, 65534] with S(x) < target, or -1
+  auto firstbelow = [&](int from, int target) -> int {
+    if (from > 65534) return -1;
+    const int x = scan32(from, target);
+    if (x >= 0) return x;
+    const int b = (from >> 5) + 1;
+    if (b >= 2048 || SM1[b] >= target) return -1;
+    int fb = scan_min(L1, b, b | 31, target);
+    if (fb < 0) { const int fg = scan_min(L2, (b >> 5) + 1, 63, target); fb = scan_min(L1, fg * 32, fg * 32 + 31, target); }
+    return scan32(fb * 32, target);
+  };
+  const int t_last = T(65534);  // = start of the 65535 run
+  auto assign_deferred = [&](int rank, int val) {
+    int slot;
+    if (rank < -mfin) { const int v = firstbelow(0, -rank); slot = v + rank + 1; }
+    else slot = t_last + 1 + (rank + mfin);
+    perm_out[slot] = (u64)val;
+  };
+
+  int tprev = T(tid * 64 - 1);
+  for (int j = 0; j < 64; j++) {
+    const int v = tid * 64 + j, tv = T(v), c = tv - tprev;
+    if (c > 0) {
+      perm_out[tprev] = (u64)v;  // first occurrence takes its own table entry
+      if (c <= 64) { for (int d = 0; d < c; d++) sorted_out[tprev + d] = (u64)v; }
+      else { const unsigned h = atomicAdd(&misc[34], 1u); heavy[h] = make_uint2((unsigned)v, (unsigned)tprev); }
+    } else if (v < 65535) {
+      const int s = v + 1 - tv;
+      const int x = firstbelow(v + 1, s);
+      if (x >= 0) perm_out[x - s + 1] = (u64)v;
+      else assign_deferred(s - mfin - 1, v);
+    } else {
+      assign_deferred(S(65534) + 1 - mfin - 1, 65535);
+    }
+    tprev = tv;
+  }
+  __syncthreads();
+  const unsigned nheavy = misc[34];
+  for (unsigned h = 0; h < nheavy; h++) {
+    const int v = (int)heavy[h].x, st = (int)heavy[h].y, c = T(v) - st;
+    for (int d = tid; d < c; d += RC_THREADS) sorted_out[st + d] = (u64)v;
+  }
+}
+
+}  // namespace tg

@@ -4,6 +4,7 @@
 // stage runs in the kernels of kernels.cuh on one HIP stream.
 #include "host_common.hpp"
 #include "kernels.cuh"
+#include "kernels_tracegen.cuh"
 #include <algorithm>
 #include <cstring>
 #include <cstdlib>
@@ -29,11 +30,11 @@ enum Stage {
   ST_TRACE_COMMIT, ST_PERM_Z, ST_Z_COMMIT, ST_QUOTIENT_EVAL, ST_QUOTIENT_COMMIT,
   ST_OPENINGS, ST_FRI_COMBINE, ST_FRI_LAYERS, ST_POW, ST_QUERIES, ST_COUNT
 };
-enum Extra { EX_TRACE_ABSORB_MS, EX_TRACE_ABSORB_LAUNCHES, EX_Z_ABSORB_MS, EX_Z_ABSORB_LAUNCHES, EX_COUNT };
+enum Extra { EX_TRACE_ABSORB_MS, EX_TRACE_ABSORB_LAUNCHES, EX_Z_ABSORB_MS, EX_Z_ABSORB_LAUNCHES, EX_TRACEGEN_MS, EX_COUNT };
 static const char* STAGE_NAMES[ST_COUNT + EX_COUNT] = {
   "trace_commit", "perm_z", "z_commit", "quotient_eval", "quotient_commit",
   "openings", "fri_combine", "fri_layers", "pow", "queries",
-  "trace_absorb_kernels_ms", "trace_absorb_launches", "z_absorb_kernels_ms", "z_absorb_launches"};
+  "trace_absorb_kernels_ms", "trace_absorb_launches", "z_absorb_kernels_ms", "z_absorb_launches", "device_tracegen_ms"};
 static constexpr int MAX_CHUNKS = 256;
 
 struct DevTree {  // Merkle digests, levels concatenated (leaf level first)
@@ -81,6 +82,7 @@ struct sbn_prover {
   hipEvent_t abs_ev[2 * MAX_CHUNKS];         // hash stream: before/after each absorb launch
   hipEvent_t hash_done;                      // hash -> main
   u64* d_sponge = nullptr;                   // [12][m] sponge state carried between column chunks
+  u64* h_chain = nullptr;                    // pinned staging for the host-computed curve chains (device tracegen)
 };
 
 static int dmalloc(u64** p, size_t words) {
@@ -363,6 +365,7 @@ extern "C" void sbn_prover_destroy(sbn_prover* P) {
   for (auto& e : P->chunk_ready) (void)hipEventDestroy(e);
   (void)hipEventDestroy(P->hash_done);
   if (P->d_sponge) (void)hipFree(P->d_sponge);
+  if (P->h_chain) (void)hipHostFree(P->h_chain);
   (void)hipStreamDestroy(P->hstream);
   (void)hipStreamDestroy(P->stream);
   delete P;
@@ -403,6 +406,110 @@ extern "C" int sbn_prover_load_trace_device(sbn_prover* P, const uint64_t* d_tra
   HIPC(hipSetDevice(P->device));
   if (d_trace != P->d_trace) HIPC(hipMemcpy(P->d_trace, d_trace, P->air.ncols * P->n * sizeof(u64), hipMemcpyDeviceToDevice));
   P->loaded = true;
+  return SBN_OK;
+}
+// ---- on-device witness generation (kernels_tracegen.cuh) ----------------------------------------------------------
+// Scratch lives in the (not yet used) LDE buffer; the only host traffic is the instance list in (20 KB) and the
+// instance outputs + error word back (8 KB).
+extern "C" int sbn_prover_generate_trace(sbn_prover* P, const uint32_t* ios, size_t num_io, uint64_t* pi_out) {
+  if (!P || !ios) return fail(SBN_ERR_BAD_ARG, "null argument");
+  if (P->air.kind != SBN_AIR_G1_EXP) return fail(SBN_ERR_UNSUPPORTED, "device witness generation covers G1ExpStark only (use sbn_generate_trace_* + sbn_prover_load_trace)");
+  if (num_io != P->air.num_io) return fail(SBN_ERR_BAD_ARG, "prover was created for %u instances, got %zu", P->air.num_io, num_io);
+  const size_t n = P->n, K = num_io;
+  if (n != 512 * K) return fail(SBN_ERR_BAD_ARG, "degree_bits does not match 512 rows per instance");
+  if (n != 65536) return fail(SBN_ERR_UNSUPPORTED, "device witness generation needs exactly 2^16 rows (u16 histogram in LDS)");
+  for (size_t k = 0; k < K; k++)
+    for (int v = 0; v < 4; v++) {
+      u64 t[4]; for (int i = 0; i < 4; i++) t[i] = (u64)ios[40 * k + 8 * v + 2 * i] | ((u64)ios[40 * k + 8 * v + 2 * i + 1] << 32);
+      if (bnw::geq_p(t)) return fail(SBN_ERR_BAD_ARG, "coordinate >= p (instance %zu)", k);
+    }
+  HIPC(hipSetDevice(P->device));
+  hipStream_t st = P->stream;
+  const ExpShape sh = exp_shape(P->air);
+  P->loaded = false;
+  // carve the scratch
+  u64* w = P->d_lde;
+  auto take = [&](size_t words) { u64* r = w; w += (words + 7) & ~(size_t)7; return r; };
+  u64* ja = take(257 * 12 * K); u64* jb = take(257 * 12 * K);
+  u64* aa = take(257 * 8 * K);  u64* ab = take(257 * 8 * K);
+  u64* sv = take(28 * n);       u64* inv = take(n);
+  u64* d_out = take(16 * K);
+  unsigned char* row_op = (unsigned char*)take(n / 8 + 1);
+  uint32_t* d_ios = (uint32_t*)take(20 * K);
+  int* d_err = (int*)take(1);
+  if ((size_t)(w - P->d_lde) > P->air.ncols * P->m) return fail(SBN_ERR_UNSUPPORTED, "scratch does not fit");
+  static bool attr_done = false;
+  if (!attr_done) { HIPC(hipFuncSetAttribute((const void*)tg::range_check_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tg::RC_LDS_BYTES)); attr_done = true; }
+
+  const bool timing = getenv("SBN_TRACE_TIMING") != nullptr;
+  hipEvent_t e0 = P->abs_ev[0], e1 = P->abs_ev[1];
+  std::vector<hipEvent_t> kev;
+  auto mark = [&]() { if (timing) { hipEvent_t e; hipEventCreate(&e); hipEventRecord(e, st); kev.push_back(e); } };
+  HIPC(hipEventRecord(e0, st));
+  HIPC(hipMemcpyAsync(d_ios, ios, 40 * K * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+  HIPC(hipMemsetAsync(d_err, 0, sizeof(int), st));
+  auto blocks = [](size_t k, unsigned b) { return dim3((unsigned)((k + b - 1) / b)); };
+  mark();
+  hipLaunchKernelGGL(tg::flags_kernel, blocks(n, 256), dim3(256), 0, st, d_ios, n, sh.start_flags, P->d_trace);
+  hipLaunchKernelGGL(tg::small_inverse_kernel, blocks(n, 256), dim3(256), 0, st, inv, n);
+  hipLaunchKernelGGL(tg::periodic_kernel, blocks(n, 256), dim3(256), 0, st, inv, n, sh.start_periodic, sh.start_io_pulses, sh.start_lookups, P->d_trace);
+  hipLaunchKernelGGL(tg::io_pulse_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)(2 * K)), dim3(256), 0, st, inv, n, sh.witness_col(0), P->d_trace);
+  mark();
+  // the two 256-step curve chains per instance: host threads while the device writes the input-independent columns
+  int host_err = 0;
+  if (getenv("SBN_TRACEGEN_DEVICE_CHAIN")) hipLaunchKernelGGL(tg::chain_kernel, blocks(K, 64), dim3(64), 0, st, d_ios, K, ja, jb, d_err);
+  else {
+    const size_t cw = 257 * 12 * K;
+    if (!P->h_chain) HIPC(hipHostMalloc((void**)&P->h_chain, 2 * cw * sizeof(u64), hipHostMallocDefault));
+    host_err = tracegen_host_chains(ios, K, P->h_chain, P->h_chain + cw);
+    if (host_err) return fail(SBN_ERR_WITNESS, "degenerate affine operation (x1 == x2 or y == 0)");
+    HIPC(hipMemcpyAsync(ja, P->h_chain, cw * sizeof(u64), hipMemcpyHostToDevice, st));
+    HIPC(hipMemcpyAsync(jb, P->h_chain + cw, cw * sizeof(u64), hipMemcpyHostToDevice, st));
+  }
+  mark();
+  hipLaunchKernelGGL(tg::affine_kernel, blocks(2 * 257 * K, 64), dim3(64), 0, st, ja, jb, K, aa, ab, d_err);
+  mark();
+  hipLaunchKernelGGL(tg::lambda_kernel, blocks(n, 64), dim3(64), 0, st, d_ios, K, aa, ab, n, sv, row_op, d_out, d_err);
+  mark();
+  hipLaunchKernelGGL(tg::row_witness_kernel, blocks(n, 128), dim3(128), 0, st, sv, row_op, n, sh.gadget_col, P->d_trace, d_err);
+  mark();
+  hipLaunchKernelGGL(tg::range_check_kernel, dim3((unsigned)sh.num_rc), dim3(tg::RC_THREADS), tg::RC_LDS_BYTES, st, P->d_trace, n, sh.rc_start, sh.start_lookups, d_err);
+  mark();
+  HIPC(hipGetLastError());
+  std::vector<u64> out(16 * K); int err = 0;
+  HIPC(hipMemcpyAsync(out.data(), d_out, 16 * K * sizeof(u64), hipMemcpyDeviceToHost, st));
+  HIPC(hipMemcpyAsync(&err, d_err, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPC(hipEventRecord(e1, st));
+  HIPC(hipStreamSynchronize(st));
+  float ms = 0; HIPC(hipEventElapsedTime(&ms, e0, e1));
+  P->stage_ms[ST_COUNT + EX_TRACEGEN_MS] = ms;
+  if (timing) {
+    static const char* names[] = {"flags+pulses", "chains", "affine", "lambda", "row_witness", "range_check"};
+    for (size_t i = 0; i + 1 < kev.size(); i++) { float t = 0; hipEventElapsedTime(&t, kev[i], kev[i + 1]); fprintf(stderr, "[device tracegen] %-14s %8.3f ms\n", names[i], t); }
+    for (auto e : kev) hipEventDestroy(e);
+    fprintf(stderr, "[device tracegen] %-14s %8.3f ms\n", "total", ms);
+  }
+  P->loaded = false;
+  if (err & tg::TG_ERR_DEGENERATE) return fail(SBN_ERR_WITNESS, "degenerate affine operation (x1 == x2 or y == 0)");
+  if (err & tg::TG_ERR_WITNESS) return fail(SBN_ERR_WITNESS, "modular witness generation failed");
+  if (err & tg::TG_ERR_RANGE) return fail(SBN_ERR_WITNESS, "range-checked column holds a value >= 2^16");
+  // public inputs: x, offset, exp_val, output as u32 limbs (g1/exp.rs:124-135)
+  P->pi.resize(P->air.npi);
+  for (size_t k = 0; k < K; k++) {
+    u64* p = P->pi.data() + (size_t)sh.pi_per_io * k;
+    for (int i = 0; i < 40; i++) p[i] = ios[40 * k + i];
+    for (int i = 0; i < 16; i++) p[40 + i] = out[16 * k + i];
+  }
+  if (pi_out) memcpy(pi_out, P->pi.data(), P->pi.size() * sizeof(u64));
+  P->loaded = true;
+  return SBN_OK;
+}
+
+extern "C" int sbn_prover_read_trace(sbn_prover* P, uint64_t* out) {
+  if (!P || !out) return fail(SBN_ERR_BAD_ARG, "null argument");
+  if (!P->loaded) return fail(SBN_ERR_BAD_ARG, "no trace loaded");
+  HIPC(hipSetDevice(P->device));
+  HIPC(hipMemcpy(out, P->d_trace, P->air.ncols * P->n * sizeof(u64), hipMemcpyDeviceToHost));
   return SBN_OK;
 }
 extern "C" uint64_t* sbn_prover_trace_device_ptr(sbn_prover* P) { return P ? P->d_trace : nullptr; }

@@ -215,6 +215,16 @@ static bool fill_split_range_check(uint64_t* trace, size_t n, int table_col, int
   return !bad;
 }
 
+// Both curve chains of every instance on host threads (the sequential 0.1% of witness generation; the device does the
+// rest, see sbn_prover_generate_trace).  ja / jb: [K][257][3][4] u64 (bn254w.cuh jac_at).
+namespace sbn {
+int tracegen_host_chains(const uint32_t* ios, size_t K, u64* ja, u64* jb) {
+  std::atomic<int> bad(0);
+  parallel_for(K, [&](size_t k) { int b = g1_chains(ios + 40 * k, k, ja, jb); if (b) bad |= b; });
+  return bad.load();
+}
+}  // namespace sbn
+
 struct PhaseTimer {  // SBN_TRACE_TIMING=1 prints per-phase wall time to stderr
   bool on; std::chrono::steady_clock::time_point t;
   PhaseTimer() : on(getenv("SBN_TRACE_TIMING") != nullptr), t(std::chrono::steady_clock::now()) {}

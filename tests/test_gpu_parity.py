@@ -125,6 +125,41 @@ def test_g1exp_full_oracle_proof_equality(gpu, O, g1exp_case, g1exp_gpu_proof):
     assert np.array_equal(p1.words, ref)
 
 
+def test_g1exp_device_witness_generation_matches_oracle(gpu, O, g1exp_case, g1exp_gpu_proof, golden):
+    """G1ExpStark::generate_trace on the device (src/curves/g1/exp.rs:255-327): trace and public inputs equal the CPU
+    oracle's word for word, and proving straight from the device-resident trace gives the same proof bytes."""
+    stark, cfg, p1, _, _ = g1exp_gpu_proof
+    prover = gpu.Prover(stark, cfg, 16)
+    try:
+        pi = prover.generate_trace(g1exp_case["ios"])
+        assert np.array_equal(pi, g1exp_case["pi"])
+        dev = prover.read_trace()
+        ref = g1exp_case["trace"]
+        bad = np.nonzero((dev != ref).any(axis=1))[0]
+        assert bad.size == 0, f"first differing columns: {bad[:8].tolist()}"
+        proof = prover.prove()
+        assert np.array_equal(proof.words, p1.words)
+        assert prover.stage_times()["device_tracegen_ms"] > 0
+        # structured columns: a constant limb column, one repeating 65535, and a degenerate instance
+        ios = g1exp_case["ios"].copy()
+        ios[:, 32:40] = 0                                          # exp_val = 0: no additions at all
+        ios[3, 32:40] = 0xFFFFFFFF
+        pi2 = prover.generate_trace(ios)
+        t_host, pi_host = stark.generate_trace_and_public_inputs(ios)
+        assert np.array_equal(pi2, pi_host)
+        assert np.array_equal(prover.read_trace(), t_host)
+        ios[5, 16:32] = ios[5, 0:16]                               # offset == x with bit 0 set: x1 == x2 in the first add
+        ios[5, 32] = 1
+        with pytest.raises(gpu.SbnError) as e:
+            prover.generate_trace(ios)
+        assert e.value.code == -8
+        with pytest.raises(gpu.SbnError) as e:
+            stark.generate_trace_and_public_inputs(ios)
+        assert e.value.code == -8
+    finally:
+        prover.close()
+
+
 def test_prover_argument_errors(gpu, g1op_case):
     stark = gpu.G1Stark()
     cfg = stark.config()
