@@ -126,6 +126,20 @@ def main():
     # every rank checks its own proof outside the timed region
     S.verify_stark_proof(stark, proof, cfg)
 
+    # instance list -> proof with the witness generated on the device (G1 table; outside the timed region, reported
+    # beside the host-generator + PCIe path): wall clock of generate_trace + prove, 5 repetitions after one warm-up
+    e2e = None
+    if rank == 0 and args.table == "g1":
+        prover.generate_trace(ios)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            pi_dev = prover.generate_trace(ios)
+            tg_ms = prover.stage_times()["device_tracegen_ms"]
+            proof_dev = prover.prove()
+        torch.cuda.synchronize()
+        e2e = {"device_tracegen_ms": tg_ms, "ios_to_proof_ms_device_witness": (time.perf_counter() - t0) / 5 * 1e3,
+               "same_proof_as_host_witness": bool((proof_dev.words == proof.words).all() and (pi_dev == pi).all())}
+
     if rank == 0:
         steps = max(args.steps, 1)
         if args.traffic_bytes is None:
@@ -167,6 +181,9 @@ def main():
             "stage_ms": stage_ms,
             "host": {"tracegen_s": t_tracegen, "h2d_s": t_h2d, "trace_bytes": int(trace.nbytes)},
         }
+        if e2e:
+            e2e["ios_to_proof_ms_host_witness"] = (t_tracegen + t_h2d) * 1e3 + ms_per_step / max(args.concurrency, 1) * max(args.concurrency, 1)
+            line["end_to_end"] = e2e
         if world == 1 and not args.skip_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(trace, pi, args.table)
         print(json.dumps(line), flush=True)

@@ -18,6 +18,9 @@
 #include <cstring>
 #include <functional>
 #include <chrono>
+#include <mutex>
+#include <condition_variable>
+#include <unistd.h>
 
 using namespace sbn;
 
@@ -111,15 +114,57 @@ inline void cbatch_inv(std::vector<Co<2>>& v) {
   for (size_t i = 0; i < v.size(); i++) { Fq a = mmul(v[i].c[0], nrm[i]), b = fsub(z, mmul(v[i].c[1], nrm[i])); v[i].c[0] = a; v[i].c[1] = b; }
 }
 
-void parallel_for(size_t n, const std::function<void(size_t)>& f) {
-  unsigned nt = std::thread::hardware_concurrency(); if (nt == 0) nt = 4; if (nt > 64) nt = 64;
-  if (nt > n) nt = (unsigned)n;
-  if (nt <= 1) { for (size_t i = 0; i < n; i++) f(i); return; }
-  std::atomic<size_t> next(0);
-  std::vector<std::thread> th;
-  for (unsigned t = 0; t < nt; t++) th.emplace_back([&] { for (size_t i; (i = next.fetch_add(1)) < n;) f(i); });
-  for (auto& t : th) t.join();
-}
+// Persistent worker pool: witness generation issues several short parallel loops per trace, and spawning threads
+// for each costs more than the loops themselves.  Workers sleep on a condition variable between loops; the calling
+// thread takes part.  The pool is rebuilt after a fork (the child has none of the parent's threads).
+class WorkerPool {
+ public:
+  static WorkerPool& get() {
+    static std::mutex gm; static WorkerPool* pool = nullptr; static pid_t owner = 0;
+    std::lock_guard<std::mutex> g(gm);
+    if (!pool || owner != getpid()) { pool = new WorkerPool(); owner = getpid(); }  // a forked child leaks the stale one
+    return *pool;
+  }
+  void run(size_t n, const std::function<void(size_t)>& f) {
+    if (in_worker() || n <= 1 || workers_.empty()) { for (size_t i = 0; i < n; i++) f(i); return; }
+    std::lock_guard<std::mutex> serial(run_m_);
+    { std::lock_guard<std::mutex> lk(m_); job_ = &f; n_ = n; next_.store(0); active_ = (unsigned)workers_.size(); gen_++; }
+    cv_.notify_all();
+    for (size_t i; (i = next_.fetch_add(1)) < n;) f(i);
+    std::unique_lock<std::mutex> lk(m_);
+    done_.wait(lk, [&] { return active_ == 0; });
+  }
+ private:
+  static bool& in_worker() { static thread_local bool w = false; return w; }
+  WorkerPool() {
+    unsigned nt = std::thread::hardware_concurrency(); if (nt == 0) nt = 4; if (nt > 64) nt = 64;
+    if (const char* e = getenv("SBN_HOST_THREADS")) { int v = atoi(e); if (v >= 1 && v <= 256) nt = (unsigned)v; }
+    for (unsigned t = 1; t < nt; t++) workers_.emplace_back([this] { worker(); });
+    for (auto& t : workers_) t.detach();  // they sleep until process exit; nothing to join at unload
+  }
+  void worker() {
+    in_worker() = true;
+    size_t seen = 0;
+    for (;;) {
+      std::unique_lock<std::mutex> lk(m_);
+      cv_.wait(lk, [&] { return gen_ != seen; });
+      seen = gen_;
+      const std::function<void(size_t)>* f = job_; const size_t n = n_;
+      lk.unlock();
+      for (size_t i; (i = next_.fetch_add(1)) < n;) (*f)(i);
+      lk.lock();
+      if (--active_ == 0) done_.notify_one();
+    }
+  }
+  std::vector<std::thread> workers_;
+  std::mutex m_, run_m_;
+  std::condition_variable cv_, done_;
+  const std::function<void(size_t)>* job_ = nullptr;
+  size_t n_ = 0, gen_ = 0;
+  std::atomic<size_t> next_{0};
+  unsigned active_ = 0;
+};
+void parallel_for(size_t n, const std::function<void(size_t)>& f) { WorkerPool::get().run(n, f); }
 // contiguous index ranges of `chunk` per task: consecutive rows written by one thread stay cache-friendly
 // in the column-major trace
 void parallel_for_chunks(size_t n, size_t chunk, const std::function<void(size_t, size_t)>& f) {
