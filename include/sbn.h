@@ -156,6 +156,9 @@ int sbn_commit_values(const uint64_t* cols, size_t ncols, size_t n, uint32_t rat
                       uint64_t* cap_out, uint64_t* coeffs_out, uint64_t* lde_out);
 /* Poseidon permutation of `count` independent width-12 states on the device (host in/out). */
 int sbn_poseidon_permute_batch(uint64_t* states, size_t count);
+/* The host permutation behind the Fiat-Shamir transcript of prove()/verify() (plonky2 Challenger's
+ * PoseidonPermutation): sparse partial rounds, or the plain definition when use_definition != 0.  Host only. */
+int sbn_poseidon_permute_host(uint64_t* states, size_t count, int use_definition);
 
 #ifdef __cplusplus
 }

@@ -27,7 +27,7 @@ EXPORTS = [
     "sbn_prover_prove", "sbn_prover_stage_times", "sbn_prover_stage_name", "sbn_prover_trace_device_ptr",
     "sbn_prover_generate_trace", "sbn_prover_read_trace",
     "sbn_prove", "sbn_proof_num_words", "sbn_proof_words", "sbn_proof_serialize", "sbn_proof_degree_bits",
-    "sbn_proof_free", "sbn_verify", "sbn_commit_values", "sbn_poseidon_permute_batch",
+    "sbn_proof_free", "sbn_verify", "sbn_commit_values", "sbn_poseidon_permute_batch", "sbn_poseidon_permute_host",
 ]
 
 
@@ -96,6 +96,7 @@ def lib():
         L.sbn_verify.argtypes = [C.POINTER(_AirDesc), C.POINTER(_Config), vp, sz]
         L.sbn_commit_values.argtypes = [vp, sz, sz, u32, u32, vp, vp, vp]
         L.sbn_poseidon_permute_batch.argtypes = [vp, sz]
+        L.sbn_poseidon_permute_host.argtypes = [vp, sz, C.c_int]
         L.sbn_set_device.argtypes = [C.c_int]
         _LIB = L
     return _LIB
@@ -341,4 +342,11 @@ def commit_values(cols, rate_bits=1, cap_height=4, want_coeffs=False, want_lde=F
 def poseidon_permute_batch(states):
     s = np.ascontiguousarray(states, dtype=np.uint64).copy()
     _check(lib().sbn_poseidon_permute_batch(_ptr(s), s.shape[0]))
+    return s
+
+
+def poseidon_permute_host(states, use_definition=False):
+    """The transcript's host permutation (no device): sparse partial rounds, or the plain definition."""
+    s = np.ascontiguousarray(states, dtype=np.uint64).copy()
+    _check(lib().sbn_poseidon_permute_host(_ptr(s), s.shape[0], 1 if use_definition else 0))
     return s

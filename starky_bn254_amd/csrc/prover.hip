@@ -861,6 +861,20 @@ extern "C" int sbn_poseidon_permute_batch(uint64_t* states, size_t count) {
   return SBN_OK;
 }
 
+// The transcript's host permutation (sparse partial rounds) or, with use_definition != 0, the plain round-by-round
+// form it must agree with.  No device involved: this is the Fiat-Shamir hasher of prove() / verify().
+extern "C" int sbn_poseidon_permute_host(uint64_t* states, size_t count, int use_definition) {
+  if (!states) return fail(SBN_ERR_BAD_ARG, "null argument");
+  for (size_t i = 0; i < count * 12; i++) if (states[i] >= GLP) return fail(SBN_ERR_NON_CANONICAL, "state word %zu is not canonical", i);
+  for (size_t k = 0; k < count; k++) {
+    F st[12];
+    for (int i = 0; i < 12; i++) st[i] = F(states[12 * k + i]);
+    if (use_definition) poseidon_permute_generic(st); else poseidon_permute(st);
+    for (int i = 0; i < 12; i++) states[12 * k + i] = st[i].v;
+  }
+  return SBN_OK;
+}
+
 extern "C" int sbn_set_device(int device) {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return fail(SBN_ERR_NO_DEVICE, "device %d not available", device);

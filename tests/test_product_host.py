@@ -34,6 +34,25 @@ def test_shapes_and_config(S):
     assert S.G1ExpStark(0).num_columns == 0 and S.G1ExpStark(129).num_columns == 0     # unknown shapes report 0
 
 
+def test_host_transcript_permutation(S, O, golden):
+    """The Fiat-Shamir hasher of prove()/verify(): sparse partial rounds == the plain definition == the oracle == KATs."""
+    kat = golden["poseidon_kat"]["vectors"]
+    states = np.array([[int(x, 16) for x in v["input"]] for v in kat], dtype=np.uint64)
+    want = [[int(x, 16) for x in v["output"]] for v in kat]
+    assert [[int(x) for x in r] for r in S.poseidon_permute_host(states)] == want
+    assert [[int(x) for x in r] for r in S.poseidon_permute_host(states, use_definition=True)] == want
+    rng = np.random.default_rng(11)
+    st = rng.integers(0, P, size=(512, 12), dtype=np.uint64)
+    st[0] = P - 1; st[1] = 0; st[2, :] = [P - 1, 0, 1, 0xFFFFFFFF, 0xFFFFFFFF00000000, 1 << 32, 1 << 63, 2, 3, 4, 5, 6]
+    fast, plain = S.poseidon_permute_host(st), S.poseidon_permute_host(st, use_definition=True)
+    assert np.array_equal(fast, plain)
+    for r in (0, 1, 2, 3, 100, 511):
+        assert [int(x) for x in fast[r]] == O.poseidon_permute([int(x) for x in st[r]])
+    with pytest.raises(S.SbnError) as e:
+        S.poseidon_permute_host(np.full((1, 12), P, dtype=np.uint64))
+    assert e.value.code == -2
+
+
 def test_tracegen_g1op_matches_oracle(S, O):
     for rows, seed in ((512, 0), (1024, 3)):
         pts, _ = O.g1op_inputs(rows, seed)
