@@ -332,11 +332,15 @@ __global__ __launch_bounds__(256) void leaf_absorb_kernel(const u64* __restrict_
   }
 }
 
-// K3' fused Merkle levels: a workgroup owns 2*blockDim consecutive digests of level `l0` and hashes
+// Measured (tools/microbench/coop_latency.hip): one permutation takes 49 us on one lane and 16 us on 16 lanes, and a
+// single wave already saturates its SIMD's issue slots, so more waves per SIMD only queue up: 256 lanes (one wave per
+// SIMD) is the best workgroup size for the latency-bound levels (A/B against 512 and 1024 lanes on the G1 proof).
+static constexpr u32 MERKLE_SUBTREE_THREADS = 256;
+// K3' fused Merkle levels: a workgroup owns up to 512 consecutive digests of level `l0` and hashes
 // up to `nlev` levels above them through LDS, writing every level to the tree (levels concatenated,
 // level l at word offset 4*(2*nleaf - (2*nleaf >> l))).  Two launches build a 2^17-leaf tree.  Levels with few
 // nodes per workgroup switch to 16 lanes per node (poseidon_permute_coop16): they are latency-bound.
-__global__ __launch_bounds__(256) void merkle_subtree_kernel(u64* __restrict__ tree, size_t nleaf, u32 l0, u32 nlev, u32 nchild) {
+__global__ __launch_bounds__(MERKLE_SUBTREE_THREADS) void merkle_subtree_kernel(u64* __restrict__ tree, size_t nleaf, u32 l0, u32 nlev, u32 nchild) {
   __shared__ u64 buf[2 * 256 * 4];
   const u32 tid = threadIdx.x, nt = blockDim.x;   // nchild = digests of level l0 owned by this workgroup (<= 512)
   const u64* child = tree + (2 * nleaf - ((2 * nleaf) >> l0)) * 4;
@@ -370,7 +374,9 @@ __global__ __launch_bounds__(256) void merkle_subtree_kernel(u64* __restrict__ t
       u32 nit = (active + groups - 1) / groups;
       for (u32 it = 0; it < nit; it++) {
         u32 parent = it * groups + grp;
-        u64 v = (parent < active && lane < 8) ? buf[parent * 8 + lane] : 0;
+        if (it * groups + (tid / 64) * 4 >= active) break;  // wave-uniform: none of this wave's four groups has a parent
+        const u32 e = lane < 12 ? lane : lane - 12;  // lanes 12..15 mirror elements 0..3
+        u64 v = (parent < active && e < 8) ? buf[parent * 8 + e] : 0;
         res[it] = poseidon_permute_coop16(v, lane);
       }
       __syncthreads();
@@ -632,37 +638,65 @@ __global__ void fri_combine_reduce_kernel(const u64* part_a, const u64* part_b, 
   out_a[i] = acc.a.v; out_b[i] = acc.b.v;
 }
 
-// Synthetic division by (X - z) (PolynomialCoeffs::divide_by_linear), single workgroup:
+// Synthetic division by (X - z) (PolynomialCoeffs::divide_by_linear):
 // B_i = c_i + z*B_{i+1}; quotient q_{i-1} = B_i, q_{n-1} = 0; then out = out*mul + q (ext).
-__global__ __launch_bounds__(256) void divide_by_linear_kernel(const u64* ca, const u64* cb, size_t n, u64 z0, u64 z1,
-                                                               u64 mul0, u64 mul1, u64* oa, u64* ob, int accumulate) {
-  __shared__ u64 ha[256], hb[256];
-  const int tid = threadIdx.x;
-  const size_t L = n / 256;
-  E2 z{F(z0), F(z1)};
-  size_t s = (size_t)tid * L;
+// The suffix recurrence is split into chunks of DBL_CHUNK coefficients:
+//   pass 1 (one lane per chunk)  h_t = sum_k c_{tL+k} z^k, the chunk's own Horner value;
+//   pass 2 (one workgroup)       carry_t = B_{(t+1)L} from B_{tL} = h_t + z^L B_{(t+1)L}, scanned from the top;
+//   pass 3 (one lane per chunk)  replays the chunk from its carry and writes the quotient.
+static constexpr u32 DBL_CHUNK = 16;
+__global__ __launch_bounds__(256) void divide_by_linear_pass1(const u64* __restrict__ ca, const u64* __restrict__ cb, size_t nchunks, u64 z0, u64 z1,
+                                                              u64* __restrict__ ha, u64* __restrict__ hb) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nchunks) return;
+  const E2 z{F(z0), F(z1)};
+  const size_t s = t * DBL_CHUNK;
   E2 h{F(0), F(0)};
-  for (size_t k = L; k-- > 0;) h = h * z + E2(F(ca[s + k]), F(cb[s + k]));
-  ha[tid] = h.a.v; hb[tid] = h.b.v;
+  for (u32 k = DBL_CHUNK; k-- > 0;) h = h * z + E2(F(ca[s + k]), F(cb[s + k]));
+  ha[t] = h.a.v; hb[t] = h.b.v;
+}
+// in place: (ha, hb)[t] <- carry_t.  One workgroup; nchunks is a power of two, min(256, nchunks) lanes own
+// nchunks/lanes consecutive chunks each.
+__global__ __launch_bounds__(256) void divide_by_linear_pass2(u64* __restrict__ ha, u64* __restrict__ hb, size_t nchunks, u64 z0, u64 z1) {
+  __shared__ u64 sa[256], sb[256];
+  const int tid = threadIdx.x;
+  const int lanes = nchunks < 256 ? (int)nchunks : 256;
+  const size_t per = tid < lanes ? nchunks / lanes : 0, base = (size_t)tid * per;
+  const E2 zl = e2_pow(E2{F(z0), F(z1)}, DBL_CHUNK);
+  E2 g{F(0), F(0)};  // value of this lane's chunks with a zero carry-in
+  for (size_t j = per; j-- > 0;) g = E2(F(ha[base + j]), F(hb[base + j])) + zl * g;
+  sa[tid] = g.a.v; sb[tid] = g.b.v;
   __syncthreads();
   if (tid == 0) {
-    E2 zl = e2_pow(z, L);
-    E2 carry{F(0), F(0)};  // B_{(t+1)L}
-    for (int t = 255; t >= 0; t--) {
-      E2 ht{F(ha[t]), F(hb[t])};
-      ha[t] = carry.a.v; hb[t] = carry.b.v;  // carry-in for chunk t
-      carry = ht + zl * carry;
+    const E2 zg = e2_pow(zl, per);
+    E2 carry{F(0), F(0)};
+    for (int t = lanes - 1; t >= 0; t--) {
+      const E2 gt{F(sa[t]), F(sb[t])};
+      sa[t] = carry.a.v; sb[t] = carry.b.v;
+      carry = gt + zg * carry;
     }
   }
   __syncthreads();
-  E2 b{F(ha[tid]), F(hb[tid])};
-  E2 mul{F(mul0), F(mul1)};
-  for (size_t k = L; k-- > 0;) {
-    size_t i = s + k;
-    // q_i = B_{i+1}: the value of b BEFORE absorbing c_i
-    E2 q = b;
+  E2 carry{F(sa[tid]), F(sb[tid])};
+  for (size_t j = per; j-- > 0;) {
+    const E2 h{F(ha[base + j]), F(hb[base + j])};
+    ha[base + j] = carry.a.v; hb[base + j] = carry.b.v;
+    carry = h + zl * carry;
+  }
+}
+__global__ __launch_bounds__(256) void divide_by_linear_pass3(const u64* __restrict__ ca, const u64* __restrict__ cb, size_t nchunks, u64 z0, u64 z1,
+                                                              const u64* __restrict__ ha, const u64* __restrict__ hb, u64 mul0, u64 mul1,
+                                                              u64* __restrict__ oa, u64* __restrict__ ob, int accumulate) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nchunks) return;
+  const E2 z{F(z0), F(z1)}, mul{F(mul0), F(mul1)};
+  const size_t s = t * DBL_CHUNK;
+  E2 b{F(ha[t]), F(hb[t])};
+  for (u32 k = DBL_CHUNK; k-- > 0;) {
+    const size_t i = s + k;
+    const E2 q = b;  // q_i = B_{i+1}: the value of b BEFORE absorbing c_i
     b = b * z + E2(F(ca[i]), F(cb[i]));
-    E2 o = accumulate ? E2(F(oa[i]), F(ob[i])) * mul + q : q;
+    const E2 o = accumulate ? E2(F(oa[i]), F(ob[i])) * mul + q : q;
     oa[i] = o.a.v; ob[i] = o.b.v;
   }
 }

@@ -192,13 +192,14 @@ static int tree_alloc(DevTree& t, size_t nleaf, u32 cap_height) {
   return dmalloc(&t.d, 2 * nleaf * 4);
 }
 static int tree_build_inner(sbn_prover* P, DevTree& t, hipStream_t st) {
+  const u32 threads = MERKLE_SUBTREE_THREADS;
   u32 l0 = 0;
   while (l0 < t.nlevels) {
     size_t nodes = t.nleaf >> l0;
     u32 nchild = (u32)std::min<size_t>(512, nodes);   // children per workgroup
     u32 lg = 0; while ((2u << lg) < nchild) lg++;       // nchild = 2^(lg+1)
     u32 nlev = std::min(t.nlevels - l0, lg + 1);
-    hipLaunchKernelGGL(merkle_subtree_kernel, dim3((unsigned)(nodes / nchild)), dim3(256), 0, st, t.d, t.nleaf, l0, nlev, nchild);
+    hipLaunchKernelGGL(merkle_subtree_kernel, dim3((unsigned)(nodes / nchild)), dim3(threads), 0, st, t.d, t.nleaf, l0, nlev, nchild);
     l0 += nlev;
   }
   HIPC(hipGetLastError());
@@ -660,9 +661,15 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
     // final_poly = alpha^(C+Z) * (F0 / (X - zeta)) + F1 / (X - g zeta), padded back to n, then lde -> m
     HIPC(hipMemsetAsync(P->d_fcoef, 0, 2 * m * sizeof(u64), st));
     E2 shift2 = e2_pow(fri_alpha, C + Z);
-    hipLaunchKernelGGL(divide_by_linear_kernel, dim3(1), dim3(256), 0, st, f0a, f0b, n, zeta.a.v, zeta.b.v, (u64)0, (u64)0, P->d_fcoef, P->d_fcoef + m, 0);
-    hipLaunchKernelGGL(divide_by_linear_kernel, dim3(1), dim3(256), 0, st, f1a, f1b, n, zeta_next.a.v, zeta_next.b.v, shift2.a.v, shift2.b.v, P->d_fcoef,
-                       P->d_fcoef + m, 1);
+    auto divide = [&](const u64* ca, const u64* cb, E2 z, E2 mul, int accumulate) {
+      const size_t nch = n / DBL_CHUNK;  // a power of two >= 32
+      u64 *ha = P->d_part, *hb = P->d_part + nch;
+      hipLaunchKernelGGL(divide_by_linear_pass1, blocks(nch), dim3(256), 0, st, ca, cb, nch, z.a.v, z.b.v, ha, hb);
+      hipLaunchKernelGGL(divide_by_linear_pass2, dim3(1), dim3(256), 0, st, ha, hb, nch, z.a.v, z.b.v);
+      hipLaunchKernelGGL(divide_by_linear_pass3, blocks(nch), dim3(256), 0, st, ca, cb, nch, z.a.v, z.b.v, ha, hb, mul.a.v, mul.b.v, P->d_fcoef, P->d_fcoef + m, accumulate);
+    };
+    divide(f0a, f0b, zeta, E2{F(0), F(0)}, 0);
+    divide(f1a, f1b, zeta_next, shift2, 1);
     HIPC(hipGetLastError());
   }
   HIPC(hipEventRecord(P->ev[ST_FRI_LAYERS], st));
