@@ -47,7 +47,8 @@ class _Config(C.Structure):
 
 
 def lib_path():
-    return os.path.join(_HERE, "libsbn254.so")
+    """The in-tree HIP library; SBN_LIB selects another build of the same ABI (A/B measurements)."""
+    return os.environ.get("SBN_LIB") or os.path.join(_HERE, "libsbn254.so")
 
 
 def lib():

@@ -65,7 +65,24 @@ GL_HD u64 gl_reduce128(u64 lo, u64 hi) {
   if (r >= GLP) r -= GLP;
   return r;
 }
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SBN_NO_ASM_MUL)
+// gfx950: hand-scheduled multiply (tools/gen_poseidon_sbox_asm.py, gl_mul_asm.inc): the 128-bit product as four chained
+// v_mad_u64_u32, reduction with carries in an SGPR pair, canonical result; 22 instructions + hazard padding where the
+// compiler needs ~33.  64-bit temporaries live in the fixed window v112..v127 (clobbered).
+#include "poseidon_asm_clobbers.inc"
+__device__ __forceinline__ u64 gl_mul_dev(u64 a, u64 b) {
+  u32 lo, hi; u64 k;
+  asm(
+#include "gl_mul_asm.inc"
+      : "=&v"(lo), "=&v"(hi), "=&s"(k)
+      : "v"((u32)a), "v"((u32)(a >> 32)), "v"((u32)b), "v"((u32)(b >> 32))
+      : GL_CLOBBER_MUL);
+  return ((u64)hi << 32) | lo;
+}
+GL_HD F operator*(F a, F b) { return F(gl_mul_dev(a.v, b.v)); }
+#else
 GL_HD F operator*(F a, F b) { return F(gl_reduce128(a.v * b.v, gl_mulhi(a.v, b.v))); }
+#endif
 GL_HD F& operator+=(F& a, F b) { a = a + b; return a; }
 GL_HD F& operator-=(F& a, F b) { a = a - b; return a; }
 GL_HD F& operator*=(F& a, F b) { a = a * b; return a; }

@@ -143,7 +143,20 @@ for k in range(3):
     fold(sf[k], f"%{6 + 4 * k}", f"%{7 + 4 * k}", f"%{8 + 4 * k}", f"%{9 + 4 * k}", f"%{k}")
 write("poseidon_fold3_asm.inc", schedule(sf),
       ["three MDS output folds, interleaved; %0-%2 out (u64), %3-%5 carry SGPR pairs, %6-%17 = al.lo al.hi ah.lo ah.hi x3; clobbers v104-v127"])
+# --- generic canonical multiply (gl.cuh operator* on the device): one stream, window v112..v127 --------------------------
+# %0,%1 = result halves (canonical), %2 = carry SGPR pair, %3,%4 = a halves, %5,%6 = b halves
+sm = Stream(112, "%2")
+sm.emit(f"v_mov_b32 {sm.hi(Z)}, 0")
+sm.emit(f"v_mov_b32 {sm.hi(Y)}, 0")
+mul(sm, ("%3", "%4"), ("%5", "%6"), sm.pair(X))            # weak product in X
+c = sm.c
+sm.emit(f"v_add_co_u32_e64 {sm.lo(P0)}, {c}, {sm.lo(X)}, -1", wr=True)        # t = w + (2^32 - 1): carries out iff w >= p,
+sm.emit(f"v_addc_co_u32_e64 {sm.hi(P0)}, {c}, {sm.hi(X)}, 0, {c}", rd=True, wr=True)   # and then t mod 2^64 = w - p
+sm.emit(f"v_cndmask_b32_e64 %0, {sm.lo(X)}, {sm.lo(P0)}, {c}", rd=True)
+sm.emit(f"v_cndmask_b32_e64 %1, {sm.hi(X)}, {sm.hi(P0)}, {c}", rd=True)
+write("gl_mul_asm.inc", schedule([sm]), ["canonical Goldilocks multiply; %0,%1 out halves, %2 carry SGPR pair, %3,%4 = a, %5,%6 = b; clobbers v112-v127"])
+
 with open(os.path.join(CSRC, "poseidon_asm_clobbers.inc"), "w") as f:
     f.write("// Generated by tools/gen_poseidon_sbox_asm.py -- do not edit.\n")
-    for name, lo in (("PW_CLOBBER_SBOX3", 62), ("PW_CLOBBER_SBOX1", 106), ("PW_CLOBBER_FOLD3", 104)):
+    for name, lo in (("PW_CLOBBER_SBOX3", 62), ("PW_CLOBBER_SBOX1", 106), ("PW_CLOBBER_FOLD3", 104), ("GL_CLOBBER_MUL", 112)):
         f.write("#define %s %s\n" % (name, ", ".join('"v%d"' % r for r in range(lo, 128))))
