@@ -390,6 +390,35 @@ __global__ __launch_bounds__(MERKLE_SUBTREE_THREADS) void merkle_subtree_kernel(
   }
 }
 
+// One Merkle level across the whole GPU, for the levels the fused kernel would keep inside a few workgroups:
+// `merkle_level_thread_kernel` (one lane per parent) for wide levels, `merkle_level_coop_kernel` (16 lanes per parent,
+// 16 parents per workgroup = one wave per SIMD) for the narrow, latency-bound ones.  l = level of the children.
+__global__ __launch_bounds__(256) void merkle_level_thread_kernel(u64* __restrict__ tree, size_t nleaf, u32 l) {
+  const size_t parents = nleaf >> (l + 1);
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= parents) return;
+  const u64* child = tree + (2 * nleaf - ((2 * nleaf) >> l)) * 4;
+  u64* out = tree + (2 * nleaf - ((2 * nleaf) >> (l + 1))) * 4;
+  F s[12];
+#pragma unroll
+  for (int k = 0; k < 8; k++) s[k] = F(child[i * 8 + k]);
+#pragma unroll
+  for (int k = 8; k < 12; k++) s[k] = F(0);
+  poseidon_permute(s);
+#pragma unroll
+  for (int k = 0; k < 4; k++) out[i * 4 + k] = s[k].v;
+}
+__global__ __launch_bounds__(256) void merkle_level_coop_kernel(u64* __restrict__ tree, size_t nleaf, u32 l) {
+  const size_t parents = nleaf >> (l + 1);
+  const size_t parent = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  const u32 lane = threadIdx.x & 15, e = lane < 12 ? lane : lane - 12;  // lanes 12..15 mirror elements 0..3
+  const u64* child = tree + (2 * nleaf - ((2 * nleaf) >> l)) * 4;
+  u64* out = tree + (2 * nleaf - ((2 * nleaf) >> (l + 1))) * 4;
+  const u64 v = (parent < parents && e < 8) ? child[parent * 8 + e] : 0;
+  const u64 r = poseidon_permute_coop16(v, lane);   // every lane of the row takes part (DPP rotations)
+  if (parent < parents && lane < 4) out[parent * 4 + lane] = r;
+}
+
 // FRI layer leaves: leaf l = the 16 extension values at bit-reversed positions 16l..16l+15 of the
 // layer's evaluation vector (planes va/vb in natural order), flattened c0,c1 (fri/prover.rs).
 __global__ __launch_bounds__(256) void fri_leaf_hash_kernel(const u64* __restrict__ va, const u64* __restrict__ vb, u32 log_m, u32 arity_bits,

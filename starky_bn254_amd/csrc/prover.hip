@@ -192,15 +192,26 @@ static int tree_alloc(DevTree& t, size_t nleaf, u32 cap_height) {
   return dmalloc(&t.d, 2 * nleaf * 4);
 }
 static int tree_build_inner(sbn_prover* P, DevTree& t, hipStream_t st) {
-  const u32 threads = MERKLE_SUBTREE_THREADS;
+  // One permutation costs 39 us on a lane and 16 us on 16 lanes, and a single wave saturates its SIMD.  So: levels with
+  // >= 2^14 parents run one lane per parent over the whole GPU; narrower levels run 16 lanes per parent, 16 parents per
+  // workgroup (one wave per SIMD), one launch per level; the last <= 16 parents finish inside one workgroup.
   u32 l0 = 0;
   while (l0 < t.nlevels) {
-    size_t nodes = t.nleaf >> l0;
-    u32 nchild = (u32)std::min<size_t>(512, nodes);   // children per workgroup
-    u32 lg = 0; while ((2u << lg) < nchild) lg++;       // nchild = 2^(lg+1)
-    u32 nlev = std::min(t.nlevels - l0, lg + 1);
-    hipLaunchKernelGGL(merkle_subtree_kernel, dim3((unsigned)(nodes / nchild)), dim3(threads), 0, st, t.d, t.nleaf, l0, nlev, nchild);
-    l0 += nlev;
+    const size_t parents = t.nleaf >> (l0 + 1);
+    if (parents >= 16384) {
+      hipLaunchKernelGGL(merkle_level_thread_kernel, dim3((unsigned)((parents + 255) / 256)), dim3(256), 0, st, t.d, t.nleaf, l0);
+      l0++;
+    } else if (parents > 16) {
+      hipLaunchKernelGGL(merkle_level_coop_kernel, dim3((unsigned)((parents * 16 + 255) / 256)), dim3(256), 0, st, t.d, t.nleaf, l0);
+      l0++;
+    } else {
+      const size_t nodes = t.nleaf >> l0;
+      u32 nchild = (u32)std::min<size_t>(512, nodes);   // children per workgroup
+      u32 lg = 0; while ((2u << lg) < nchild) lg++;       // nchild = 2^(lg+1)
+      u32 nlev = std::min(t.nlevels - l0, lg + 1);
+      hipLaunchKernelGGL(merkle_subtree_kernel, dim3((unsigned)(nodes / nchild)), dim3(MERKLE_SUBTREE_THREADS), 0, st, t.d, t.nleaf, l0, nlev, nchild);
+      l0 += nlev;
+    }
   }
   HIPC(hipGetLastError());
   return 0;
