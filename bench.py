@@ -159,10 +159,10 @@ def main():
         for p in provers[1:]:
             p.close()
 
-    # instance list -> proof with the witness generated on the device (G1 table; outside the timed region, reported
+    # instance list -> proof with the witness generated on the device (outside the timed region, reported
     # beside the host-generator + PCIe path): wall clock of generate_trace + prove, 5 repetitions after one warm-up
     e2e = None
-    if rank == 0 and args.table == "g1":
+    if rank == 0:
         prover.generate_trace(ios)
         t0 = time.perf_counter()
         for _ in range(5):

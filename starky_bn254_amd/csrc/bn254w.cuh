@@ -185,71 +185,137 @@ GL_HD bool g1_output_row(bool is_double, const u64* ax, const u64* ay, const u64
   return cur == 320;
 }
 
-// ---- curve chains of one G1ExpStark instance ---------------------------------------------------------------------
+// ---- Fq2 limb products and the G2 gadget row ---------------------------------------------------------------------------
+// Fq2 limb product (src/fields/fq2.rs:41-58): c0 = x0*y0 - x1*y1, c1 = x0*y1 + x1*y0.
+GL_HD void conv16_fq2(const int64_t x[2][16], const int64_t y[2][16], int64_t out[2][31]) {
+  int64_t t[31];
+  conv16(x[0], y[0], out[0]); conv16(x[1], y[1], t); for (int k = 0; k < 31; k++) out[0][k] -= t[k];
+  conv16(x[0], y[1], out[1]); conv16(x[1], y[0], t); for (int k = 0; k < 31; k++) out[1][k] += t[k];
+}
+// Writes the 640 G2Output columns (src/curves/g2/muladd.rs:56-80) for one add / double.
+// Each value is an Fq2 given as two standard-form Fq (c0 = v, c1 = v + 4).
+GL_HD bool g2_output_row(bool is_double, const u64* ax, const u64* ay, const u64* bx, const u64* by, const u64* lam, const u64* nx, const u64* ny, u64* lv) {
+  int64_t l[2][16], axl[2][16], ayl[2][16], bxl[2][16], byl[2][16], nxl[2][16], nyl[2][16], t16[2][16];
+  int64_t zero_pol[2][31], inx[2][31], iny[2][31], c[2][31];
+  for (int q = 0; q < 2; q++) {
+    limbs16(lam + 4 * q, l[q]); limbs16(ax + 4 * q, axl[q]); limbs16(ay + 4 * q, ayl[q]); limbs16(nx + 4 * q, nxl[q]); limbs16(ny + 4 * q, nyl[q]);
+    if (is_double) { for (int i = 0; i < 16; i++) { bxl[q][i] = axl[q][i]; byl[q][i] = ayl[q][i]; } } else { limbs16(bx + 4 * q, bxl[q]); limbs16(by + 4 * q, byl[q]); }
+  }
+  if (is_double) {
+    conv16_fq2(l, ayl, zero_pol); conv16_fq2(axl, axl, c);
+    for (int q = 0; q < 2; q++) for (int k = 0; k < 31; k++) zero_pol[q][k] = 2 * zero_pol[q][k] - 3 * c[q][k];
+  } else {
+    for (int q = 0; q < 2; q++) for (int i = 0; i < 16; i++) t16[q][i] = bxl[q][i] - axl[q][i];
+    conv16_fq2(l, t16, zero_pol);
+    for (int q = 0; q < 2; q++) for (int i = 0; i < 16; i++) zero_pol[q][i] -= byl[q][i] - ayl[q][i];
+  }
+  conv16_fq2(l, l, inx);
+  for (int q = 0; q < 2; q++) for (int i = 0; i < 16; i++) inx[q][i] -= axl[q][i] + bxl[q][i];
+  for (int q = 0; q < 2; q++) for (int i = 0; i < 16; i++) t16[q][i] = axl[q][i] - nxl[q][i];
+  conv16_fq2(l, t16, iny);
+  for (int q = 0; q < 2; q++) for (int i = 0; i < 16; i++) iny[q][i] -= ayl[q][i];
+  ModW wz[2], wx[2], wy[2];
+  for (int q = 0; q < 2; q++)
+    if (!mod_witness(zero_pol[q], nullptr, false, wz[q]) || !mod_witness(inx[q], nx + 4 * q, true, wx[q]) || !mod_witness(iny[q], ny + 4 * q, true, wy[q])) return false;
+  int cur = 0;
+  for (int q = 0; q < 2; q++) for (int i = 0; i < 16; i++) lv[cur++] = (u64)l[q][i];
+  for (int q = 0; q < 2; q++) for (int i = 0; i < 16; i++) lv[cur++] = (u64)nxl[q][i];
+  for (int q = 0; q < 2; q++) for (int i = 0; i < 16; i++) lv[cur++] = (u64)nyl[q][i];
+  for (int blk = 0; blk < 3; blk++) {
+    const ModW* ws = blk == 0 ? wz : (blk == 1 ? wx : wy);
+    for (int q = 0; q < 2; q++) {
+      const ModW& w = ws[q];
+      if (blk) for (int i = 0; i < 16; i++) lv[cur++] = (u64)w.out_aux_red[i];
+      for (int i = 0; i < 17; i++) lv[cur++] = (u64)w.quot_abs[i];
+      for (int i = 0; i < 31; i++) lv[cur++] = (u64)w.aux_lo[i];
+      for (int i = 0; i < 31; i++) lv[cur++] = (u64)w.aux_hi[i];
+    }
+  }
+  for (int q = 0; q < 2; q++) lv[cur++] = wz[q].sign > 0 ? 1 : GLP - 1;
+  for (int q = 0; q < 2; q++) lv[cur++] = wx[q].sign > 0 ? 1 : GLP - 1;
+  for (int q = 0; q < 2; q++) lv[cur++] = wy[q].sign > 0 ? 1 : GLP - 1;
+  return cur == 640;
+}
+
+// ---- curve chains of one G1ExpStark / G2ExpStark instance -----------------------------------------------------------------
+// Coordinates: E = 1 -> Fq, E = 2 -> Fq2 = Fq[i]/(i^2+1), Montgomery form.
+template <int E> struct Co { Fq c[E]; };
+template <int E> GL_HD Co<E> cadd(const Co<E>& a, const Co<E>& b) { Co<E> r; for (int q = 0; q < E; q++) r.c[q] = fadd(a.c[q], b.c[q]); return r; }
+template <int E> GL_HD Co<E> csub(const Co<E>& a, const Co<E>& b) { Co<E> r; for (int q = 0; q < E; q++) r.c[q] = fsub(a.c[q], b.c[q]); return r; }
+GL_HD Co<1> cmul(const Co<1>& a, const Co<1>& b) { Co<1> r; r.c[0] = mmul(a.c[0], b.c[0]); return r; }
+GL_HD Co<2> cmul(const Co<2>& a, const Co<2>& b) {
+  Co<2> r;
+  r.c[0] = fsub(mmul(a.c[0], b.c[0]), mmul(a.c[1], b.c[1]));
+  r.c[1] = fadd(mmul(a.c[0], b.c[1]), mmul(a.c[1], b.c[0]));
+  return r;
+}
+template <int E> GL_HD bool czero(const Co<E>& a) { for (int q = 0; q < E; q++) if (!fzero(a.c[q])) return false; return true; }
+template <int E> GL_HD Co<E> cone() { Co<E> r; r.c[0] = fq_one(); for (int q = 1; q < E; q++) r.c[q] = Fq{{0, 0, 0, 0}}; return r; }
+
 // Strided Fq access: limb i of entry idx lives at base[i * stride + idx].
 GL_HD Fq ldq(const u64* base, size_t idx, size_t stride) { Fq r; for (int i = 0; i < 4; i++) r.l[i] = base[i * stride + idx]; return r; }
 GL_HD void stq(u64* base, size_t idx, size_t stride, const Fq& v) { for (int i = 0; i < 4; i++) base[i * stride + idx] = v.l[i]; }
 GL_HD void u32x8_to_u64x4(const uint32_t* w, u64* out) { for (int i = 0; i < 4; i++) out[i] = (u64)w[2 * i] | ((u64)w[2 * i + 1] << 32); }
 enum { TG_ERR_DEGENERATE = 1, TG_ERR_WITNESS = 2, TG_ERR_RANGE = 4 };
 
-struct Jac { Fq X, Y, Z; };
-// dbl-2009-l for y^2 = x^3 + b: 2M + 5S.
-GL_HD Jac jac_double(const Jac& p) {
-  Fq A = mmul(p.X, p.X), B = mmul(p.Y, p.Y), C = mmul(B, B);
-  Fq t = fadd(p.X, B); t = mmul(t, t); t = fsub(fsub(t, A), C);
-  Fq D = fadd(t, t), E = fadd(fadd(A, A), A), F = mmul(E, E);
-  Jac r;
-  r.X = fsub(F, fadd(D, D));
-  Fq C8 = fadd(C, C); C8 = fadd(C8, C8); C8 = fadd(C8, C8);
-  r.Y = fsub(mmul(E, fsub(D, r.X)), C8);
-  Fq yz = mmul(p.Y, p.Z);
-  r.Z = fadd(yz, yz);
+template <int E> struct Jac { Co<E> X, Y, Z; };
+// dbl-2009-l for y^2 = x^3 + b (no curve constant involved): 2M + 5S.
+template <int E> GL_HD Jac<E> jac_double(const Jac<E>& p) {
+  Co<E> A = cmul(p.X, p.X), B = cmul(p.Y, p.Y), C = cmul(B, B);
+  Co<E> t = cadd(p.X, B); t = cmul(t, t); t = csub(csub(t, A), C);
+  Co<E> D = cadd(t, t), Ee = cadd(cadd(A, A), A), F = cmul(Ee, Ee);
+  Jac<E> r;
+  r.X = csub(F, cadd(D, D));
+  Co<E> C8 = cadd(C, C); C8 = cadd(C8, C8); C8 = cadd(C8, C8);
+  r.Y = csub(cmul(Ee, csub(D, r.X)), C8);
+  Co<E> yz = cmul(p.Y, p.Z);
+  r.Z = cadd(yz, yz);
   return r;
 }
 // add-2007-bl (both Jacobian): 11M + 5S.  *degenerate is set when the x coordinates agree (H = 0).
-GL_HD Jac jac_add(const Jac& p, const Jac& q, bool* degenerate) {
-  Fq Z1Z1 = mmul(p.Z, p.Z), Z2Z2 = mmul(q.Z, q.Z);
-  Fq U1 = mmul(p.X, Z2Z2), U2 = mmul(q.X, Z1Z1);
-  Fq S1 = mmul(mmul(p.Y, q.Z), Z2Z2), S2 = mmul(mmul(q.Y, p.Z), Z1Z1);
-  Fq H = fsub(U2, U1);
-  *degenerate = fzero(H);
-  Fq I = fadd(H, H); I = mmul(I, I);
-  Fq J = mmul(H, I);
-  Fq r = fsub(S2, S1); r = fadd(r, r);
-  Fq V = mmul(U1, I);
-  Jac o;
-  o.X = fsub(fsub(mmul(r, r), J), fadd(V, V));
-  Fq sj = mmul(S1, J);
-  o.Y = fsub(mmul(r, fsub(V, o.X)), fadd(sj, sj));
-  Fq zz = fadd(p.Z, q.Z); zz = mmul(zz, zz); zz = fsub(fsub(zz, Z1Z1), Z2Z2);
-  o.Z = mmul(zz, H);
+template <int E> GL_HD Jac<E> jac_add(const Jac<E>& p, const Jac<E>& q, bool* degenerate) {
+  Co<E> Z1Z1 = cmul(p.Z, p.Z), Z2Z2 = cmul(q.Z, q.Z);
+  Co<E> U1 = cmul(p.X, Z2Z2), U2 = cmul(q.X, Z1Z1);
+  Co<E> S1 = cmul(cmul(p.Y, q.Z), Z2Z2), S2 = cmul(cmul(q.Y, p.Z), Z1Z1);
+  Co<E> H = csub(U2, U1);
+  *degenerate = czero(H);
+  Co<E> I = cadd(H, H); I = cmul(I, I);
+  Co<E> J = cmul(H, I);
+  Co<E> r = csub(S2, S1); r = cadd(r, r);
+  Co<E> V = cmul(U1, I);
+  Jac<E> o;
+  o.X = csub(csub(cmul(r, r), J), cadd(V, V));
+  Co<E> sj = cmul(S1, J);
+  o.Y = csub(cmul(r, csub(V, o.X)), cadd(sj, sj));
+  Co<E> zz = cadd(p.Z, q.Z); zz = cmul(zz, zz); zz = csub(csub(zz, Z1Z1), Z2Z2);
+  o.Z = cmul(zz, H);
   return o;
 }
 
-
-// Jacobian chain storage, instance-major (one host thread or one lane writes a contiguous 24 KB run):
-// entry (t, c) of instance k, t = 0..256, c = X,Y,Z -> 4 consecutive words at base + jac_at(k, t, c)
-GL_HD size_t jac_at(size_t k, int t, int c) { return (k * 257 + (size_t)t) * 12 + (size_t)c * 4; }
-// io: x.x x.y offset.x offset.y exp_val (8 u32 each).  A[t] = 2^t x (t = 0..256), B[0] = offset,
-// B[t+1] = bit_t ? B[t] + A[t] : B[t]   (g1/exp.rs:165-230: even rows add-if-bit, odd rows double), all in Jacobian
-// coordinates and Montgomery form, so no step needs an inversion.  Returns TG_ERR_* flags.
-GL_HD int g1_chains(const uint32_t* io, size_t k, u64* ja, u64* jb) {
+// Jacobian chain storage, instance-major (one host thread or one lane writes a contiguous run): coordinate c (X,Y,Z)
+// of step t (0..256) of instance k = E consecutive Fq (4 words each) at base + jac_at<E>(k, t, c).
+template <int E> GL_HD size_t jac_at(size_t k, int t, int c) { return ((k * 257 + (size_t)t) * 3 + (size_t)c) * 4 * E; }
+template <int E> GL_HD Co<E> ldc(const u64* p) { Co<E> r; for (int q = 0; q < E; q++) r.c[q] = ldq(p + 4 * q, 0, 1); return r; }
+template <int E> GL_HD void stc(u64* p, const Co<E>& v) { for (int q = 0; q < E; q++) stq(p + 4 * q, 0, 1, v.c[q]); }
+// io: x.x x.y offset.x offset.y (E x 8 u32 each) exp_val (8 u32).  A[t] = 2^t x (t = 0..256), B[0] = offset,
+// B[t+1] = bit_t ? B[t] + A[t] : B[t]   (g1/exp.rs:165-230, g2/exp.rs:180-246: even rows add-if-bit, odd rows double),
+// all in Jacobian coordinates and Montgomery form, so no step needs an inversion.  Returns TG_ERR_* flags.
+template <int E> GL_HD int exp_chains(const uint32_t* io, size_t k, u64* ja, u64* jb) {
   u64 t4[4];
-  Jac a, b;
-  u32x8_to_u64x4(io, t4); a.X = to_m(t4);
-  u32x8_to_u64x4(io + 8, t4); a.Y = to_m(t4);
-  u32x8_to_u64x4(io + 16, t4); b.X = to_m(t4);
-  u32x8_to_u64x4(io + 24, t4); b.Y = to_m(t4);
-  a.Z = fq_one(); b.Z = fq_one();
+  Jac<E> a, b;
+  Co<E>* dst[4] = {&a.X, &a.Y, &b.X, &b.Y};
+  for (int v = 0; v < 4; v++) for (int q = 0; q < E; q++) { u32x8_to_u64x4(io + 8 * (v * E + q), t4); dst[v]->c[q] = to_m(t4); }
+  a.Z = cone<E>(); b.Z = cone<E>();
+  const uint32_t* e = io + 32 * E;
   int bad = 0;
   for (int t = 0;; t++) {
-    stq(ja + jac_at(k, t, 0), 0, 1, a.X); stq(ja + jac_at(k, t, 1), 0, 1, a.Y); stq(ja + jac_at(k, t, 2), 0, 1, a.Z);
-    stq(jb + jac_at(k, t, 0), 0, 1, b.X); stq(jb + jac_at(k, t, 1), 0, 1, b.Y); stq(jb + jac_at(k, t, 2), 0, 1, b.Z);
+    stc<E>(ja + jac_at<E>(k, t, 0), a.X); stc<E>(ja + jac_at<E>(k, t, 1), a.Y); stc<E>(ja + jac_at<E>(k, t, 2), a.Z);
+    stc<E>(jb + jac_at<E>(k, t, 0), b.X); stc<E>(jb + jac_at<E>(k, t, 1), b.Y); stc<E>(jb + jac_at<E>(k, t, 2), b.Z);
     if (t == 256) break;
-    const bool bit = (io[32 + (t >> 5)] >> (t & 31)) & 1;
-    if (bit) { bool deg; b = jac_add(b, a, &deg); if (deg) bad |= TG_ERR_DEGENERATE; }
-    if (fzero(a.Y)) bad |= TG_ERR_DEGENERATE;
-    a = jac_double(a);
+    const bool bit = (e[t >> 5] >> (t & 31)) & 1;
+    if (bit) { bool deg; b = jac_add<E>(b, a, &deg); if (deg) bad |= TG_ERR_DEGENERATE; }
+    if (czero<E>(a.Y)) bad |= TG_ERR_DEGENERATE;
+    a = jac_double<E>(a);
   }
   return bad;
 }

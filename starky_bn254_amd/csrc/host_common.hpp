@@ -85,7 +85,7 @@ static inline bool config_supported(const sbn_config* c) {
 }
 
 // tracegen.hip: Jacobian curve chains of every G1ExpStark instance on host threads (layout: bn254w.cuh g1_chains)
-int tracegen_host_chains(const uint32_t* ios, size_t K, u64* ja, u64* jb);
+int tracegen_host_chains(int E, const uint32_t* ios, size_t K, u64* ja, u64* jb);
 
 }  // namespace sbn
 

@@ -1,5 +1,5 @@
-// Device witness generation for G1ExpStark: replaces G1ExpStark::generate_trace / generate_public_inputs
-// (src/curves/g1/exp.rs:255-327) with kernels that fill the column-major trace directly in HBM, so the 0.9 GB
+// Device witness generation for G1ExpStark and G2ExpStark (E = 1, 2): replaces generate_trace / generate_public_inputs
+// (src/curves/g1/exp.rs:255-327, src/curves/g2/exp.rs:271-342) with kernels that fill the column-major trace directly in HBM, so the 0.9 GB
 // trace never crosses PCIe.  The host generator (tracegen.hip) is the bit-exact counterpart; both share bn254w.cuh.
 //
 // The reference's per-instance loop is sequential in two ways: a = 2^t x is a chain of doublings and
@@ -38,19 +38,35 @@ __device__ __noinline__ Fq finv_fermat(const Fq& a) {
 }
 
 
-// affine storage: (t, c) with c = x,y
-__device__ __forceinline__ size_t aff_off(int t, int c, size_t K) { return ((size_t)(t * 2 + c) * 4) * K; }
+// inverse of a coordinate: Fq directly, Fq2 through the norm a^2 + b^2 (one Fq inversion)
+__device__ __forceinline__ Co<1> cinv(const Co<1>& a) { Co<1> r; r.c[0] = finv_fermat(a.c[0]); return r; }
+__device__ __forceinline__ Co<2> cinv(const Co<2>& a) {
+  const Fq ni = finv_fermat(fadd(mmul(a.c[0], a.c[0]), mmul(a.c[1], a.c[1])));
+  Co<2> r; r.c[0] = mmul(a.c[0], ni); r.c[1] = fsub(Fq{{0, 0, 0, 0}}, mmul(a.c[1], ni));
+  return r;
+}
 
-// One lane per instance: g1_chains (bn254w.cuh).  512 strictly sequential point operations per lane: the host
+// affine storage: coordinate c (x, y) of step t, component q: limb i of instance k at base + aff_off<E>(t, c, q, K) + i*K + k
+template <int E> __device__ __forceinline__ size_t aff_off(int t, int c, int q, size_t K) { return ((size_t)((t * 2 + c) * E + q) * 4) * K; }
+template <int E> __device__ __forceinline__ Co<E> lda(const u64* base, int t, int c, size_t k, size_t K) {
+  Co<E> r; for (int q = 0; q < E; q++) r.c[q] = ldq(base + aff_off<E>(t, c, q, K), k, K); return r;
+}
+template <int E> __device__ __forceinline__ void sta(u64* base, int t, int c, size_t k, size_t K, const Co<E>& v) {
+  for (int q = 0; q < E; q++) stq(base + aff_off<E>(t, c, q, K), k, K, v.c[q]);
+}
+
+// One lane per instance: exp_chains (bn254w.cuh).  512 strictly sequential point operations per lane: the host
 // threads do this faster (prover.hip picks), the kernel keeps the path host-free when asked (SBN_TRACEGEN_DEVICE_CHAIN=1).
+template <int E>
 __global__ void chain_kernel(const uint32_t* __restrict__ ios, size_t K, u64* __restrict__ ja, u64* __restrict__ jb, int* __restrict__ err) {
   const size_t k = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (k >= K) return;
-  const int bad = g1_chains(ios + 40 * k, k, ja, jb);
+  const int bad = exp_chains<E>(ios + 8 * (4 * E + 1) * k, k, ja, jb);
   if (bad) atomicOr(err, bad);
 }
 
 // One lane per (which, t, k): affine x = X / Z^2, y = Y / Z^3 (Montgomery form) for t = 0..256 of both chains.
+template <int E>
 __global__ void affine_kernel(const u64* __restrict__ ja, const u64* __restrict__ jb, size_t K, u64* __restrict__ aa, u64* __restrict__ ab, int* __restrict__ err) {
   const size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   const size_t per = 257 * K;
@@ -59,77 +75,86 @@ __global__ void affine_kernel(const u64* __restrict__ ja, const u64* __restrict_
   const size_t h = second ? g - per : g;
   const int t = (int)(h / K); const size_t k = h % K;
   const u64* j = second ? jb : ja; u64* o = second ? ab : aa;
-  Fq X = ldq(j + jac_at(k, t, 0), 0, 1), Y = ldq(j + jac_at(k, t, 1), 0, 1), Z = ldq(j + jac_at(k, t, 2), 0, 1);
-  if (fzero(Z)) { atomicOr(err, TG_ERR_DEGENERATE); return; }
-  Fq zi = finv_fermat(Z), zi2 = mmul(zi, zi);
-  stq(o + aff_off(t, 0, K), k, K, mmul(X, zi2));
-  stq(o + aff_off(t, 1, K), k, K, mmul(Y, mmul(zi2, zi)));
+  const Co<E> X = ldc<E>(j + jac_at<E>(k, t, 0)), Y = ldc<E>(j + jac_at<E>(k, t, 1)), Z = ldc<E>(j + jac_at<E>(k, t, 2));
+  if (czero<E>(Z)) { atomicOr(err, TG_ERR_DEGENERATE); return; }
+  const Co<E> zi = cinv(Z), zi2 = cmul(zi, zi);
+  sta<E>(o, t, 0, k, K, cmul(X, zi2));
+  sta<E>(o, t, 1, k, K, cmul(Y, cmul(zi2, zi)));
 }
 
-// One lane per row: the standard-form values ax ay bx by lam nx ny of the row (sv[(v*4 + limb) * n + row]) and its
-// operation (0 none, 1 add, 2 double).  Row r of instance k: a = A[r>>1]; even rows: b = B[r>>1], add if bit;
+// One lane per row: the standard-form values ax ay bx by lam nx ny of the row (sv[((v*E + q)*4 + limb) * n + row]) and
+// its operation (0 none, 1 add, 2 double).  Row r of instance k: a = A[r>>1]; even rows: b = B[r>>1], add if bit;
 // odd rows: b = B[(r>>1)+1], double.  Also writes the instance output B[256] (u32 limbs) for the public inputs.
+template <int E>
 __global__ void lambda_kernel(const uint32_t* __restrict__ ios, size_t K, const u64* __restrict__ aa, const u64* __restrict__ ab, size_t n,
                               u64* __restrict__ sv, unsigned char* __restrict__ row_op, u64* __restrict__ pi_out, int* __restrict__ err) {
   const size_t row = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (row >= n) return;
   const size_t k = row >> 9; const int r = (int)(row & 511), t = r >> 1; const bool dbl = r & 1;
-  const bool bit = (ios[40 * k + 32 + (t >> 5)] >> (t & 31)) & 1;
+  const bool bit = (ios[8 * (4 * E + 1) * k + 32 * E + (t >> 5)] >> (t & 31)) & 1;
   const int op = dbl ? 2 : (bit ? 1 : 0);
   const int tb = dbl ? t + 1 : t;
-  Fq v[7];
-  v[0] = ldq(aa + aff_off(t, 0, K), k, K); v[1] = ldq(aa + aff_off(t, 1, K), k, K);
-  v[2] = ldq(ab + aff_off(tb, 0, K), k, K); v[3] = ldq(ab + aff_off(tb, 1, K), k, K);
+  Co<E> v[7];
+  v[0] = lda<E>(aa, t, 0, k, K); v[1] = lda<E>(aa, t, 1, k, K);
+  v[2] = lda<E>(ab, tb, 0, k, K); v[3] = lda<E>(ab, tb, 1, k, K);
   if (op) {
-    Fq den, num;
-    if (dbl) { den = fadd(v[1], v[1]); Fq x2 = mmul(v[0], v[0]); num = fadd(fadd(x2, x2), x2); }
-    else { den = fsub(v[2], v[0]); num = fsub(v[3], v[1]); }
-    if (fzero(den)) atomicOr(err, TG_ERR_DEGENERATE);
-    v[4] = mmul(num, finv_fermat(den));
+    Co<E> den, num;
+    if (dbl) { den = cadd(v[1], v[1]); Co<E> x2 = cmul(v[0], v[0]); num = cadd(cadd(x2, x2), x2); }
+    else { den = csub(v[2], v[0]); num = csub(v[3], v[1]); }
+    if (czero<E>(den)) atomicOr(err, TG_ERR_DEGENERATE);
+    v[4] = cmul(num, cinv(den));
     const u64* nsrc = dbl ? aa : ab;
-    v[5] = ldq(nsrc + aff_off(t + 1, 0, K), k, K); v[6] = ldq(nsrc + aff_off(t + 1, 1, K), k, K);
+    v[5] = lda<E>(nsrc, t + 1, 0, k, K); v[6] = lda<E>(nsrc, t + 1, 1, k, K);
   }
-  for (int q = 0; q < (op ? 7 : 4); q++) {
-    u64 s[4]; from_m(v[q], s);
-    for (int i = 0; i < 4; i++) sv[(size_t)(q * 4 + i) * n + row] = s[i];
-  }
-  row_op[row] = (unsigned char)op;
-  if (r == 511) {  // b at the last row is the output (g1/exp.rs:124-135)
-    for (int c = 0; c < 2; c++) {
-      u64 s[4]; from_m(v[2 + c], s);
-      for (int i = 0; i < 8; i++) pi_out[16 * k + 8 * c + i] = (s[i >> 1] >> (32 * (i & 1))) & 0xffffffffULL;
+  for (int w = 0; w < (op ? 7 : 4); w++)
+    for (int q = 0; q < E; q++) {
+      u64 s[4]; from_m(v[w].c[q], s);
+      for (int i = 0; i < 4; i++) sv[(size_t)((w * E + q) * 4 + i) * n + row] = s[i];
     }
+  row_op[row] = (unsigned char)op;
+  if (r == 511) {  // b at the last row is the output (g1/exp.rs:124-135, g2/exp.rs:139-156)
+    for (int c = 0; c < 2; c++)
+      for (int q = 0; q < E; q++) {
+        u64 s[4]; from_m(v[2 + c].c[q], s);
+        for (int i = 0; i < 8; i++) pi_out[16 * E * k + 8 * (c * E + q) + i] = (s[i >> 1] >> (32 * (i & 1))) & 0xffffffffULL;
+      }
   }
 }
 
-// One lane per row: limb columns of a and b (columns 0..63) and the 320 G1Output columns at gadget_col.
+// One lane per row: limb columns of a and b (columns 0..64E-1) and the 320E gadget columns at gadget_col.
+template <int E>
 __global__ void __launch_bounds__(128) row_witness_kernel(const u64* __restrict__ sv, const unsigned char* __restrict__ row_op, size_t n, int gadget_col,
                                                           u64* __restrict__ trace, int* __restrict__ err) {
   const size_t row = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (row >= n) return;
-  u64 s[7][4];
+  u64 s[7][4 * E];
   const int op = row_op[row];
-  for (int q = 0; q < (op ? 7 : 4); q++) for (int i = 0; i < 4; i++) s[q][i] = sv[(size_t)(q * 4 + i) * n + row];
-  for (int q = 0; q < 4; q++)
-    for (int i = 0; i < 16; i++) trace[(size_t)(16 * q + i) * n + row] = (s[q][i >> 2] >> (16 * (i & 3))) & 0xffff;
+  for (int w = 0; w < (op ? 7 : 4); w++) for (int i = 0; i < 4 * E; i++) s[w][i] = sv[(size_t)(w * 4 * E + i) * n + row];
+  for (int w = 0; w < 4; w++)
+    for (int q = 0; q < E; q++)
+      for (int i = 0; i < 16; i++) trace[(size_t)(16 * (w * E + q) + i) * n + row] = (s[w][4 * q + (i >> 2)] >> (16 * (i & 3))) & 0xffff;
   u64* g = trace + (size_t)gadget_col * n + row;
+  constexpr int GW = 320 * E;
   if (op) {
-    u64 lv[320];
-    if (!g1_output_row(op == 2, s[0], s[1], s[2], s[3], s[4], s[5], s[6], lv)) { atomicOr(err, TG_ERR_WITNESS); return; }
-    for (int c = 0; c < 320; c++) g[(size_t)c * n] = lv[c];
-  } else {  // G1Output::default: zeros, quotient signs = 1
-    for (int c = 0; c < 317; c++) g[(size_t)c * n] = 0;
-    for (int c = 317; c < 320; c++) g[(size_t)c * n] = 1;
+    u64 lv[GW];
+    const bool ok = E == 1 ? g1_output_row(op == 2, s[0], s[1], s[2], s[3], s[4], s[5], s[6], lv)
+                           : g2_output_row(op == 2, s[0], s[1], s[2], s[3], s[4], s[5], s[6], lv);
+    if (!ok) { atomicOr(err, TG_ERR_WITNESS); return; }
+    for (int c = 0; c < GW; c++) g[(size_t)c * n] = lv[c];
+  } else {  // G1Output / G2Output::default: zeros, quotient signs = 1
+    for (int c = 0; c < GW - 3 * E; c++) g[(size_t)c * n] = 0;
+    for (int c = GW - 3 * E; c < GW; c++) g[(size_t)c * n] = 1;
   }
 }
 
 // flags columns (flags.rs:46-134) in closed form: within the 64-row block q of an instance the u32 limb e[q] is
-// consumed one bit per two rows; the limb window rotates after row 62 of the block.
-__global__ void flags_kernel(const uint32_t* __restrict__ ios, size_t n, int sf, u64* __restrict__ trace) {
+// consumed one bit per two rows; the limb window rotates after row 62 of the block.  iow = u32 words per instance,
+// the scalar sits in its last 8.
+__global__ void flags_kernel(const uint32_t* __restrict__ ios, size_t iow, size_t n, int sf, u64* __restrict__ trace) {
   const size_t row = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (row >= n) return;
   const size_t k = row >> 9; const int r = (int)(row & 511), q = r >> 6, s = r & 63, t = s >> 1;
-  const uint32_t* e = ios + 40 * k + 32;
+  const uint32_t* e = ios + iow * k + (iow - 8);
   auto limb = [&](int i) -> u64 { return i < 8 ? (u64)e[i] : 0; };
   const u64 a = r & 1, b = 1 - a, bit = (limb(q) >> t) & 1;
   auto col = [&](int c) -> u64& { return trace[(size_t)(sf + c) * n + row]; };

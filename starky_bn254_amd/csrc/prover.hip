@@ -83,6 +83,7 @@ struct sbn_prover {
   hipEvent_t hash_done;                      // hash -> main
   u64* d_sponge = nullptr;                   // [12][m] sponge state carried between column chunks
   u64* h_chain = nullptr;                    // pinned staging for the host-computed curve chains (device tracegen)
+  size_t h_chain_words = 0;
 };
 
 static int dmalloc(u64** p, size_t words) {
@@ -423,16 +424,13 @@ extern "C" int sbn_prover_load_trace_device(sbn_prover* P, const uint64_t* d_tra
 // ---- on-device witness generation (kernels_tracegen.cuh) ----------------------------------------------------------
 // Scratch lives in the (not yet used) LDE buffer; the only host traffic is the instance list in (20 KB) and the
 // instance outputs + error word back (8 KB).
-extern "C" int sbn_prover_generate_trace(sbn_prover* P, const uint32_t* ios, size_t num_io, uint64_t* pi_out) {
-  if (!P || !ios) return fail(SBN_ERR_BAD_ARG, "null argument");
-  if (P->air.kind != SBN_AIR_G1_EXP) return fail(SBN_ERR_UNSUPPORTED, "device witness generation covers G1ExpStark only (use sbn_generate_trace_* + sbn_prover_load_trace)");
-  if (num_io != P->air.num_io) return fail(SBN_ERR_BAD_ARG, "prover was created for %u instances, got %zu", P->air.num_io, num_io);
-  const size_t n = P->n, K = num_io;
-  if (n != 512 * K) return fail(SBN_ERR_BAD_ARG, "degree_bits does not match 512 rows per instance");
-  if (n != 65536) return fail(SBN_ERR_UNSUPPORTED, "device witness generation needs exactly 2^16 rows (u16 histogram in LDS)");
+template <int E>
+static int generate_trace_device(sbn_prover* P, const uint32_t* ios, size_t K, uint64_t* pi_out) {
+  const size_t n = P->n;
+  const size_t IOW = 8 * (4 * E + 1);  // u32 words per instance: x and offset (2E Fq each) + exp_val
   for (size_t k = 0; k < K; k++)
-    for (int v = 0; v < 4; v++) {
-      u64 t[4]; for (int i = 0; i < 4; i++) t[i] = (u64)ios[40 * k + 8 * v + 2 * i] | ((u64)ios[40 * k + 8 * v + 2 * i + 1] << 32);
+    for (int v = 0; v < 4 * E; v++) {
+      u64 t[4]; for (int i = 0; i < 4; i++) t[i] = (u64)ios[IOW * k + 8 * v + 2 * i] | ((u64)ios[IOW * k + 8 * v + 2 * i + 1] << 32);
       if (bnw::geq_p(t)) return fail(SBN_ERR_BAD_ARG, "coordinate >= p (instance %zu)", k);
     }
   HIPC(hipSetDevice(P->device));
@@ -442,12 +440,13 @@ extern "C" int sbn_prover_generate_trace(sbn_prover* P, const uint32_t* ios, siz
   // carve the scratch
   u64* w = P->d_lde;
   auto take = [&](size_t words) { u64* r = w; w += (words + 7) & ~(size_t)7; return r; };
-  u64* ja = take(257 * 12 * K); u64* jb = take(257 * 12 * K);
-  u64* aa = take(257 * 8 * K);  u64* ab = take(257 * 8 * K);
-  u64* sv = take(28 * n);       u64* inv = take(n);
-  u64* d_out = take(16 * K);
+  const size_t cw = 257 * 12 * E * K;  // one Jacobian chain of every instance
+  u64* ja = take(cw); u64* jb = take(cw);
+  u64* aa = take(257 * 8 * E * K);  u64* ab = take(257 * 8 * E * K);
+  u64* sv = take(28 * E * n);       u64* inv = take(n);
+  u64* d_out = take(16 * E * K);
   unsigned char* row_op = (unsigned char*)take(n / 8 + 1);
-  uint32_t* d_ios = (uint32_t*)take(20 * K);
+  uint32_t* d_ios = (uint32_t*)take(IOW * K / 2 + 1);
   int* d_err = (int*)take(1);
   if ((size_t)(w - P->d_lde) > P->air.ncols * P->m) return fail(SBN_ERR_UNSUPPORTED, "scratch does not fit");
   static bool attr_done = false;
@@ -458,38 +457,40 @@ extern "C" int sbn_prover_generate_trace(sbn_prover* P, const uint32_t* ios, siz
   std::vector<hipEvent_t> kev;
   auto mark = [&]() { if (timing) { hipEvent_t e; hipEventCreate(&e); hipEventRecord(e, st); kev.push_back(e); } };
   HIPC(hipEventRecord(e0, st));
-  HIPC(hipMemcpyAsync(d_ios, ios, 40 * K * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+  HIPC(hipMemcpyAsync(d_ios, ios, IOW * K * sizeof(uint32_t), hipMemcpyHostToDevice, st));
   HIPC(hipMemsetAsync(d_err, 0, sizeof(int), st));
   auto blocks = [](size_t k, unsigned b) { return dim3((unsigned)((k + b - 1) / b)); };
   mark();
-  hipLaunchKernelGGL(tg::flags_kernel, blocks(n, 256), dim3(256), 0, st, d_ios, n, sh.start_flags, P->d_trace);
+  hipLaunchKernelGGL(tg::flags_kernel, blocks(n, 256), dim3(256), 0, st, d_ios, IOW, n, sh.start_flags, P->d_trace);
   hipLaunchKernelGGL(tg::small_inverse_kernel, blocks(n, 256), dim3(256), 0, st, inv, n);
   hipLaunchKernelGGL(tg::periodic_kernel, blocks(n, 256), dim3(256), 0, st, inv, n, sh.start_periodic, sh.start_io_pulses, sh.start_lookups, P->d_trace);
   hipLaunchKernelGGL(tg::io_pulse_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)(2 * K)), dim3(256), 0, st, inv, n, sh.witness_col(0), P->d_trace);
   mark();
   // the two 256-step curve chains per instance: host threads while the device writes the input-independent columns
-  int host_err = 0;
-  if (getenv("SBN_TRACEGEN_DEVICE_CHAIN")) hipLaunchKernelGGL(tg::chain_kernel, blocks(K, 64), dim3(64), 0, st, d_ios, K, ja, jb, d_err);
+  if (getenv("SBN_TRACEGEN_DEVICE_CHAIN")) hipLaunchKernelGGL(tg::chain_kernel<E>, blocks(K, 64), dim3(64), 0, st, d_ios, K, ja, jb, d_err);
   else {
-    const size_t cw = 257 * 12 * K;
-    if (!P->h_chain) HIPC(hipHostMalloc((void**)&P->h_chain, 2 * cw * sizeof(u64), hipHostMallocDefault));
-    host_err = tracegen_host_chains(ios, K, P->h_chain, P->h_chain + cw);
-    if (host_err) return fail(SBN_ERR_WITNESS, "degenerate affine operation (x1 == x2 or y == 0)");
+    if (P->h_chain_words < 2 * cw) {
+      if (P->h_chain) (void)hipHostFree(P->h_chain);
+      P->h_chain = nullptr; P->h_chain_words = 0;
+      HIPC(hipHostMalloc((void**)&P->h_chain, 2 * cw * sizeof(u64), hipHostMallocDefault));
+      P->h_chain_words = 2 * cw;
+    }
+    if (tracegen_host_chains(E, ios, K, P->h_chain, P->h_chain + cw)) return fail(SBN_ERR_WITNESS, "degenerate affine operation (x1 == x2 or y == 0)");
     HIPC(hipMemcpyAsync(ja, P->h_chain, cw * sizeof(u64), hipMemcpyHostToDevice, st));
     HIPC(hipMemcpyAsync(jb, P->h_chain + cw, cw * sizeof(u64), hipMemcpyHostToDevice, st));
   }
   mark();
-  hipLaunchKernelGGL(tg::affine_kernel, blocks(2 * 257 * K, 64), dim3(64), 0, st, ja, jb, K, aa, ab, d_err);
+  hipLaunchKernelGGL(tg::affine_kernel<E>, blocks(2 * 257 * K, 64), dim3(64), 0, st, ja, jb, K, aa, ab, d_err);
   mark();
-  hipLaunchKernelGGL(tg::lambda_kernel, blocks(n, 64), dim3(64), 0, st, d_ios, K, aa, ab, n, sv, row_op, d_out, d_err);
+  hipLaunchKernelGGL(tg::lambda_kernel<E>, blocks(n, 64), dim3(64), 0, st, d_ios, K, aa, ab, n, sv, row_op, d_out, d_err);
   mark();
-  hipLaunchKernelGGL(tg::row_witness_kernel, blocks(n, 128), dim3(128), 0, st, sv, row_op, n, sh.gadget_col, P->d_trace, d_err);
+  hipLaunchKernelGGL(tg::row_witness_kernel<E>, blocks(n, 128), dim3(128), 0, st, sv, row_op, n, sh.gadget_col, P->d_trace, d_err);
   mark();
   hipLaunchKernelGGL(tg::range_check_kernel, dim3((unsigned)sh.num_rc), dim3(tg::RC_THREADS), tg::RC_LDS_BYTES, st, P->d_trace, n, sh.rc_start, sh.start_lookups, d_err);
   mark();
   HIPC(hipGetLastError());
-  std::vector<u64> out(16 * K); int err = 0;
-  HIPC(hipMemcpyAsync(out.data(), d_out, 16 * K * sizeof(u64), hipMemcpyDeviceToHost, st));
+  std::vector<u64> out(16 * E * K); int err = 0;
+  HIPC(hipMemcpyAsync(out.data(), d_out, out.size() * sizeof(u64), hipMemcpyDeviceToHost, st));
   HIPC(hipMemcpyAsync(&err, d_err, sizeof(int), hipMemcpyDeviceToHost, st));
   HIPC(hipEventRecord(e1, st));
   HIPC(hipStreamSynchronize(st));
@@ -501,20 +502,29 @@ extern "C" int sbn_prover_generate_trace(sbn_prover* P, const uint32_t* ios, siz
     for (auto e : kev) hipEventDestroy(e);
     fprintf(stderr, "[device tracegen] %-14s %8.3f ms\n", "total", ms);
   }
-  P->loaded = false;
   if (err & tg::TG_ERR_DEGENERATE) return fail(SBN_ERR_WITNESS, "degenerate affine operation (x1 == x2 or y == 0)");
   if (err & tg::TG_ERR_WITNESS) return fail(SBN_ERR_WITNESS, "modular witness generation failed");
   if (err & tg::TG_ERR_RANGE) return fail(SBN_ERR_WITNESS, "range-checked column holds a value >= 2^16");
-  // public inputs: x, offset, exp_val, output as u32 limbs (g1/exp.rs:124-135)
+  // public inputs: x, offset, exp_val, output as u32 limbs (g1/exp.rs:124-135, g2/exp.rs:139-156)
   P->pi.resize(P->air.npi);
   for (size_t k = 0; k < K; k++) {
     u64* p = P->pi.data() + (size_t)sh.pi_per_io * k;
-    for (int i = 0; i < 40; i++) p[i] = ios[40 * k + i];
-    for (int i = 0; i < 16; i++) p[40 + i] = out[16 * k + i];
+    for (size_t i = 0; i < IOW; i++) p[i] = ios[IOW * k + i];
+    for (int i = 0; i < 16 * E; i++) p[IOW + i] = out[16 * E * k + i];
   }
   if (pi_out) memcpy(pi_out, P->pi.data(), P->pi.size() * sizeof(u64));
   P->loaded = true;
   return SBN_OK;
+}
+
+extern "C" int sbn_prover_generate_trace(sbn_prover* P, const uint32_t* ios, size_t num_io, uint64_t* pi_out) {
+  if (!P || !ios) return fail(SBN_ERR_BAD_ARG, "null argument");
+  if (P->air.kind != SBN_AIR_G1_EXP && P->air.kind != SBN_AIR_G2_EXP)
+    return fail(SBN_ERR_UNSUPPORTED, "device witness generation covers G1ExpStark and G2ExpStark (use sbn_generate_trace_* + sbn_prover_load_trace)");
+  if (num_io != P->air.num_io) return fail(SBN_ERR_BAD_ARG, "prover was created for %u instances, got %zu", P->air.num_io, num_io);
+  if (P->n != 512 * num_io) return fail(SBN_ERR_BAD_ARG, "degree_bits does not match 512 rows per instance");
+  if (P->n != 65536) return fail(SBN_ERR_UNSUPPORTED, "device witness generation needs exactly 2^16 rows (u16 histogram in LDS)");
+  return P->air.kind == SBN_AIR_G1_EXP ? generate_trace_device<1>(P, ios, num_io, pi_out) : generate_trace_device<2>(P, ios, num_io, pi_out);
 }
 
 extern "C" int sbn_prover_read_trace(sbn_prover* P, uint64_t* out) {

@@ -41,70 +41,8 @@ void batch_inv(std::vector<Fq>& v) {
   for (size_t i = n; i-- > 0;) { Fq t = v[i]; v[i] = mmul(inv, pre[i]); inv = mmul(inv, t); }
 }
 
-// Fq2 limb product (src/fields/fq2.rs:41-58): c0 = x0*y0 - x1*y1, c1 = x0*y1 + x1*y0.
-inline void conv16_fq2(const int64_t x[2][16], const int64_t y[2][16], int64_t out[2][31]) {
-  int64_t t[31];
-  conv16(x[0], y[0], out[0]); conv16(x[1], y[1], t); for (int k = 0; k < 31; k++) out[0][k] -= t[k];
-  conv16(x[0], y[1], out[1]); conv16(x[1], y[0], t); for (int k = 0; k < 31; k++) out[1][k] += t[k];
-}
-// Writes the 640 G2Output columns (src/curves/g2/muladd.rs:56-80) for one add / double.
-// Each value is an Fq2 given as two standard-form Fq (c0 = v, c1 = v + 4).
-bool g2_output_row(bool is_double, const u64* ax, const u64* ay, const u64* bx, const u64* by, const u64* lam, const u64* nx, const u64* ny, u64* lv) {
-  int64_t l[2][16], axl[2][16], ayl[2][16], bxl[2][16], byl[2][16], nxl[2][16], nyl[2][16], t16[2][16];
-  int64_t zero_pol[2][31], inx[2][31], iny[2][31], c[2][31];
-  for (int q = 0; q < 2; q++) {
-    limbs16(lam + 4 * q, l[q]); limbs16(ax + 4 * q, axl[q]); limbs16(ay + 4 * q, ayl[q]); limbs16(nx + 4 * q, nxl[q]); limbs16(ny + 4 * q, nyl[q]);
-    if (is_double) { memcpy(bxl[q], axl[q], sizeof axl[q]); memcpy(byl[q], ayl[q], sizeof ayl[q]); } else { limbs16(bx + 4 * q, bxl[q]); limbs16(by + 4 * q, byl[q]); }
-  }
-  if (is_double) {
-    conv16_fq2(l, ayl, zero_pol); conv16_fq2(axl, axl, c);
-    for (int q = 0; q < 2; q++) for (int k = 0; k < 31; k++) zero_pol[q][k] = 2 * zero_pol[q][k] - 3 * c[q][k];
-  } else {
-    for (int q = 0; q < 2; q++) for (int i = 0; i < 16; i++) t16[q][i] = bxl[q][i] - axl[q][i];
-    conv16_fq2(l, t16, zero_pol);
-    for (int q = 0; q < 2; q++) for (int i = 0; i < 16; i++) zero_pol[q][i] -= byl[q][i] - ayl[q][i];
-  }
-  conv16_fq2(l, l, inx);
-  for (int q = 0; q < 2; q++) for (int i = 0; i < 16; i++) inx[q][i] -= axl[q][i] + bxl[q][i];
-  for (int q = 0; q < 2; q++) for (int i = 0; i < 16; i++) t16[q][i] = axl[q][i] - nxl[q][i];
-  conv16_fq2(l, t16, iny);
-  for (int q = 0; q < 2; q++) for (int i = 0; i < 16; i++) iny[q][i] -= ayl[q][i];
-  ModW wz[2], wx[2], wy[2];
-  for (int q = 0; q < 2; q++)
-    if (!mod_witness(zero_pol[q], nullptr, false, wz[q]) || !mod_witness(inx[q], nx + 4 * q, true, wx[q]) || !mod_witness(iny[q], ny + 4 * q, true, wy[q])) return false;
-  int cur = 0;
-  auto put16 = [&](const int64_t* v) { for (int i = 0; i < 16; i++) lv[cur++] = (u64)v[i]; };
-  for (int q = 0; q < 2; q++) put16(l[q]);
-  for (int q = 0; q < 2; q++) put16(nxl[q]);
-  for (int q = 0; q < 2; q++) put16(nyl[q]);
-  auto put_aux = [&](const ModW& w, bool oar) {
-    if (oar) put16(w.out_aux_red);
-    for (int i = 0; i < 17; i++) lv[cur++] = (u64)w.quot_abs[i];
-    for (int i = 0; i < 31; i++) lv[cur++] = (u64)w.aux_lo[i];
-    for (int i = 0; i < 31; i++) lv[cur++] = (u64)w.aux_hi[i];
-  };
-  for (int q = 0; q < 2; q++) put_aux(wz[q], false);
-  for (int q = 0; q < 2; q++) put_aux(wx[q], true);
-  for (int q = 0; q < 2; q++) put_aux(wy[q], true);
-  for (int q = 0; q < 2; q++) lv[cur++] = wz[q].sign > 0 ? 1 : GLP - 1;
-  for (int q = 0; q < 2; q++) lv[cur++] = wx[q].sign > 0 ? 1 : GLP - 1;
-  for (int q = 0; q < 2; q++) lv[cur++] = wy[q].sign > 0 ? 1 : GLP - 1;
-  return cur == 640;
-}
-
-// Coordinate arithmetic for the lockstep curve loop: E = 1 -> Fq, E = 2 -> Fq2 = Fq[i]/(i^2+1).
-template <int E> struct Co { Fq c[E]; };
-template <int E> inline Co<E> cadd(const Co<E>& a, const Co<E>& b) { Co<E> r; for (int q = 0; q < E; q++) r.c[q] = fadd(a.c[q], b.c[q]); return r; }
-template <int E> inline Co<E> csub(const Co<E>& a, const Co<E>& b) { Co<E> r; for (int q = 0; q < E; q++) r.c[q] = fsub(a.c[q], b.c[q]); return r; }
-inline Co<1> cmul(const Co<1>& a, const Co<1>& b) { Co<1> r; r.c[0] = mmul(a.c[0], b.c[0]); return r; }
-inline Co<2> cmul(const Co<2>& a, const Co<2>& b) {
-  Co<2> r;
-  r.c[0] = fsub(mmul(a.c[0], b.c[0]), mmul(a.c[1], b.c[1]));
-  r.c[1] = fadd(mmul(a.c[0], b.c[1]), mmul(a.c[1], b.c[0]));
-  return r;
-}
-template <int E> inline bool czero(const Co<E>& a) { for (int q = 0; q < E; q++) if (!fzero(a.c[q])) return false; return true; }
 // batch inversion: E = 1 directly; E = 2 through the norms a^2 + b^2 (one Fq inversion for the whole batch)
+// (Co<E>, cadd/csub/cmul/czero, conv16_fq2 and g2_output_row live in bn254w.cuh, shared with the device generator)
 inline void cbatch_inv(std::vector<Co<1>>& v) { std::vector<Fq> t(v.size()); for (size_t i = 0; i < v.size(); i++) t[i] = v[i].c[0]; batch_inv(t); for (size_t i = 0; i < v.size(); i++) v[i].c[0] = t[i]; }
 inline void cbatch_inv(std::vector<Co<2>>& v) {
   std::vector<Fq> nrm(v.size());
@@ -261,11 +199,12 @@ static bool fill_split_range_check(uint64_t* trace, size_t n, int table_col, int
 }
 
 // Both curve chains of every instance on host threads (the sequential 0.1% of witness generation; the device does the
-// rest, see sbn_prover_generate_trace).  ja / jb: [K][257][3][4] u64 (bn254w.cuh jac_at).
+// rest, see sbn_prover_generate_trace).  ja / jb: [K][257][3][E][4] u64 (bn254w.cuh jac_at).
 namespace sbn {
-int tracegen_host_chains(const uint32_t* ios, size_t K, u64* ja, u64* jb) {
+int tracegen_host_chains(int E, const uint32_t* ios, size_t K, u64* ja, u64* jb) {
   std::atomic<int> bad(0);
-  parallel_for(K, [&](size_t k) { int b = g1_chains(ios + 40 * k, k, ja, jb); if (b) bad |= b; });
+  const size_t iow = 8 * (4 * (size_t)E + 1);
+  parallel_for(K, [&](size_t k) { int b = E == 1 ? exp_chains<1>(ios + iow * k, k, ja, jb) : exp_chains<2>(ios + iow * k, k, ja, jb); if (b) bad |= b; });
   return bad.load();
 }
 }  // namespace sbn

@@ -213,6 +213,36 @@ def test_g2exp_proof_matches_oracle_digest_and_verifies(gpu, O, g2exp_case, gold
         gpu.verify_stark_proof(stark, gpu.Proof(t, 16), cfg)
 
 
+def test_g2exp_device_witness_generation_matches_oracle(gpu, O, g2exp_case, golden):
+    """G2ExpStark::generate_trace on the device (src/curves/g2/exp.rs:271-342): trace and public inputs equal the CPU
+    oracle's word for word; proving straight from the device-resident trace gives the committed proof digest."""
+    stark = gpu.G2ExpStark(128)
+    cfg = stark.config()
+    prover = gpu.Prover(stark, cfg, 16)
+    try:
+        pi = prover.generate_trace(g2exp_case["ios"])
+        assert np.array_equal(pi, g2exp_case["pi"])
+        dev = prover.read_trace()
+        bad = np.nonzero((dev != g2exp_case["trace"]).any(axis=1))[0]
+        assert bad.size == 0, f"first differing columns: {bad[:8].tolist()}"
+        proof = prover.prove()
+        assert hashlib.sha256(proof.to_bytes()).hexdigest() == golden["proof_digests"]["g2exp_io128_seed2"]["proof_sha256"]
+        ios = g2exp_case["ios"].copy()
+        ios[:, 64:72] = 0                                          # exp_val = 0 everywhere but one instance
+        ios[7, 64:72] = 0xFFFFFFFF
+        pi2 = prover.generate_trace(ios)
+        t_host, pi_host = stark.generate_trace_and_public_inputs(ios)
+        assert np.array_equal(pi2, pi_host)
+        assert np.array_equal(prover.read_trace(), t_host)
+        ios[5, 32:64] = ios[5, 0:32]                               # offset == x with bit 0 set: x1 == x2 in the first add
+        ios[5, 64] = 1
+        with pytest.raises(gpu.SbnError) as e:
+            prover.generate_trace(ios)
+        assert e.value.code == -8
+    finally:
+        prover.close()
+
+
 def test_fq12exp_proof_matches_oracle_digest_and_verifies(gpu, O, fq12exp_case, golden):
     """Fq12ExpStark(16) (the reference's test_fq12_exp_raw size, 2^13 rows x 9802 columns, split range check):
     GPU proof bytes == the CPU oracle's (committed sha256), both verifiers accept, tampering rejected."""
