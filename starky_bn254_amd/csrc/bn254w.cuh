@@ -237,6 +237,58 @@ GL_HD bool g2_output_row(bool is_double, const u64* ax, const u64* ay, const u64
   return cur == 640;
 }
 
+// ---- Fq12 (flat basis of plonky2-bn254 MyFq12: coefficient of w^k is c[k] + c[k+6] i, w^6 = 9 + i) ------------------------
+// flat-basis product (src/fields/fq12/mul.rs:24-87) in Montgomery Fq
+GL_HD void fq12_mul_m(const Fq* a, const Fq* b, Fq* out) {
+  Fq z = {{0, 0, 0, 0}}, d[11], s[11];
+  for (int m = 0; m < 11; m++) { d[m] = z; s[m] = z; }
+  for (int i = 0; i < 6; i++)
+    for (int j = 0; j < 6; j++) {
+      d[i + j] = fadd(d[i + j], fsub(mmul(a[i], b[j]), mmul(a[i + 6], b[j + 6])));
+      s[i + j] = fadd(s[i + j], fadd(mmul(a[i], b[j + 6]), mmul(a[i + 6], b[j])));
+    }
+  for (int m = 0; m < 6; m++) {
+    if (m < 5) {
+      Fq t = fadd(d[m + 6], d[m + 6]); t = fadd(t, t); t = fadd(t, t); const Fq d9 = fadd(t, d[m + 6]);
+      t = fadd(s[m + 6], s[m + 6]); t = fadd(t, t); t = fadd(t, t); const Fq s9 = fadd(t, s[m + 6]);
+      out[m] = fsub(fadd(d[m], d9), s[m + 6]); out[m + 6] = fadd(fadd(s[m], d[m + 6]), s9);
+    } else { out[m] = d[m]; out[m + 6] = s[m]; }
+  }
+}
+// Fq12Output columns (mul.rs:217-231) of x*y given the product `out` (standard form): 1344 words, handed one by one to
+// put(index, value) -- the host writes them into a row buffer, the device straight into the column-major trace.
+template <typename Put>
+GL_HD bool fq12_output_row(const u64 (*x)[4], const u64 (*y)[4], const u64 (*out)[4], Put put) {
+  int64_t xl[12][16], yl[12][16], d[11][31], s[11][31], t[31];
+  for (int c = 0; c < 12; c++) { limbs16(x[c], xl[c]); limbs16(y[c], yl[c]); }
+  for (int m = 0; m < 11; m++) for (int k = 0; k < 31; k++) { d[m][k] = 0; s[m][k] = 0; }
+  for (int i = 0; i < 6; i++)
+    for (int j = 0; j < 6; j++) {
+      conv16(xl[i], yl[j], t); for (int k = 0; k < 31; k++) d[i + j][k] += t[k];
+      conv16(xl[i + 6], yl[j + 6], t); for (int k = 0; k < 31; k++) d[i + j][k] -= t[k];
+      conv16(xl[i], yl[j + 6], t); for (int k = 0; k < 31; k++) s[i + j][k] += t[k];
+      conv16(xl[i + 6], yl[j], t); for (int k = 0; k < 31; k++) s[i + j][k] += t[k];
+    }
+  for (int c = 0; c < 12; c++) {
+    const int m = c < 6 ? c : c - 6;
+    for (int k = 0; k < 31; k++) {
+      if (m < 5) t[k] = c < 6 ? d[m][k] + 9 * d[m + 6][k] - s[m + 6][k] : s[m][k] + d[m + 6][k] + 9 * s[m + 6][k];
+      else t[k] = c < 6 ? d[m][k] : s[m][k];
+    }
+    ModW w;
+    if (!mod_witness(t, out[c], true, w)) return false;
+    int64_t ol[16]; limbs16(out[c], ol);
+    for (int i = 0; i < 16; i++) put(16 * c + i, (u64)ol[i]);
+    int cur = 192 + 95 * c;
+    for (int i = 0; i < 16; i++) put(cur++, (u64)w.out_aux_red[i]);
+    for (int i = 0; i < 17; i++) put(cur++, (u64)w.quot_abs[i]);
+    for (int i = 0; i < 31; i++) put(cur++, (u64)w.aux_lo[i]);
+    for (int i = 0; i < 31; i++) put(cur++, (u64)w.aux_hi[i]);
+    put(1332 + c, w.sign > 0 ? (u64)1 : GLP - 1);
+  }
+  return true;
+}
+
 // ---- curve chains of one G1ExpStark / G2ExpStark instance -----------------------------------------------------------------
 // Coordinates: E = 1 -> Fq, E = 2 -> Fq2 = Fq[i]/(i^2+1), Montgomery form.
 template <int E> struct Co { Fq c[E]; };

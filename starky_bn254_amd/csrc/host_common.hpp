@@ -86,6 +86,8 @@ static inline bool config_supported(const sbn_config* c) {
 
 // tracegen.hip: Jacobian curve chains of every G1ExpStark instance on host threads (layout: bn254w.cuh g1_chains)
 int tracegen_host_chains(int E, const uint32_t* ios, size_t K, u64* ja, u64* jb);
+// tracegen.hip: square-and-multiply chains of every Fq12ExpStark instance, standard form, [K][257][12][4] each
+int tracegen_host_chains_fq12(const uint32_t* ios, size_t K, u64* ca, u64* cb);
 
 }  // namespace sbn
 

@@ -172,14 +172,14 @@ __global__ void small_inverse_kernel(u64* __restrict__ inv, size_t n) {
 }
 
 // periodic pulse (pulse.rs:100-144) + io-pulse counter, and the lookup table column (range_check.rs:20-47).
-__global__ void periodic_kernel(const u64* __restrict__ inv, size_t n, int start_periodic, int start_io_pulses, int start_lookups, u64* __restrict__ trace) {
+__global__ void periodic_kernel(const u64* __restrict__ inv, size_t n, int start_periodic, int start_io_pulses, int start_lookups, u64 table_max, u64* __restrict__ trace) {
   const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (i >= n) return;
   const u64 c = (i + 1) & 63;
   trace[(size_t)start_periodic * n + i] = c;
   trace[(size_t)(start_periodic + 1) * n + i] = c == 63 ? 0 : (-F(inv[63 - c])).v;
   trace[(size_t)start_io_pulses * n + i] = i;
-  trace[(size_t)start_lookups * n + i] = i < 65536 ? i : 65535;
+  trace[(size_t)start_lookups * n + i] = i < table_max ? i : table_max;  // 0..table_max then table_max repeated
 }
 // io pulses (pulse.rs:20-43): pulse q sits at row pos(q) = 512*(q/2) + (q odd ? 511 : 0); witness = 1/(i - pos).
 __global__ void io_pulse_kernel(const u64* __restrict__ inv, size_t n, int first_col, u64* __restrict__ trace) {
@@ -190,6 +190,110 @@ __global__ void io_pulse_kernel(const u64* __restrict__ inv, size_t n, int first
   u64* w = trace + (size_t)(first_col + 2 * q) * n;  // witness_col(q); pulse_col(q) = witness_col(q) + 1
   w[i] = i > pos ? inv[i - pos] : (i < pos ? (-F(inv[pos - i])).v : 0);
   w[n + i] = i == pos;
+}
+
+// ---- Fq12ExpStark rows (src/fields/fq12/exp.rs:229-319) -----------------------------------------------------------------
+// One lane per row.  ca / cb: the square-and-multiply chains of every instance in standard form, [K][257][12][4]
+// (A[t] = x^(2^t), B[t]); row r of instance k: a = A[r>>1]; even rows: b = B[r>>1], multiply when the bit is set
+// (product B[(r>>1)+1]); odd rows: b = B[(r>>1)+1], square (product A[(r>>1)+1]).  Writes the 384 limb columns of
+// a and b and the 1344 Fq12Output columns (mul.rs:217-231) straight into the column-major trace.
+__global__ void __launch_bounds__(64) fq12_row_kernel(const uint32_t* __restrict__ ios, const u64* __restrict__ ca, const u64* __restrict__ cb, size_t n,
+                                                      u64* __restrict__ trace, int* __restrict__ err) {
+  const size_t row = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (row >= n) return;
+  const size_t k = row >> 9; const int r = (int)(row & 511), t = r >> 1; const bool sq = r & 1;
+  const bool bit = (ios[200 * k + 192 + (t >> 5)] >> (t & 31)) & 1;
+  const int op = sq ? 1 : (bit ? 2 : 0);  // 1 square, 2 multiply
+  const u64 (*a)[4] = reinterpret_cast<const u64 (*)[4]>(ca + ((k * 257 + t) * 12) * 4);
+  const u64 (*b)[4] = reinterpret_cast<const u64 (*)[4]>(cb + ((k * 257 + t + (sq ? 1 : 0)) * 12) * 4);
+  for (int c = 0; c < 12; c++)
+    for (int i = 0; i < 16; i++) {
+      trace[(size_t)(16 * c + i) * n + row] = (a[c][i >> 2] >> (16 * (i & 3))) & 0xffff;
+      trace[(size_t)(192 + 16 * c + i) * n + row] = (b[c][i >> 2] >> (16 * (i & 3))) & 0xffff;
+    }
+  u64* g = trace + (size_t)384 * n + row;
+  if (op) {
+    const u64 (*prod)[4] = reinterpret_cast<const u64 (*)[4]>((op == 1 ? ca : cb) + ((k * 257 + t + 1) * 12) * 4);
+    if (!fq12_output_row(a, op == 1 ? a : b, prod, [&](int i, u64 v) { g[(size_t)i * n] = v; })) atomicOr(err, TG_ERR_WITNESS);
+  } else {  // Fq12Output::default (mul.rs:179-187)
+    for (int i = 0; i < 1332; i++) g[(size_t)i * n] = 0;
+    for (int i = 1332; i < 1344; i++) g[(size_t)i * n] = 1;
+  }
+}
+
+// ---- split range check (range_check.rs:116-160): table 0..255 then 255 repeated; per target column the low and the high
+// byte, each with its sorted column and permuted table (lookup.rs:60-111).  One workgroup of 256 lanes per target.
+// With 256 distinct values the reference's merge is simulated value by value by one lane (push a missing value; the
+// first occurrence of a present value takes its table entry, repeats pop the pool or are deferred; repeats of 255 keep
+// matching the table's tail of 255s), then every sorted slot is classified independently from the per-value records.
+__global__ void __launch_bounds__(256) split_range_check_kernel(u64* __restrict__ trace, size_t n, int first_target, int table_col, int* __restrict__ err) {
+  __shared__ unsigned hist[2][256], tincl[256], npop[256], pbase[256], defbase[256];
+  __shared__ unsigned char pool[256], poplist[256];
+  __shared__ unsigned misc[8];
+  const int tid = threadIdx.x, kcol = blockIdx.x;
+  const u64* col = trace + (size_t)(first_target + kcol) * n;
+  u64* base = trace + (size_t)(table_col + 1 + 6 * kcol) * n;  // lo, sorted lo, perm lo, hi, sorted hi, perm hi
+  hist[0][tid] = 0; hist[1][tid] = 0;
+  __syncthreads();
+  bool bad = false;
+  for (size_t i = tid; i < n; i += 256) {
+    const u64 v = col[i];
+    if (v >= 65536) { bad = true; continue; }
+    const unsigned lo = (unsigned)v & 255, hi = (unsigned)v >> 8;
+    base[i] = lo; base[3 * n + i] = hi;
+    atomicAdd(&hist[0][lo], 1u); atomicAdd(&hist[1][hi], 1u);
+  }
+  if (bad) atomicOr(err, TG_ERR_RANGE);
+  __syncthreads();
+  for (int h = 0; h < 2; h++) {
+    u64* sorted_out = base + (size_t)(3 * h + 1) * n;
+    u64* perm_out = sorted_out + n;
+    // inclusive prefix counts
+    unsigned incl = hist[h][tid];
+    for (int o = 1; o < 64; o <<= 1) { unsigned t = __shfl_up(incl, o, 64); if ((tid & 63) >= o) incl += t; }
+    if ((tid & 63) == 63) misc[tid >> 6] = incl;
+    __syncthreads();
+    for (int w = 0; w < (tid >> 6); w++) incl += misc[w];
+    tincl[tid] = incl;
+    __syncthreads();
+    if (tid == 0) {
+      unsigned sp = 0, npl = 0, ndef = 0;
+      for (int v = 0; v < 255; v++) {
+        const unsigned c = hist[h][v];
+        npop[v] = 0; pbase[v] = npl; defbase[v] = ndef;
+        if (c == 0) { pool[sp++] = (unsigned char)v; continue; }
+        const unsigned k = c - 1 < sp ? c - 1 : sp;
+        for (unsigned j = 0; j < k; j++) poplist[npl++] = pool[--sp];
+        npop[v] = k; ndef += c - 1 - k;
+      }
+      const unsigned c255 = hist[h][255];
+      const size_t tail = n - 255;             // table entries equal to 255
+      npop[255] = 0; pbase[255] = npl; defbase[255] = ndef;
+      if (c255 > tail) ndef += (unsigned)(c255 - tail);
+      misc[4] = sp; misc[5] = ndef;
+    }
+    __syncthreads();
+    const unsigned sp = misc[4];
+    const size_t tail = n - 255;
+    for (size_t i = tid; i < n; i += 256) {
+      // value of sorted slot i: first v with tincl[v] > i
+      int lo = 0, hi = 255;
+      while (lo < hi) { const int mid = (lo + hi) >> 1; if (tincl[mid] > i) hi = mid; else lo = mid + 1; }
+      const int v = lo;
+      const size_t d = i - (tincl[v] - hist[h][v]);
+      unsigned out;
+      if (v < 255) {
+        if (d == 0) out = v;
+        else if (d <= npop[v]) out = poplist[pbase[v] + d - 1];
+        else { const unsigned rank = defbase[v] + (unsigned)(d - 1 - npop[v]); out = rank < sp ? pool[rank] : 255u; }
+      } else {
+        if (d < tail) out = 255u;
+        else { const unsigned rank = defbase[255] + (unsigned)(d - tail); out = rank < sp ? pool[rank] : 255u; }
+      }
+      sorted_out[i] = (u64)v; perm_out[i] = (u64)out;
+    }
+    __syncthreads();
+  }
 }
 
 // ---- u16 range check (range_check.rs:20-47, lookup.rs:60-111), n == 65536 ------------------------------------------

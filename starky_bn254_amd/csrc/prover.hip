@@ -463,7 +463,7 @@ static int generate_trace_device(sbn_prover* P, const uint32_t* ios, size_t K, u
   mark();
   hipLaunchKernelGGL(tg::flags_kernel, blocks(n, 256), dim3(256), 0, st, d_ios, IOW, n, sh.start_flags, P->d_trace);
   hipLaunchKernelGGL(tg::small_inverse_kernel, blocks(n, 256), dim3(256), 0, st, inv, n);
-  hipLaunchKernelGGL(tg::periodic_kernel, blocks(n, 256), dim3(256), 0, st, inv, n, sh.start_periodic, sh.start_io_pulses, sh.start_lookups, P->d_trace);
+  hipLaunchKernelGGL(tg::periodic_kernel, blocks(n, 256), dim3(256), 0, st, inv, n, sh.start_periodic, sh.start_io_pulses, sh.start_lookups, (u64)65535, P->d_trace);
   hipLaunchKernelGGL(tg::io_pulse_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)(2 * K)), dim3(256), 0, st, inv, n, sh.witness_col(0), P->d_trace);
   mark();
   // the two 256-step curve chains per instance: host threads while the device writes the input-independent columns
@@ -517,12 +517,91 @@ static int generate_trace_device(sbn_prover* P, const uint32_t* ios, size_t K, u
   return SBN_OK;
 }
 
+// Fq12ExpStark: the square-and-multiply chains (no inversion anywhere) on host threads in standard form, then one lane
+// per row for the limb columns and the twelve modular-gadget witnesses, and the split range check per target column.
+static int generate_trace_device_fq12(sbn_prover* P, const uint32_t* ios, size_t K, uint64_t* pi_out) {
+  const size_t n = P->n, IOW = 200;
+  for (size_t k = 0; k < K; k++)
+    for (int v = 0; v < 24; v++) {
+      u64 t[4]; for (int i = 0; i < 4; i++) t[i] = (u64)ios[IOW * k + 8 * v + 2 * i] | ((u64)ios[IOW * k + 8 * v + 2 * i + 1] << 32);
+      if (bnw::geq_p(t)) return fail(SBN_ERR_BAD_ARG, "coefficient >= p (instance %zu)", k);
+    }
+  HIPC(hipSetDevice(P->device));
+  hipStream_t st = P->stream;
+  const ExpShape sh = exp_shape(P->air);
+  P->loaded = false;
+  u64* w = P->d_lde;
+  auto take = [&](size_t words) { u64* r = w; w += (words + 7) & ~(size_t)7; return r; };
+  const size_t cw = 257 * 48 * K;  // one chain of every instance, standard form
+  u64* ca = take(cw); u64* cb = take(cw);
+  u64* inv = take(n);
+  uint32_t* d_ios = (uint32_t*)take(IOW * K / 2 + 1);
+  int* d_err = (int*)take(1);
+  if ((size_t)(w - P->d_lde) > P->air.ncols * P->m) return fail(SBN_ERR_UNSUPPORTED, "scratch does not fit");
+
+  const bool timing = getenv("SBN_TRACE_TIMING") != nullptr;
+  hipEvent_t e0 = P->abs_ev[0], e1 = P->abs_ev[1];
+  std::vector<hipEvent_t> kev;
+  auto mark = [&]() { if (timing) { hipEvent_t e; hipEventCreate(&e); hipEventRecord(e, st); kev.push_back(e); } };
+  HIPC(hipEventRecord(e0, st));
+  HIPC(hipMemcpyAsync(d_ios, ios, IOW * K * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+  HIPC(hipMemsetAsync(d_err, 0, sizeof(int), st));
+  auto blocks = [](size_t k, unsigned b) { return dim3((unsigned)((k + b - 1) / b)); };
+  mark();
+  hipLaunchKernelGGL(tg::flags_kernel, blocks(n, 256), dim3(256), 0, st, d_ios, IOW, n, sh.start_flags, P->d_trace);
+  hipLaunchKernelGGL(tg::small_inverse_kernel, blocks(n, 256), dim3(256), 0, st, inv, n);
+  hipLaunchKernelGGL(tg::periodic_kernel, blocks(n, 256), dim3(256), 0, st, inv, n, sh.start_periodic, sh.start_io_pulses, sh.start_lookups, (u64)255, P->d_trace);
+  hipLaunchKernelGGL(tg::io_pulse_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)(2 * K)), dim3(256), 0, st, inv, n, sh.witness_col(0), P->d_trace);
+  mark();
+  if (P->h_chain_words < 2 * cw) {
+    if (P->h_chain) (void)hipHostFree(P->h_chain);
+    P->h_chain = nullptr; P->h_chain_words = 0;
+    HIPC(hipHostMalloc((void**)&P->h_chain, 2 * cw * sizeof(u64), hipHostMallocDefault));
+    P->h_chain_words = 2 * cw;
+  }
+  tracegen_host_chains_fq12(ios, K, P->h_chain, P->h_chain + cw);
+  HIPC(hipMemcpyAsync(ca, P->h_chain, 2 * cw * sizeof(u64), hipMemcpyHostToDevice, st));  // ca and cb are adjacent
+  mark();
+  hipLaunchKernelGGL(tg::fq12_row_kernel, blocks(n, 64), dim3(64), 0, st, d_ios, ca, cb, n, P->d_trace, d_err);
+  mark();
+  hipLaunchKernelGGL(tg::split_range_check_kernel, dim3((unsigned)sh.num_rc), dim3(256), 0, st, P->d_trace, n, sh.rc_start, sh.start_lookups, d_err);
+  mark();
+  HIPC(hipGetLastError());
+  int err = 0;
+  HIPC(hipMemcpyAsync(&err, d_err, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPC(hipEventRecord(e1, st));
+  HIPC(hipStreamSynchronize(st));
+  float ms = 0; HIPC(hipEventElapsedTime(&ms, e0, e1));
+  P->stage_ms[ST_COUNT + EX_TRACEGEN_MS] = ms;
+  if (timing) {
+    static const char* names[] = {"flags+pulses", "chains", "row_witness", "range_check"};
+    for (size_t i = 0; i + 1 < kev.size(); i++) { float t = 0; hipEventElapsedTime(&t, kev[i], kev[i + 1]); fprintf(stderr, "[device tracegen] %-14s %8.3f ms\n", names[i], t); }
+    for (auto e : kev) hipEventDestroy(e);
+    fprintf(stderr, "[device tracegen] %-14s %8.3f ms\n", "total", ms);
+  }
+  if (err & tg::TG_ERR_WITNESS) return fail(SBN_ERR_WITNESS, "modular witness generation failed");
+  if (err & tg::TG_ERR_RANGE) return fail(SBN_ERR_WITNESS, "range-checked column holds a value >= 2^16");
+  // public inputs: x, offset as 16-bit limbs, exp_val, output = b at the last row (fq12/exp.rs:95-117)
+  P->pi.resize(P->air.npi);
+  for (size_t k = 0; k < K; k++) {
+    u64* p = P->pi.data() + (size_t)sh.pi_per_io * k;
+    for (int c = 0; c < 24; c++)
+      for (int i = 0; i < 16; i++) p[16 * c + i] = (ios[IOW * k + 8 * c + (i >> 1)] >> (16 * (i & 1))) & 0xffff;
+    for (int i = 0; i < 8; i++) p[384 + i] = ios[IOW * k + 192 + i];
+    const u64* out = P->h_chain + cw + ((k * 257 + 256) * 12) * 4;  // B[256]
+    for (int c = 0; c < 12; c++) for (int i = 0; i < 16; i++) p[392 + 16 * c + i] = (out[4 * c + (i >> 2)] >> (16 * (i & 3))) & 0xffff;
+  }
+  if (pi_out) memcpy(pi_out, P->pi.data(), P->pi.size() * sizeof(u64));
+  P->loaded = true;
+  return SBN_OK;
+}
+
 extern "C" int sbn_prover_generate_trace(sbn_prover* P, const uint32_t* ios, size_t num_io, uint64_t* pi_out) {
   if (!P || !ios) return fail(SBN_ERR_BAD_ARG, "null argument");
-  if (P->air.kind != SBN_AIR_G1_EXP && P->air.kind != SBN_AIR_G2_EXP)
-    return fail(SBN_ERR_UNSUPPORTED, "device witness generation covers G1ExpStark and G2ExpStark (use sbn_generate_trace_* + sbn_prover_load_trace)");
+  if (!is_exp_air(P->air.kind)) return fail(SBN_ERR_UNSUPPORTED, "device witness generation covers the Exp tables (use sbn_generate_trace_g1_op + sbn_prover_load_trace)");
   if (num_io != P->air.num_io) return fail(SBN_ERR_BAD_ARG, "prover was created for %u instances, got %zu", P->air.num_io, num_io);
   if (P->n != 512 * num_io) return fail(SBN_ERR_BAD_ARG, "degree_bits does not match 512 rows per instance");
+  if (P->air.kind == SBN_AIR_FQ12_EXP) return generate_trace_device_fq12(P, ios, num_io, pi_out);
   if (P->n != 65536) return fail(SBN_ERR_UNSUPPORTED, "device witness generation needs exactly 2^16 rows (u16 histogram in LDS)");
   return P->air.kind == SBN_AIR_G1_EXP ? generate_trace_device<1>(P, ios, num_io, pi_out) : generate_trace_device<2>(P, ios, num_io, pi_out);
 }

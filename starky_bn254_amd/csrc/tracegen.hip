@@ -363,53 +363,28 @@ extern "C" int sbn_generate_trace_g1_op(const uint32_t* pts, size_t rows, uint64
 }
 
 // ---- Fq12ExpStark (src/fields/fq12/exp.rs:229-319) --------------------------------------------------------------
-namespace {
-// flat-basis product (src/fields/fq12/mul.rs:24-87) in Montgomery Fq
-void fq12_mul_m(const Fq* a, const Fq* b, Fq* out) {
-  Fq z = {{0, 0, 0, 0}}, d[11], s[11];
-  for (int m = 0; m < 11; m++) { d[m] = z; s[m] = z; }
-  for (int i = 0; i < 6; i++)
-    for (int j = 0; j < 6; j++) {
-      d[i + j] = fadd(d[i + j], fsub(mmul(a[i], b[j]), mmul(a[i + 6], b[j + 6])));
-      s[i + j] = fadd(s[i + j], fadd(mmul(a[i], b[j + 6]), mmul(a[i + 6], b[j])));
+// (fq12_mul_m and fq12_output_row live in bn254w.cuh, shared with the device generator)
+
+// Square-and-multiply chains of every Fq12ExpStark instance on host threads, in standard form:
+// A[t] = x^(2^t), B[0] = offset, B[t+1] = bit_t ? A[t] * B[t] : B[t]  (fq12/exp.rs:165-221: even rows multiply when the
+// bit is set, odd rows square).  ca / cb: [K][257][12][4] u64.
+namespace sbn {
+int tracegen_host_chains_fq12(const uint32_t* ios, size_t K, u64* ca, u64* cb) {
+  parallel_for(K, [&](size_t k) {
+    const uint32_t* io = ios + 200 * k;
+    Fq a[12], b[12], prod[12];
+    for (int c = 0; c < 12; c++) { u64 t[4]; u32x8_to_u64x4(io + 8 * c, t); a[c] = to_m(t); u32x8_to_u64x4(io + 96 + 8 * c, t); b[c] = to_m(t); }
+    for (int t = 0;; t++) {
+      u64* pa = ca + ((k * 257 + t) * 12) * 4; u64* pb = cb + ((k * 257 + t) * 12) * 4;
+      for (int c = 0; c < 12; c++) { from_m(a[c], pa + 4 * c); from_m(b[c], pb + 4 * c); }
+      if (t == 256) break;
+      if ((io[192 + (t >> 5)] >> (t & 31)) & 1) { fq12_mul_m(a, b, prod); memcpy(b, prod, sizeof b); }
+      fq12_mul_m(a, a, prod); memcpy(a, prod, sizeof a);
     }
-  auto x9 = [&](const Fq& v) { Fq t = fadd(v, v); t = fadd(t, t); t = fadd(t, t); return fadd(t, v); };
-  for (int m = 0; m < 6; m++) {
-    if (m < 5) { out[m] = fsub(fadd(d[m], x9(d[m + 6])), s[m + 6]); out[m + 6] = fadd(fadd(s[m], d[m + 6]), x9(s[m + 6])); }
-    else { out[m] = d[m]; out[m + 6] = s[m]; }
-  }
+  });
+  return 0;
 }
-// Fq12Output columns (mul.rs:217-231) of x*y given the product `out` (standard form): 1344 words
-bool fq12_output_row(const u64 x[12][4], const u64 y[12][4], const u64 out[12][4], u64* lv) {
-  static thread_local int64_t xl[12][16], yl[12][16], d[11][31], s[11][31], t[31], in[12][31];
-  for (int c = 0; c < 12; c++) { limbs16(x[c], xl[c]); limbs16(y[c], yl[c]); }
-  memset(d, 0, sizeof d); memset(s, 0, sizeof s);
-  for (int i = 0; i < 6; i++)
-    for (int j = 0; j < 6; j++) {
-      conv16(xl[i], yl[j], t); for (int k = 0; k < 31; k++) d[i + j][k] += t[k];
-      conv16(xl[i + 6], yl[j + 6], t); for (int k = 0; k < 31; k++) d[i + j][k] -= t[k];
-      conv16(xl[i], yl[j + 6], t); for (int k = 0; k < 31; k++) s[i + j][k] += t[k];
-      conv16(xl[i + 6], yl[j], t); for (int k = 0; k < 31; k++) s[i + j][k] += t[k];
-    }
-  for (int m = 0; m < 6; m++)
-    for (int k = 0; k < 31; k++) {
-      if (m < 5) { in[m][k] = d[m][k] + 9 * d[m + 6][k] - s[m + 6][k]; in[m + 6][k] = s[m][k] + d[m + 6][k] + 9 * s[m + 6][k]; }
-      else { in[m][k] = d[m][k]; in[m + 6][k] = s[m][k]; }
-    }
-  ModW w[12];
-  for (int c = 0; c < 12; c++) if (!mod_witness(in[c], out[c], true, w[c])) return false;
-  int cur = 0;
-  for (int c = 0; c < 12; c++) { int64_t ol[16]; limbs16(out[c], ol); for (int i = 0; i < 16; i++) lv[cur++] = (u64)ol[i]; }
-  for (int c = 0; c < 12; c++) {
-    for (int i = 0; i < 16; i++) lv[cur++] = (u64)w[c].out_aux_red[i];
-    for (int i = 0; i < 17; i++) lv[cur++] = (u64)w[c].quot_abs[i];
-    for (int i = 0; i < 31; i++) lv[cur++] = (u64)w[c].aux_lo[i];
-    for (int i = 0; i < 31; i++) lv[cur++] = (u64)w[c].aux_hi[i];
-  }
-  for (int c = 0; c < 12; c++) lv[cur++] = w[c].sign > 0 ? 1 : GLP - 1;
-  return cur == 1344;
-}
-}  // namespace
+}  // namespace sbn
 
 extern "C" int sbn_generate_trace_fq12_exp(const uint32_t* ios, size_t num_io, uint64_t* trace, uint64_t* pi_out) {
   if (!ios || !trace || !pi_out || num_io == 0 || num_io > (size_t)G1EXP_MAX_IO || (num_io & (num_io - 1))) return fail(SBN_ERR_BAD_ARG, "bad arguments");
@@ -435,7 +410,7 @@ extern "C" int sbn_generate_trace_fq12_exp(const uint32_t* ios, size_t num_io, u
       if (op) {
         fq12_mul_m(a, op == 1 ? a : b, prod);
         for (int c = 0; c < 12; c++) from_m(prod[c], ps[c]);
-        if (!fq12_output_row(as, op == 1 ? as : bs, ps, lv.data())) { bad = 1; return; }
+        if (!fq12_output_row(as, op == 1 ? as : bs, ps, [&](int i, u64 v) { lv[i] = v; })) { bad = 1; return; }
       } else {  // Fq12Output::default (mul.rs:179-187)
         for (int i = 0; i < 1332; i++) lv[i] = 0;
         for (int i = 1332; i < 1344; i++) lv[i] = 1;

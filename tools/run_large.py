@@ -40,7 +40,18 @@ for it in range(3):
     print(f"# prove {it}: {times[-1]*1e3:.1f} ms", file=sys.stderr, flush=True)
 stages = prover.stage_times()
 t0 = time.time(); S.verify_stark_proof(stark, proof, cfg); t_ver = time.time() - t0
+# the same instances with the witness generated on the device: no host trace, no PCIe transfer of it
+dev = {}
+try:
+    prover.generate_trace(ios)                                   # warm-up (pinned staging buffer, worker pool)
+    t0 = time.time(); pi_dev = prover.generate_trace(ios); dev["device_tracegen_wall_ms"] = (time.time() - t0) * 1e3
+    dev["device_tracegen_gpu_ms"] = prover.stage_times()["device_tracegen_ms"]
+    t0 = time.time(); proof_dev = prover.prove(); dev["prove_ms"] = (time.time() - t0) * 1e3
+    dev["same_public_inputs"] = bool((pi_dev == pi).all())
+    dev["same_proof"] = bool((proof_dev.words == proof.words).all())
+except S.SbnError as e:
+    dev["unsupported"] = str(e)
 print(json.dumps({"table": type(stark).__name__, "num_io": num_io, "rows": 512 * num_io, "columns": stark.num_columns,
                   "public_inputs": stark.num_public_inputs, "trace_GB": trace.nbytes / 1e9, "tracegen_s": t_gen, "create_s": t_create,
                   "h2d_s": t_load, "prove_ms": [t * 1e3 for t in times], "verify_s": t_ver, "proof_words": int(len(proof.words)),
-                  "stage_ms": stages}))
+                  "stage_ms": stages, "device_witness": dev}))
