@@ -124,12 +124,12 @@ int sbn_prover_stage_times(const sbn_prover* p, float* ms_out, int cap);
 const char* sbn_prover_stage_name(int i);
 /* Raw device pointer of the loaded trace buffer (for callers that fill it on-device). */
 uint64_t* sbn_prover_trace_device_ptr(sbn_prover* p);
-/* Witness generation ON THE DEVICE, straight into the prover's trace buffer: G1ExpStark / G2ExpStark::generate_trace +
- * generate_public_inputs (src/curves/g1/exp.rs:255-327, src/curves/g2/exp.rs:271-342) without the trace ever crossing
- * PCIe.  Same `ios` layout and the same resulting trace / public inputs, bit for bit, as sbn_generate_trace_g1_exp /
- * sbn_generate_trace_g2_exp; afterwards the prover is loaded and sbn_prover_prove can run.  pi_out (optional):
- * [num_public_inputs].  G1_EXP and G2_EXP with 2^16 rows only (SBN_ERR_UNSUPPORTED otherwise: use the host
- * generators + sbn_prover_load_trace). */
+/* Witness generation ON THE DEVICE, straight into the prover's trace buffer: G1ExpStark / G2ExpStark / Fq12ExpStark
+ * ::generate_trace + generate_public_inputs (src/curves/g1/exp.rs:255-327, src/curves/g2/exp.rs:271-342,
+ * src/fields/fq12/exp.rs:283-319) without the trace ever crossing PCIe.  Same `ios` layout and the same resulting trace /
+ * public inputs, bit for bit, as sbn_generate_trace_{g1,g2,fq12}_exp; afterwards the prover is loaded and
+ * sbn_prover_prove can run.  pi_out (optional): [num_public_inputs].  G1_EXP / G2_EXP: tables of exactly 2^16 rows
+ * (SBN_ERR_UNSUPPORTED otherwise: use the host generators + sbn_prover_load_trace); FQ12_EXP: any size. */
 int sbn_prover_generate_trace(sbn_prover* p, const uint32_t* ios, size_t num_io, uint64_t* pi_out);
 /* Device -> host copy of the loaded trace, column-major [num_columns][N] (tests, debugging). */
 int sbn_prover_read_trace(sbn_prover* p, uint64_t* trace_out);

@@ -3,6 +3,7 @@ libsbn254.so and is compared bit-for-bit with the CPU oracle, the committed gold
 the full BASELINE size -- through size-independent properties (independent verifier accepts, tamper
 rejection, determinism)."""
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -148,6 +149,12 @@ def test_g1exp_device_witness_generation_matches_oracle(gpu, O, g1exp_case, g1ex
         t_host, pi_host = stark.generate_trace_and_public_inputs(ios)
         assert np.array_equal(pi2, pi_host)
         assert np.array_equal(prover.read_trace(), t_host)
+        os.environ["SBN_TRACEGEN_DEVICE_CHAIN"] = "1"              # the host-free variant: chains walked by chain_kernel
+        try:
+            assert np.array_equal(prover.generate_trace(ios), pi_host)
+            assert np.array_equal(prover.read_trace(), t_host)
+        finally:
+            del os.environ["SBN_TRACEGEN_DEVICE_CHAIN"]
         ios[5, 16:32] = ios[5, 0:16]                               # offset == x with bit 0 set: x1 == x2 in the first add
         ios[5, 32] = 1
         with pytest.raises(gpu.SbnError) as e:
