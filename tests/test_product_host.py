@@ -179,3 +179,21 @@ def test_fq12_shape_tracegen_and_power(S, O, fq12exp_case, golden):
         acc = O.eval_constraints(O.AIR_FQ12_EXP, 16, tr[:, i], tr[:, (i + 1) % n], pi, [0x1234567, 0x7654321],
                                  (x - pow(w, n - 1, P)) % P, int(i == 0), int(i == n - 1))
         assert acc == [0, 0], i
+
+
+def test_generated_tables_and_instruction_streams_are_current(tmp_path):
+    """Every committed *.inc under csrc/ (Poseidon constants, sparse partial-round tables, MDS / S-box / fold / multiply
+    instruction streams) is what its generator in tools/ produces; the generators check their own algebra
+    (rewritten partial rounds == plain permutation, plonky2 test vector) before writing."""
+    import subprocess
+    import sys
+    env = dict(os.environ, SBN_GEN_OUT=str(tmp_path))
+    for script in ("gen_poseidon_constants.py", "gen_poseidon_fast_partial.py", "gen_poseidon_mds_asm.py", "gen_poseidon_sbox_asm.py"):
+        subprocess.run([sys.executable, script], cwd=os.path.join(ROOT, "tools"), env=env, check=True, capture_output=True)
+    produced = sorted(os.listdir(tmp_path))
+    assert len(produced) >= 9
+    csrc = os.path.join(ROOT, "starky_bn254_amd", "csrc")
+    assert sorted(f for f in os.listdir(csrc) if f.endswith(".inc")) == produced
+    for f in produced:
+        assert open(os.path.join(tmp_path, f)).read() == open(os.path.join(csrc, f)).read(), f
+

@@ -128,7 +128,7 @@ for trial in range(20):
     assert permute_plain(st) == permute_fast(st), "rewritten partial rounds disagree with the plain permutation"
 assert permute_plain([0] * 12)[0] == 0x3c18a9786cb0b359      # plonky2 test vector (all-zero input)
 
-csrc = os.path.join(os.path.dirname(__file__), "..", "starky_bn254_amd", "csrc")
+csrc = os.environ.get("SBN_GEN_OUT") or os.path.join(os.path.dirname(__file__), "..", "starky_bn254_amd", "csrc")
 # (1) "effective" round constants: same shape as the plain table, partial rounds carry one scalar (device + host)
 eff = RC[:]
 eff[12 * 4:12 * 5] = first_const

@@ -24,7 +24,7 @@ interleaved streams provide them (a single stream pads with s_nop).
 """
 import os
 
-CSRC = os.path.join(os.path.dirname(__file__), "..", "starky_bn254_amd", "csrc")
+CSRC = os.environ.get("SBN_GEN_OUT") or os.path.join(os.path.dirname(__file__), "..", "starky_bn254_amd", "csrc")
 
 
 class Stream:
