@@ -207,7 +207,8 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                          "traffic": args.traffic_bytes, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": dom_ms,
-                         "note": "ALU-bound kernel (210 Poseidon permutations per row); see DESIGN.md"},
+                         "note": "ALU-bound kernel (210 Poseidon permutations per row); see DESIGN.md",
+                         "valu_issue": valu_issue(dom_ms)},
             "proof_roofline": {"algorithmic_bytes_per_proof": proof_alg_bytes,
                                "achieved_GBps": proof_alg_bytes / (ms_per_step * 1e-3) / 1e9,
                                "frac_of_hbm_peak": proof_alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
@@ -227,14 +228,29 @@ def main():
         dist.destroy_process_group()
 
 
-def committed_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the newest committed PMC summary (tools/summarize_pmc.py)."""
+def committed_pmc(kernel, key="hbm_bytes_per_launch_corrected"):
+    """A per-launch figure of `kernel` from the newest committed PMC summary (tools/summarize_pmc.py)."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
     if not files:
         return None
     d = json.load(open(files[-1]))
-    return d.get(kernel, {}).get("hbm_bytes_per_launch_corrected")
+    return d.get(kernel, {}).get(key)
+
+
+def committed_traffic(kernel):
+    return committed_pmc(kernel)
+
+
+def valu_issue(dom_ms):
+    """The bound this kernel actually runs against: VALU issue.  Wave-instructions per launch from the committed
+    SQ_INSTS_VALU pass; a wave64 VALU instruction occupies its SIMD for 4 cycles, 1,024 SIMDs at the 2.4 GHz peak clock."""
+    n = committed_pmc("leaf_absorb_kernel", "valu_wave_instructions_per_launch")
+    if not n or not dom_ms or dom_ms <= 0:
+        return None
+    peak = 1024 * 2.4e9 / 4
+    ach = n / (dom_ms * 1e-3)
+    return {"wave_instructions_per_launch": n, "achieved_per_s": ach, "peak_per_s": peak, "frac": ach / peak}
 
 
 def synthetic_ios(num_io, seed, table="g1"):
