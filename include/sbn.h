@@ -53,11 +53,13 @@ typedef enum sbn_status {
 
 /* Table kinds.  G1_OP = reference `G1Stark` (src/curves/g1/muladd.rs:462-624);
  * G1_EXP = reference `G1ExpStark` (src/curves/g1/exp.rs:232-742). */
-typedef enum sbn_air_kind { SBN_AIR_G1_OP = 1, SBN_AIR_G1_EXP = 2, SBN_AIR_G2_EXP = 3, SBN_AIR_FQ12_EXP = 4 } sbn_air_kind;
+typedef enum sbn_air_kind { SBN_AIR_G1_OP = 1, SBN_AIR_G1_EXP = 2, SBN_AIR_G2_EXP = 3, SBN_AIR_FQ12_EXP = 4, SBN_AIR_FQ_EXP = 5 } sbn_air_kind;
 /* G2_EXP = reference `G2ExpStark` (src/curves/g2/exp.rs:248-807): the same machine over Fq2 coordinates.
  * FQ12_EXP = reference `Fq12ExpStark` (src/fields/fq12/exp.rs:223-605): offset * x^e in Fq12 (flat basis of
  * plonky2-bn254 `MyFq12`: coefficient of w^k is c[k] + c[k+6]*i, w^6 = 9 + i), 512 rows per instance, num_io a
- * power of two between 1 and 512. */
+ * power of two between 1 and 512.
+ * FQ_EXP = reference `FqExpStark` (src/fields/fq/exp.rs:193-582): offset * x^e in the base field Fq, the same
+ * square-and-multiply machine over one coefficient (960 columns at num_io = 128), u32 public inputs, u16 range check. */
 
 typedef struct sbn_air_desc {
   int32_t kind;    /* sbn_air_kind */
@@ -106,6 +108,9 @@ int sbn_generate_trace_g2_exp(const uint32_t* ios, size_t num_io, uint64_t* trac
  * ios: num_io x 200 u32 = x[12] offset[12] (flat-basis coefficients, 8 u32 limbs each) exp_val[8];
  * trace_out: [num_columns][512*num_io]; pi_out: [584*num_io]. */
 int sbn_generate_trace_fq12_exp(const uint32_t* ios, size_t num_io, uint64_t* trace_out, uint64_t* pi_out);
+/* FqExpStark::generate_trace / generate_public_inputs (src/fields/fq/exp.rs:248-284).
+ * ios: num_io x 24 u32 = x[8] offset[8] exp_val[8]; trace_out: [num_columns][512*num_io]; pi_out: [32*num_io]. */
+int sbn_generate_trace_fq_exp(const uint32_t* ios, size_t num_io, uint64_t* trace_out, uint64_t* pi_out);
 /* pts: rows x 32 u32 = a.x[8] a.y[8] b.x[8] b.y[8]; trace_out: [num_columns][rows]. */
 int sbn_generate_trace_g1_op(const uint32_t* pts, size_t rows, uint64_t* trace_out);
 
@@ -124,12 +129,12 @@ int sbn_prover_stage_times(const sbn_prover* p, float* ms_out, int cap);
 const char* sbn_prover_stage_name(int i);
 /* Raw device pointer of the loaded trace buffer (for callers that fill it on-device). */
 uint64_t* sbn_prover_trace_device_ptr(sbn_prover* p);
-/* Witness generation ON THE DEVICE, straight into the prover's trace buffer: G1ExpStark / G2ExpStark / Fq12ExpStark
+/* Witness generation ON THE DEVICE, straight into the prover's trace buffer: G1ExpStark / G2ExpStark / Fq12ExpStark / FqExpStark
  * ::generate_trace + generate_public_inputs (src/curves/g1/exp.rs:255-327, src/curves/g2/exp.rs:271-342,
  * src/fields/fq12/exp.rs:283-319) without the trace ever crossing PCIe.  Same `ios` layout and the same resulting trace /
  * public inputs, bit for bit, as sbn_generate_trace_{g1,g2,fq12}_exp; afterwards the prover is loaded and
- * sbn_prover_prove can run.  pi_out (optional): [num_public_inputs].  G1_EXP / G2_EXP: tables of exactly 2^16 rows
- * (SBN_ERR_UNSUPPORTED otherwise: use the host generators + sbn_prover_load_trace); FQ12_EXP: any size. */
+ * sbn_prover_prove can run.  pi_out (optional): [num_public_inputs].  G1_EXP / G2_EXP / FQ_EXP: tables of exactly 2^16
+ * rows (SBN_ERR_UNSUPPORTED otherwise: use the host generators + sbn_prover_load_trace); FQ12_EXP: any size. */
 int sbn_prover_generate_trace(sbn_prover* p, const uint32_t* ios, size_t num_io, uint64_t* pi_out);
 /* Device -> host copy of the loaded trace, column-major [num_columns][N] (tests, debugging). */
 int sbn_prover_read_trace(sbn_prover* p, uint64_t* trace_out);

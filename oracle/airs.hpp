@@ -1100,4 +1100,151 @@ struct Fq12ExpAir : AirBase<Fq12ExpAir> {
   }
 };
 
+// ---- FqExpStark: src/fields/fq/exp.rs (offset * x^e in Fq by square-and-multiply; u16 range check) --------------------
+// FqOutput (src/fields/fq/mul.rs:18-22, column layout :49-54): output[16], ModulusAux (95), quot_sign = 7*N_LIMBS columns.
+template <class T> struct FqOutput { Arr<T, 16> output; ModulusAux<T> aux; T quot_sign; };
+static const int FQ_OUTPUT_COLS = 7 * N_LIMBS;
+template <class T> static inline FqOutput<T> read_fq_output(const T* lv, int& cur) {  // mul.rs:57-68
+  FqOutput<T> o;
+  o.output = read16(lv, cur);
+  o.aux.out_aux_red = read16(lv, cur); o.aux.quot_abs = readn<T, 17>(lv, cur); o.aux.aux_input_lo = readn<T, 31>(lv, cur); o.aux.aux_input_hi = readn<T, 31>(lv, cur);
+  o.quot_sign = lv[cur++];
+  return o;
+}
+template <class P>
+static inline void eval_fq_mul(Consumer<P>& yc, P filter, const Arr<P, 16>& x, const Arr<P, 16>& y, const FqOutput<P>& o) {  // mul.rs:70-88
+  eval_modular_op(yc, filter, bn254_modulus_p<P>(), pol_mul_wide(x, y), o.output, o.quot_sign, o.aux);
+}
+// generate_fq_mul (mul.rs:35-46) + write_fq_output: writes lv[0..112), returns the product limbs
+static inline void generate_fq_mul(const Arr<int64_t, 16>& x, const Arr<int64_t, 16>& y, GF* lv, Arr<int64_t, 16>& out) {
+  ModWitness w = generate_modular_witness(pol_mul_wide<int64_t>(x, y), false);
+  out = w.output;
+  int cur = 0;
+  for (int k = 0; k < 16; k++) lv[cur++] = GF((u64)w.output[k]);
+  write_mod_aux(lv, cur, w, true);
+  lv[cur++] = GF::from_i64(w.quot_sign);
+  assert(cur == FQ_OUTPUT_COLS);
+}
+static inline void write_fq_output_default(GF* lv) {  // FqOutput::default mul.rs:24-32
+  for (int i = 0; i < FQ_OUTPUT_COLS - 1; i++) lv[i] = GF();
+  lv[FQ_OUTPUT_COLS - 1] = GF::one();
+}
+struct FqExpIONative { U256 x, offset; uint32_t exp_val[NUM_INPUT_LIMBS]; U256 output; };  // exp.rs:89-94
+struct FqExpAir : AirBase<FqExpAir> {
+  size_t num_io;
+  int start_flags_col, num_main_cols, start_periodic_pulse_col, start_io_pulses_col, start_lookups_col, num_range_check_cols;  // exp.rs:6-34
+  size_t ncols, npi;
+  std::vector<size_t> pulse_positions;
+  static const int IO_LEN = 4 * NUM_INPUT_LIMBS;  // exp.rs:96
+  explicit FqExpAir(size_t n) : num_io(n) {
+    start_flags_col = 9 * N_LIMBS;
+    num_main_cols = start_flags_col + NUM_FLAGS_COLS;
+    start_periodic_pulse_col = num_main_cols;
+    start_io_pulses_col = start_periodic_pulse_col + 2;
+    start_lookups_col = start_io_pulses_col + 1 + 4 * (int)num_io;
+    num_range_check_cols = 9 * N_LIMBS - 1;
+    ncols = start_lookups_col + 1 + 2 * num_range_check_cols;
+    npi = IO_LEN * num_io;
+    size_t rpb = 2 * INPUT_LIMB_BITS * NUM_INPUT_LIMBS;
+    for (size_t i = 0; i < num_io; i++) { pulse_positions.push_back(i * rpb); pulse_positions.push_back(i * rpb + rpb - 1); }
+  }
+  size_t num_columns() const override { return ncols; }
+  size_t num_public_inputs() const override { return npi; }
+  std::vector<std::pair<size_t, size_t>> permutation_pairs() const override {  // exp.rs:574-580, range_check.rs:96-113
+    std::vector<std::pair<size_t, size_t>> p;
+    for (int i = 0; i < num_range_check_cols; i++) {
+      p.push_back({(size_t)start_lookups_col, (size_t)start_lookups_col + 1 + 2 * i + 1});
+      p.push_back({(size_t)i, (size_t)start_lookups_col + 1 + 2 * i});
+    }
+    return p;
+  }
+  template <class P> void eval_t(const P* lv, const P* nv, const P* pi, Consumer<P>& yc) const {  // exp.rs:288-394
+    int is_final_col = start_flags_col, is_sq_col = start_flags_col + 2, is_mul_col = start_flags_col + 4, start_limbs_col = start_flags_col + 6;
+    P one = cst<P>(1);
+    int cur = 0;
+    Arr<P, 16> a = read16(lv, cur), b = read16(lv, cur);
+    FqOutput<P> output = read_fq_output(lv, cur);
+    P is_mul = lv[is_mul_col], is_sq = lv[is_sq_col], is_final = lv[is_final_col];
+    P is_not_final = one - is_final;
+    P sum_is_output = P();
+    for (size_t i = 1; i < 2 * num_io; i += 2) sum_is_output = sum_is_output + lv[get_pulse_col(start_io_pulses_col, (int)i)];
+    yc.constraint(is_final - sum_is_output);
+    {  // public inputs :320-337 ; x offset exp_val output as 8 u32 limbs each (read_fq_exp_io :110-126)
+      Arr<P, 8> a32 = G1ExpAir::u16_to_u32(a), b32 = G1ExpAir::u16_to_u32(b);
+      Arr<P, 8> limbs; for (int k = 0; k < 8; k++) limbs[k] = lv[start_limbs_col + k];
+      limbs[0] = limbs[0] * cst<P>(2) + is_mul;
+      size_t pc = 0;
+      for (size_t i = 0; i < 2 * num_io; i += 2) {
+        const P* io = pi + pc; pc += IO_LEN;
+        P is_in = lv[get_pulse_col(start_io_pulses_col, (int)i)], is_out = lv[get_pulse_col(start_io_pulses_col, (int)i + 1)];
+        for (int k = 0; k < 8; k++) yc.constraint(is_in * (io[k] - a32[k]));
+        for (int k = 0; k < 8; k++) yc.constraint(is_in * (io[8 + k] - b32[k]));
+        for (int k = 0; k < 8; k++) yc.constraint(is_out * (io[24 + k] - b32[k]));
+        for (int k = 0; k < 8; k++) yc.constraint(is_in * (io[16 + k] - limbs[k]));
+      }
+    }
+    cur = 0;
+    Arr<P, 16> next_a = read16(nv, cur), next_b = read16(nv, cur);
+    auto eqt = [&](P filter, const Arr<P, 16>& x, const Arr<P, 16>& y) { for (int k = 0; k < 16; k++) yc.constraint_transition(filter * (x[k] - y[k])); };
+    P fs = is_not_final * is_sq;
+    eqt(fs, next_a, output.output); eqt(fs, next_b, b);
+    P fm = is_not_final * is_mul;
+    eqt(fm, next_a, a); eqt(fm, next_b, output.output);
+    P fn = is_not_final * (one - is_sq - is_mul);
+    eqt(fn, next_a, a); eqt(fn, next_b, b);
+    eval_flags(yc, lv, nv, start_flags_col);     // :361
+    eval_fq_mul(yc, is_sq, a, a, output);        // :362
+    eval_fq_mul(yc, is_mul, a, b, output);       // :363
+    eval_flags(yc, lv, nv, start_flags_col);     // :366 (duplicate, kept)
+    eval_periodic_pulse(yc, lv, nv, start_flags_col + 1, start_periodic_pulse_col, 2 * INPUT_LIMB_BITS, 2 * INPUT_LIMB_BITS - 2);
+    eval_pulse(yc, lv, nv, start_io_pulses_col, pulse_positions);
+    eval_u16_range_check(yc, lv, nv, start_lookups_col, (size_t)num_range_check_cols);
+  }
+  void generate_block(const FqExpIONative& in, std::vector<std::vector<GF>>& cols, size_t row0, U256& out) const {  // :128-176, :214-246
+    size_t num_rows = 2 * INPUT_LIMB_BITS * NUM_INPUT_LIMBS;
+    std::vector<GF> lv(num_main_cols, GF()), nvv(num_main_cols, GF());
+    int sf = start_flags_col;
+    Arr<int64_t, 16> a = u256_to_limbs16(in.x), b = u256_to_limbs16(in.offset), prod;
+    auto put = [&](GF* r, int off, const Arr<int64_t, 16>& v) { for (int k = 0; k < 16; k++) r[off + k] = GF((u64)v[k]); };
+    generate_flags_first_row(lv.data(), sf, in.exp_val);
+    put(lv.data(), 0, a); put(lv.data(), 16, b);
+    if (lv[sf + 4] == GF::one()) generate_fq_mul(a, b, lv.data() + 32, prod); else write_fq_output_default(lv.data() + 32);
+    for (int c = 0; c < num_main_cols; c++) cols[c][row0] = lv[c];
+    for (size_t i = 0; i + 1 < num_rows; i++) {
+      std::fill(nvv.begin(), nvv.end(), GF());
+      generate_flags_next_row(lv.data(), nvv.data(), i, sf);
+      if (lv[sf + 2] == GF::one()) a = prod; else if (lv[sf + 4] == GF::one()) b = prod;
+      put(nvv.data(), 0, a); put(nvv.data(), 16, b);
+      if (nvv[sf + 2] == GF::one()) generate_fq_mul(a, a, nvv.data() + 32, prod);
+      else if (nvv[sf + 4] == GF::one()) generate_fq_mul(a, b, nvv.data() + 32, prod);
+      else write_fq_output_default(nvv.data() + 32);
+      for (int c = 0; c < num_main_cols; c++) cols[c][row0 + i + 1] = nvv[c];
+      lv.swap(nvv);
+    }
+    out = limbs16_to_u256(b.data());
+  }
+  std::vector<std::vector<GF>> generate_trace(std::vector<FqExpIONative>& inputs) const {  // :248-277
+    assert(inputs.size() == num_io);
+    size_t rpb = 2 * INPUT_LIMB_BITS * NUM_INPUT_LIMBS, rows = rpb * num_io;
+    std::vector<std::vector<GF>> cols(num_main_cols, std::vector<GF>(rows));
+#pragma omp parallel for schedule(dynamic, 1)
+    for (size_t k = 0; k < num_io; k++) generate_block(inputs[k], cols, k * rpb, inputs[k].output);
+    generate_periodic_pulse_witness(cols, start_flags_col + 1, 2 * INPUT_LIMB_BITS, 2 * INPUT_LIMB_BITS - 2);
+    generate_pulse(cols, pulse_positions);
+    generate_u16_range_check(0, (size_t)num_range_check_cols, cols);
+    assert(cols.size() == ncols);
+    return cols;
+  }
+  std::vector<GF> generate_public_inputs(const std::vector<FqExpIONative>& inputs) const {  // :98-108, :279-284
+    std::vector<GF> pi;
+    auto put32 = [&](const U256& v) { for (int i = 0; i < 8; i++) pi.push_back(GF((v.l[i >> 1] >> (32 * (i & 1))) & 0xffffffffULL)); };
+    for (auto& in : inputs) {
+      put32(in.x); put32(in.offset);
+      for (int i = 0; i < 8; i++) pi.push_back(GF(in.exp_val[i]));
+      put32(in.output);
+    }
+    return pi;
+  }
+};
+
 }  // namespace orc

@@ -414,11 +414,50 @@ GL_HD void fq12_gadget(const Cons<P>& cs, const Row& row, P* h_sq, P* h_mul) {
   }
 }
 
+// ---- Fq multiplication gadget (src/fields/fq/mul.rs) -------------------------------------------------------------
+// Columns relative to the row: a[16] at 0, b[16] at 16, FqOutput at 32 = output[16], aux (out_aux_red 16, quot_abs 17,
+// lo 31, hi 31), quot_sign (mul.rs:49-54).  eval_fq_mul(is_sq, a, a) and eval_fq_mul(is_mul, a, b) on one row
+// (fq/exp.rs:362-363): two 66-constraint local sums sharing the modular-reduction side.
+template <class P, class Row>
+GL_HD void fq_gadget(const Cons<P>& cs, const Row& row, P* h_sq, P* h_mul) {
+  constexpr int A = 0, B = 16, OUT = 32, AUX = 48, SGN = 143;
+  const P base = lift<P>(65536), off = lift<P>(1ULL << 29), zero = lift<P>(0);
+  Horner2<P> hs, hm;
+#pragma unroll
+  for (int j = 0; j < SBN_NCH; j++) hs.h[j] = zero;
+  modop_prefix(cs, row, AUX, OUT, SGN, hs);
+  hm = hs;
+  const P sgn = row.l(SGN);
+  P pa = zero;
+  for (int k = 0; k < 32; k++) {
+    P in_s = zero, in_m = zero;
+    if (k < 31) {
+      int u0 = k > 15 ? k - 15 : 0, u1 = k < 15 ? k : 15;
+      for (int u = u0; u <= u1; u++) { P au = row.l(A + u); in_s += au * row.l(A + k - u); in_m += au * row.l(B + k - u); }
+    }
+    P qv = zero;
+    int i0 = k > 15 ? k - 15 : 0, i1 = k < 16 ? k : 16;
+    for (int i = i0; i <= i1; i++) qv += row.l(AUX + 16 + i) * lift<P>(bn254_modulus_limb(k - i));
+    P ax = zero;
+    if (k < 31) ax = row.l(AUX + 33 + k) - off + base * row.l(AUX + 64 + k);
+    P adj = pa - base * ax;
+    pa = ax;
+    P xk = sgn * qv + adj;
+    if (k < 16) xk = xk + row.l(OUT + k);
+    hs.push(cs, xk - in_s);
+    hm.push(cs, xk - in_m);
+  }
+#pragma unroll
+  for (int j = 0; j < SBN_NCH; j++) { h_sq[j] = hs.h[j]; h_mul[j] = hm.h[j]; }
+}
+
 // ---- G1ExpStark / G2ExpStark (src/curves/g1/exp.rs, src/curves/g2/exp.rs) --------------------------------
 // Both tables are the same double-and-add machine; E = 1 (Fq coordinates) or 2 (Fq2 coordinates) scales
 // the point columns (32E per point), the gadget (320E columns, 165E constraints) and the public inputs.
 struct ExpShape {  // constants(num_io): g1/exp.rs:6-34, g2/exp.rs:6-34, fq12/exp.rs:6-34
-  // E = 1: G1ExpStark, 2: G2ExpStark (curve tables), 12: Fq12ExpStark (offset * x^e, square-and-multiply)
+  // E = 1: G1ExpStark, 2: G2ExpStark (curve tables), 12: Fq12ExpStark (offset * x^e, square-and-multiply),
+  // 0: FqExpStark (the same square-and-multiply machine over one Fq coefficient; u32 public inputs, u16 range check;
+  //    constants(num_io): fq/exp.rs:6-34)
   int E, num_io, W, L, pi_per_io, b_col, gadget_col, nx_col, gadget_cons, start_flags, num_main, start_periodic, start_io_pulses, start_lookups;
   int rc_start, num_rc, split_rc, num_cols, num_pi;
   GL_HD ExpShape(int e, int n) {
@@ -426,6 +465,9 @@ struct ExpShape {  // constants(num_io): g1/exp.rs:6-34, g2/exp.rs:6-34, fq12/ex
     if (e == 12) {
       W = 192; L = 192; gadget_col = 384; nx_col = 384; gadget_cons = 792; start_flags = 108 * 16;
       rc_start = 384; num_rc = 84 * 16 - 12; split_rc = 1;
+    } else if (e == 0) {
+      W = 16; L = 8; gadget_col = 32; nx_col = 32; gadget_cons = 66; start_flags = 9 * 16;
+      rc_start = 0; num_rc = 9 * 16 - 1; split_rc = 0;
     } else {
       W = 32 * e; L = 16 * e; gadget_col = 64 * e; nx_col = gadget_col + 16 * e; gadget_cons = 165 * e; start_flags = 384 * e;
       rc_start = 0; num_rc = 381 * e; split_rc = 0;
@@ -556,7 +598,7 @@ GL_HD void exp_eval(Cons<P>& cs, const Row& row, const ExpShape& sh, const ExpPi
   }
   // [3] state transitions (fq_equal_transition / fq2_equal_transition x12)      g1/exp.rs:395-461, g2/exp.rs:416-473
   {
-    constexpr int W = E == 12 ? 192 : 32 * E;  // columns of one operand (point / Fq12 element)
+    constexpr int W = E == 12 ? 192 : (E == 0 ? 16 : 32 * E);  // columns of one operand (point / Fq12 element / Fq element)
     Horner2<P> d_na_a, d_nb_b, d_na_new, d_nb_new;  // (next_a - a), (next_b - b), (next_a - new), (next_b - new)
 #pragma unroll
     for (int j = 0; j < SBN_NCH; j++) d_na_a.h[j] = d_nb_b.h[j] = d_na_new.h[j] = d_nb_new.h[j] = lift<P>(0);
@@ -588,10 +630,11 @@ GL_HD void exp_eval(Cons<P>& cs, const Row& row, const ExpShape& sh, const ExpPi
   cs.merge(hf.h, one, FLAGS_CONSTRAINTS);
   {
     P h_add[SBN_NCH], h_dbl[SBN_NCH];
-    // curve tables: eval_g*_add (filter is_add) then eval_g*_double (is_double); fq12: eval_fq12_mul(is_sq, a, a)
-    // then eval_fq12_mul(is_mul, a, b) -- is_sq shares the column of is_double, is_mul that of is_add.
-    if (E == 1) g1_gadget(cs, row, h_add, h_dbl); else if (E == 2) g2_gadget(cs, row, h_add, h_dbl); else fq12_gadget(cs, row, h_dbl, h_add);
-    if (E == 12) { cs.merge(h_dbl, is_double, sh.gadget_cons); cs.merge(h_add, is_add, sh.gadget_cons); }
+    // curve tables: eval_g*_add (filter is_add) then eval_g*_double (is_double); fq12 / fq: eval_fq*_mul(is_sq, a, a)
+    // then eval_fq*_mul(is_mul, a, b) -- is_sq shares the column of is_double, is_mul that of is_add.
+    if (E == 1) g1_gadget(cs, row, h_add, h_dbl); else if (E == 2) g2_gadget(cs, row, h_add, h_dbl);
+    else if (E == 0) fq_gadget(cs, row, h_dbl, h_add); else fq12_gadget(cs, row, h_dbl, h_add);
+    if (E == 12 || E == 0) { cs.merge(h_dbl, is_double, sh.gadget_cons); cs.merge(h_add, is_add, sh.gadget_cons); }
     else { cs.merge(h_add, is_add, sh.gadget_cons); cs.merge(h_dbl, is_double, sh.gadget_cons); }
   }
   cs.merge(hf.h, one, FLAGS_CONSTRAINTS);

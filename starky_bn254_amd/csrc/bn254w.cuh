@@ -237,6 +237,23 @@ GL_HD bool g2_output_row(bool is_double, const u64* ax, const u64* ay, const u64
   return cur == 640;
 }
 
+// FqOutput columns (src/fields/fq/mul.rs:49-54) of x*y given the product (standard form): 112 words
+GL_HD bool fq_output_row(const u64* x, const u64* y, const u64* out, u64* lv) {
+  int64_t xl[16], yl[16], ol[16], pol[31];
+  limbs16(x, xl); limbs16(y, yl); limbs16(out, ol);
+  conv16(xl, yl, pol);
+  ModW w;
+  if (!mod_witness(pol, out, true, w)) return false;
+  int cur = 0;
+  for (int i = 0; i < 16; i++) lv[cur++] = (u64)ol[i];
+  for (int i = 0; i < 16; i++) lv[cur++] = (u64)w.out_aux_red[i];
+  for (int i = 0; i < 17; i++) lv[cur++] = (u64)w.quot_abs[i];
+  for (int i = 0; i < 31; i++) lv[cur++] = (u64)w.aux_lo[i];
+  for (int i = 0; i < 31; i++) lv[cur++] = (u64)w.aux_hi[i];
+  lv[cur++] = w.sign > 0 ? 1 : GLP - 1;
+  return cur == 112;
+}
+
 // ---- Fq12 (flat basis of plonky2-bn254 MyFq12: coefficient of w^k is c[k] + c[k+6] i, w^6 = 9 + i) ------------------------
 // flat-basis product (src/fields/fq12/mul.rs:24-87) in Montgomery Fq
 GL_HD void fq12_mul_m(const Fq* a, const Fq* b, Fq* out) {

@@ -221,6 +221,32 @@ __global__ void __launch_bounds__(64) fq12_row_kernel(const uint32_t* __restrict
   }
 }
 
+// ---- FqExpStark rows (src/fields/fq/exp.rs:128-176): as fq12_row_kernel with one coefficient; ca / cb: [K][257][4] ---------
+__global__ void __launch_bounds__(128) fq_row_kernel(const uint32_t* __restrict__ ios, const u64* __restrict__ ca, const u64* __restrict__ cb, size_t n,
+                                                     u64* __restrict__ trace, int* __restrict__ err) {
+  const size_t row = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (row >= n) return;
+  const size_t k = row >> 9; const int r = (int)(row & 511), t = r >> 1; const bool sq = r & 1;
+  const bool bit = (ios[24 * k + 16 + (t >> 5)] >> (t & 31)) & 1;
+  const int op = sq ? 1 : (bit ? 2 : 0);  // 1 square, 2 multiply
+  u64 a[4], b[4], prod[4];
+  for (int i = 0; i < 4; i++) { a[i] = ca[(k * 257 + t) * 4 + i]; b[i] = cb[(k * 257 + t + (sq ? 1 : 0)) * 4 + i]; }
+  for (int i = 0; i < 16; i++) {
+    trace[(size_t)i * n + row] = (a[i >> 2] >> (16 * (i & 3))) & 0xffff;
+    trace[(size_t)(16 + i) * n + row] = (b[i >> 2] >> (16 * (i & 3))) & 0xffff;
+  }
+  u64* g = trace + (size_t)32 * n + row;
+  if (op) {
+    for (int i = 0; i < 4; i++) prod[i] = (op == 1 ? ca : cb)[(k * 257 + t + 1) * 4 + i];
+    u64 lv[112];
+    if (!fq_output_row(a, op == 1 ? a : b, prod, lv)) { atomicOr(err, TG_ERR_WITNESS); return; }
+    for (int c = 0; c < 112; c++) g[(size_t)c * n] = lv[c];
+  } else {  // FqOutput::default (mul.rs:24-32)
+    for (int c = 0; c < 111; c++) g[(size_t)c * n] = 0;
+    g[(size_t)111 * n] = 1;
+  }
+}
+
 // ---- split range check (range_check.rs:116-160): table 0..255 then 255 repeated; per target column the low and the high
 // byte, each with its sorted column and permuted table (lookup.rs:60-111).  One workgroup of 256 lanes per target.
 // With 256 distinct values the reference's merge is simulated value by value by one lane (push a missing value; the

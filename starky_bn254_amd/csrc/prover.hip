@@ -272,9 +272,9 @@ extern "C" int sbn_prover_create(const sbn_air_desc* air, const sbn_config* cfg,
   if (!air_shape(air, cfg, as)) return fail(SBN_ERR_BAD_ARG, "unknown air kind / num_io");
   if (degree_bits < 9 || degree_bits > 22) return fail(SBN_ERR_UNSUPPORTED, "degree_bits out of range");
   if (is_exp_air(as.kind)) {
-    if (((size_t)512 * as.num_io) != ((size_t)1 << degree_bits)) return fail(SBN_ERR_BAD_ARG, "G1_EXP / G2_EXP need 512*num_io rows");
+    if (((size_t)512 * as.num_io) != ((size_t)1 << degree_bits)) return fail(SBN_ERR_BAD_ARG, "the Exp tables need 512*num_io rows");
     if (as.kind != SBN_AIR_FQ12_EXP && degree_bits < 16)
-      return fail(SBN_ERR_UNSUPPORTED, "G1_EXP / G2_EXP need >= 2^16 rows (u16 range check, range_check.rs:26)");
+      return fail(SBN_ERR_UNSUPPORTED, "G1_EXP / G2_EXP / FQ_EXP need >= 2^16 rows (u16 range check, range_check.rs:26)");
   }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(SBN_ERR_NO_DEVICE, "no HIP device available: the prover path has no CPU fallback");
@@ -596,6 +596,68 @@ static int generate_trace_device_fq12(sbn_prover* P, const uint32_t* ios, size_t
   return SBN_OK;
 }
 
+// FqExpStark: chains on host threads (512 Montgomery products per instance), rows and the u16 range check on the device.
+static int generate_trace_device_fq(sbn_prover* P, const uint32_t* ios, size_t K, uint64_t* pi_out) {
+  const size_t n = P->n, IOW = 24;
+  for (size_t k = 0; k < K; k++)
+    for (int v = 0; v < 2; v++) {
+      u64 t[4]; for (int i = 0; i < 4; i++) t[i] = (u64)ios[IOW * k + 8 * v + 2 * i] | ((u64)ios[IOW * k + 8 * v + 2 * i + 1] << 32);
+      if (bnw::geq_p(t)) return fail(SBN_ERR_BAD_ARG, "value >= p (instance %zu)", k);
+    }
+  HIPC(hipSetDevice(P->device));
+  hipStream_t st = P->stream;
+  const ExpShape sh = exp_shape(P->air);
+  P->loaded = false;
+  u64* w = P->d_lde;
+  auto take = [&](size_t words) { u64* r = w; w += (words + 7) & ~(size_t)7; return r; };
+  const size_t cw = 257 * 4 * K;
+  u64* ca = take(cw); u64* cb = take(cw);
+  u64* inv = take(n);
+  uint32_t* d_ios = (uint32_t*)take(IOW * K / 2 + 1);
+  int* d_err = (int*)take(1);
+  static bool attr_done = false;
+  if (!attr_done) { HIPC(hipFuncSetAttribute((const void*)tg::range_check_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tg::RC_LDS_BYTES)); attr_done = true; }
+  hipEvent_t e0 = P->abs_ev[0], e1 = P->abs_ev[1];
+  HIPC(hipEventRecord(e0, st));
+  HIPC(hipMemcpyAsync(d_ios, ios, IOW * K * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+  HIPC(hipMemsetAsync(d_err, 0, sizeof(int), st));
+  auto blocks = [](size_t k, unsigned b) { return dim3((unsigned)((k + b - 1) / b)); };
+  hipLaunchKernelGGL(tg::flags_kernel, blocks(n, 256), dim3(256), 0, st, d_ios, IOW, n, sh.start_flags, P->d_trace);
+  hipLaunchKernelGGL(tg::small_inverse_kernel, blocks(n, 256), dim3(256), 0, st, inv, n);
+  hipLaunchKernelGGL(tg::periodic_kernel, blocks(n, 256), dim3(256), 0, st, inv, n, sh.start_periodic, sh.start_io_pulses, sh.start_lookups, (u64)65535, P->d_trace);
+  hipLaunchKernelGGL(tg::io_pulse_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)(2 * K)), dim3(256), 0, st, inv, n, sh.witness_col(0), P->d_trace);
+  if (P->h_chain_words < 2 * cw) {
+    if (P->h_chain) (void)hipHostFree(P->h_chain);
+    P->h_chain = nullptr; P->h_chain_words = 0;
+    HIPC(hipHostMalloc((void**)&P->h_chain, 2 * cw * sizeof(u64), hipHostMallocDefault));
+    P->h_chain_words = 2 * cw;
+  }
+  tracegen_host_chains_fq(ios, K, P->h_chain, P->h_chain + cw);
+  HIPC(hipMemcpyAsync(ca, P->h_chain, 2 * cw * sizeof(u64), hipMemcpyHostToDevice, st));  // ca and cb are adjacent
+  hipLaunchKernelGGL(tg::fq_row_kernel, blocks(n, 128), dim3(128), 0, st, d_ios, ca, cb, n, P->d_trace, d_err);
+  hipLaunchKernelGGL(tg::range_check_kernel, dim3((unsigned)sh.num_rc), dim3(tg::RC_THREADS), tg::RC_LDS_BYTES, st, P->d_trace, n, sh.rc_start, sh.start_lookups, d_err);
+  HIPC(hipGetLastError());
+  int err = 0;
+  HIPC(hipMemcpyAsync(&err, d_err, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPC(hipEventRecord(e1, st));
+  HIPC(hipStreamSynchronize(st));
+  float ms = 0; HIPC(hipEventElapsedTime(&ms, e0, e1));
+  P->stage_ms[ST_COUNT + EX_TRACEGEN_MS] = ms;
+  if (err & tg::TG_ERR_WITNESS) return fail(SBN_ERR_WITNESS, "modular witness generation failed");
+  if (err & tg::TG_ERR_RANGE) return fail(SBN_ERR_WITNESS, "range-checked column holds a value >= 2^16");
+  // public inputs: x, offset, exp_val, output = b at the last row, as u32 limbs (fq/exp.rs:98-108)
+  P->pi.resize(P->air.npi);
+  for (size_t k = 0; k < K; k++) {
+    u64* p = P->pi.data() + (size_t)sh.pi_per_io * k;
+    for (size_t i = 0; i < IOW; i++) p[i] = ios[IOW * k + i];
+    const u64* out = P->h_chain + cw + (k * 257 + 256) * 4;  // B[256]
+    for (int i = 0; i < 8; i++) p[24 + i] = (out[i >> 1] >> (32 * (i & 1))) & 0xffffffffULL;
+  }
+  if (pi_out) memcpy(pi_out, P->pi.data(), P->pi.size() * sizeof(u64));
+  P->loaded = true;
+  return SBN_OK;
+}
+
 extern "C" int sbn_prover_generate_trace(sbn_prover* P, const uint32_t* ios, size_t num_io, uint64_t* pi_out) {
   if (!P || !ios) return fail(SBN_ERR_BAD_ARG, "null argument");
   if (!is_exp_air(P->air.kind)) return fail(SBN_ERR_UNSUPPORTED, "device witness generation covers the Exp tables (use sbn_generate_trace_g1_op + sbn_prover_load_trace)");
@@ -603,6 +665,7 @@ extern "C" int sbn_prover_generate_trace(sbn_prover* P, const uint32_t* ios, siz
   if (P->n != 512 * num_io) return fail(SBN_ERR_BAD_ARG, "degree_bits does not match 512 rows per instance");
   if (P->air.kind == SBN_AIR_FQ12_EXP) return generate_trace_device_fq12(P, ios, num_io, pi_out);
   if (P->n != 65536) return fail(SBN_ERR_UNSUPPORTED, "device witness generation needs exactly 2^16 rows (u16 histogram in LDS)");
+  if (P->air.kind == SBN_AIR_FQ_EXP) return generate_trace_device_fq(P, ios, num_io, pi_out);
   return P->air.kind == SBN_AIR_G1_EXP ? generate_trace_device<1>(P, ios, num_io, pi_out) : generate_trace_device<2>(P, ios, num_io, pi_out);
 }
 
@@ -695,6 +758,7 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
     if (P->air.kind == SBN_AIR_G1_OP) hipLaunchKernelGGL(quotient_kernel<1>, blocks(m), dim3(256), 0, st, qp);
     else if (P->air.kind == SBN_AIR_G1_EXP) hipLaunchKernelGGL(quotient_kernel<2>, blocks(m), dim3(256), 0, st, qp);
     else if (P->air.kind == SBN_AIR_G2_EXP) hipLaunchKernelGGL(quotient_kernel<3>, blocks(m), dim3(256), 0, st, qp);
+    else if (P->air.kind == SBN_AIR_FQ_EXP) hipLaunchKernelGGL(quotient_kernel<5>, blocks(m), dim3(256), 0, st, qp);
     else hipLaunchKernelGGL(quotient_kernel<4>, blocks(m), dim3(256), 0, st, qp);
     HIPC(hipGetLastError());
   }

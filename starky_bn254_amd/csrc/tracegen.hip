@@ -429,3 +429,84 @@ extern "C" int sbn_generate_trace_fq12_exp(const uint32_t* ios, size_t num_io, u
   if (!fill_split_range_check(trace, n, sh.start_lookups, sh.rc_start, sh.num_rc)) return fail(SBN_ERR_WITNESS, "range-checked column holds a value >= 2^16");
   return SBN_OK;
 }
+
+// ---- FqExpStark (src/fields/fq/exp.rs:128-284) ---------------------------------------------------------------------
+// (fq_output_row lives in bn254w.cuh, shared with the device generator)
+
+// Square-and-multiply chains of every FqExpStark instance on host threads, standard form: A[t] = x^(2^t), B[0] = offset,
+// B[t+1] = bit_t ? A[t] * B[t] : B[t].  ca / cb: [K][257][4] u64.
+namespace sbn {
+int tracegen_host_chains_fq(const uint32_t* ios, size_t K, u64* ca, u64* cb) {
+  parallel_for_chunks(K, 8, [&](size_t k0, size_t k1) {
+    for (size_t k = k0; k < k1; k++) {
+      const uint32_t* io = ios + 24 * k;
+      u64 t4[4];
+      u32x8_to_u64x4(io, t4); Fq a = to_m(t4);
+      u32x8_to_u64x4(io + 8, t4); Fq b = to_m(t4);
+      for (int t = 0;; t++) {
+        from_m(a, ca + (k * 257 + t) * 4); from_m(b, cb + (k * 257 + t) * 4);
+        if (t == 256) break;
+        if ((io[16 + (t >> 5)] >> (t & 31)) & 1) b = mmul(a, b);
+        a = mmul(a, a);
+      }
+    }
+  });
+  return 0;
+}
+}  // namespace sbn
+
+extern "C" int sbn_generate_trace_fq_exp(const uint32_t* ios, size_t num_io, uint64_t* trace, uint64_t* pi_out) {
+  if (!ios || !trace || !pi_out || num_io == 0 || num_io > (size_t)G1EXP_MAX_IO || (num_io & (num_io - 1))) return fail(SBN_ERR_BAD_ARG, "bad arguments");
+  const ExpShape sh(0, (int)num_io);
+  const size_t RPB = 512, n = RPB * num_io, IOW = 24;
+  if (n < 65536) return fail(SBN_ERR_UNSUPPORTED, "the table needs >= 2^16 rows (u16 range check, range_check.rs:26)");
+  const int sf = sh.start_flags;
+  auto col = [&](int c) { return trace + (size_t)c * n; };
+  for (size_t k = 0; k < num_io; k++)
+    for (int c = 0; c < 2; c++) { u64 t[4]; from_u32(ios + IOW * k + 8 * c, t); if (geq_p(t)) return fail(SBN_ERR_BAD_ARG, "value >= p (instance %zu)", k); }
+  fill_flags(trace, n, sf, num_io, [&](size_t k) { return ios + IOW * k + 16; });
+  std::atomic<int> bad(0);
+  parallel_for(num_io, [&](size_t k) {
+    u64 t[4];
+    from_u32(ios + IOW * k, t); Fq a = to_m(t);
+    from_u32(ios + IOW * k + 8, t); Fq b = to_m(t);
+    Fq prod = a;
+    u64 as[4], bs[4], ps[4], lv[112];
+    int prev_op = 0;  // 0 none, 1 square (a <- prod), 2 multiply (b <- prod)
+    for (size_t r = 0; r < RPB; r++) {
+      size_t row = k * RPB + r;
+      if (prev_op == 1) a = prod; else if (prev_op == 2) b = prod;
+      from_m(a, as); from_m(b, bs);
+      put_limbs(col(0) + row, n, as); put_limbs(col(16) + row, n, bs);
+      int op = (r & 1) ? 1 : (col(sf + 4)[row] ? 2 : 0);  // odd rows square, even rows multiply when the bit is set
+      if (op) {
+        prod = mmul(a, op == 1 ? a : b);
+        from_m(prod, ps);
+        if (!fq_output_row(as, op == 1 ? as : bs, ps, lv)) { bad = 1; return; }
+      } else {  // FqOutput::default (mul.rs:24-32)
+        for (int i = 0; i < 111; i++) lv[i] = 0;
+        lv[111] = 1;
+      }
+      for (int c = 0; c < 112; c++) col(32 + c)[row] = lv[c];
+      prev_op = op;
+    }
+    // public inputs: x, offset, exp_val, output = b at the last row, as u32 limbs (fq/exp.rs:98-108)
+    u64* p = pi_out + (size_t)sh.pi_per_io * k;
+    for (int i = 0; i < 24; i++) p[i] = ios[IOW * k + i];
+    for (int i = 0; i < 8; i++) p[24 + i] = (bs[i / 2] >> (32 * (i % 2))) & 0xffffffffULL;
+  });
+  if (bad) return fail(SBN_ERR_WITNESS, "modular witness generation failed");
+  fill_pulses(trace, n, sh);
+  {
+    u64* table = col(sh.start_lookups);
+    for (size_t i = 0; i < n; i++) table[i] = i < 65536 ? i : 65535;
+    parallel_for((size_t)sh.num_rc, [&](size_t k) {
+      const u64* c = col((int)k);
+      for (size_t i = 0; i < n; i++) if (c[i] >= 65536) { bad = 1; return; }
+      permuted_cols_u(c, n, 65536, col(sh.start_lookups + 1 + 2 * (int)k), col(sh.start_lookups + 2 + 2 * (int)k));
+    });
+    if (bad) return fail(SBN_ERR_WITNESS, "range-checked column holds a value >= 2^16");
+  }
+  return SBN_OK;
+}
+

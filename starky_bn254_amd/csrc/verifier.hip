@@ -181,7 +181,7 @@ extern "C" int sbn_verify(const sbn_air_desc* air, const sbn_config* cfg, const 
     static thread_local ExpPiConsts<E2> pic;
     const E2* app[SBN_NCH] = {apow[0].data(), apow[1].data()};
     exp_pi_consts<E2>(sh, app, epi.data(), pic);
-    if (sh.E == 1) exp_eval<1>(cs, row, sh, &pic); else if (sh.E == 2) exp_eval<2>(cs, row, sh, &pic); else exp_eval<12>(cs, row, sh, &pic);
+    if (sh.E == 1) exp_eval<1>(cs, row, sh, &pic); else if (sh.E == 2) exp_eval<2>(cs, row, sh, &pic); else if (sh.E == 0) exp_eval<0>(cs, row, sh, &pic); else exp_eval<12>(cs, row, sh, &pic);
     permutation_checks(cs, row, zrow, sh, (int)nz, g0, g1);
   }
   for (u32 i = 0; i < cfg->num_challenges; i++) {

@@ -70,3 +70,12 @@ def fq12exp_case(O):
     ios, native = O.fq12exp_inputs(16, 3)
     trace, pi = O.fq12exp_trace(ios)
     return {"ios": ios, "native": native, "trace": trace, "pi": pi}
+
+
+@pytest.fixture(scope="session")
+def fqexp_case(O):
+    """Seeded FqExpStark(128) trace (2^16 rows x 960 columns), the size of the reference's test_fq_exp_raw."""
+    ios, native = O.fqexp_inputs(128, 4)
+    trace, pi = O.fqexp_trace(ios)
+    return {"ios": ios, "native": native, "trace": trace, "pi": pi}
+

@@ -445,3 +445,36 @@ def fq12exp_trace(ios):
     L.orc_fq12exp_generate_trace.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     L.orc_fq12exp_generate_trace(ptr(ios), num_io, ptr(trace), ptr(pi))
     return trace, pi
+
+
+# ---- FqExpStark (src/fields/fq/exp.rs) ---------------------------------------------------------------------------------
+AIR_FQ_EXP = 5
+
+
+def fqexp_inputs(num_io, seed):
+    """Mirror of src/fields/fq/exp.rs:594-607 with seeded randomness: random Fq x, offset; 256-bit exponent limbs."""
+    rng = np.random.default_rng(seed)
+    ios = np.zeros((num_io, 24), dtype=np.uint32)
+    native = []
+    for k in range(num_io):
+        x = int.from_bytes(rng.bytes(32), "little") % BN_P
+        off = int.from_bytes(rng.bytes(32), "little") % BN_P
+        e = int.from_bytes(rng.bytes(32), "little")
+        ios[k, 0:8] = u32_limbs(x)
+        ios[k, 8:16] = u32_limbs(off)
+        ios[k, 16:24] = u32_limbs(e)
+        native.append((x, off, e))
+    return ios, native
+
+
+def fqexp_trace(ios):
+    num_io = ios.shape[0]
+    L = lib()
+    ncols = L.orc_air_num_columns(AIR_FQ_EXP, num_io)
+    npi = L.orc_air_num_public_inputs(AIR_FQ_EXP, num_io)
+    trace = np.zeros((ncols, 512 * num_io), dtype=np.uint64)
+    pi = np.zeros(npi, dtype=np.uint64)
+    ios = np.ascontiguousarray(ios, dtype=np.uint32)
+    L.orc_fqexp_generate_trace.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    L.orc_fqexp_generate_trace(ptr(ios), num_io, ptr(trace), ptr(pi))
+    return trace, pi

@@ -316,3 +316,33 @@ def test_fq12exp_device_witness_generation_matches_oracle(gpu, O, fq12exp_case, 
     finally:
         prover.close()
 
+
+def test_fqexp_proof_and_device_witness_match_oracle(gpu, O, fqexp_case, golden):
+    """FqExpStark(128), 2^16 rows x 960 columns (the reference's test_fq_exp_raw): GPU proof bytes == the CPU oracle's
+    (committed sha256), both verifiers accept, tampering rejected; the device-generated witness equals the oracle's and
+    proves to the same bytes."""
+    stark = gpu.FqExpStark(128)
+    cfg = stark.config()
+    prover = gpu.Prover(stark, cfg, 16)
+    try:
+        prover.load_trace(fqexp_case["trace"], fqexp_case["pi"])
+        proof = prover.prove()
+        g = golden["proof_digests"]["fqexp_io128_seed4"]
+        assert len(proof.words) == g["proof_words"]
+        assert [int(x) for x in proof.words[12:16]] == g["trace_cap0"]
+        assert hashlib.sha256(proof.to_bytes()).hexdigest() == g["proof_sha256"]
+        assert O.verify(O.AIR_FQ_EXP, 128, proof.words) == (0, "")
+        gpu.verify_stark_proof(stark, proof, cfg)
+        t = proof.words.copy()
+        t[12 + 3 * 64 + 9] = (int(t[12 + 3 * 64 + 9]) + 1) % P
+        assert O.verify(O.AIR_FQ_EXP, 128, t)[0] != 0
+        with pytest.raises(gpu.SbnError):
+            gpu.verify_stark_proof(stark, gpu.Proof(t, 16), cfg)
+        pi = prover.generate_trace(fqexp_case["ios"])
+        assert np.array_equal(pi, fqexp_case["pi"])
+        bad = np.nonzero((prover.read_trace() != fqexp_case["trace"]).any(axis=1))[0]
+        assert bad.size == 0, f"first differing columns: {bad[:8].tolist()}"
+        assert np.array_equal(prover.prove().words, proof.words)
+    finally:
+        prover.close()
+

@@ -47,6 +47,30 @@ def test_g1exp_constraints_vanish_on_trace(O, g1exp_case):
     assert O.eval_constraints(O.AIR_G1_EXP, 128, tr[:, 511], tr[:, 512], pi2, alphas, zl, lf, ll) != [0, 0]
 
 
+def test_fqexp_constraints_vanish_on_trace_and_power(O, fqexp_case):
+    """FqExpStark (src/fields/fq/exp.rs): every constraint vanishes on the generated trace (all three row kinds, block
+    boundaries, wrap-around), outputs = offset * x^e with Python integers (exp.rs:239-243), a wrong output is caught."""
+    tr, pi = fqexp_case["trace"], fqexp_case["pi"]
+    n = tr.shape[1]
+    L = O.lib()
+    assert (L.orc_air_num_columns(O.AIR_FQ_EXP, 128), L.orc_air_num_public_inputs(O.AIR_FQ_EXP, 128), L.orc_air_num_permutation_zs(O.AIR_FQ_EXP, 128)) == (960, 4096, 286)
+    alphas = [0x0123456789abcdef, 0x2222222211111111]
+    for i in [0, 1, 2, 61, 62, 63, 64, 510, 511, 512, 513, 30000, n - 2, n - 1]:
+        zl, lf, ll = _trace_domain_consumer_args(n, i)
+        assert O.eval_constraints(O.AIR_FQ_EXP, 128, tr[:, i], tr[:, (i + 1) % n], pi, alphas, zl, lf, ll) == [0, 0], f"row {i}"
+    for k in (0, 5, 127):
+        x, off, e = fqexp_case["native"][k]
+        assert sum(int(pi[32 * k + 24 + i]) << (32 * i) for i in range(8)) == off * pow(x, e, O.BN_P) % O.BN_P
+    pi2 = pi.copy()
+    pi2[24] = (int(pi2[24]) + 1) & 0xFFFFFFFF                      # instance 0 output limb 0
+    zl, lf, ll = _trace_domain_consumer_args(n, 511)
+    assert O.eval_constraints(O.AIR_FQ_EXP, 128, tr[:, 511], tr[:, 512], pi2, alphas, zl, lf, ll) != [0, 0]
+    bad = tr[:, 7].copy()
+    bad[40] = (int(bad[40]) + 1) % 65536                           # a limb of the product on a squaring row
+    zl, lf, ll = _trace_domain_consumer_args(n, 7)
+    assert O.eval_constraints(O.AIR_FQ_EXP, 128, bad, tr[:, 8], pi, alphas, zl, lf, ll) != [0, 0]
+
+
 def test_g1exp_shape(O):
     L = O.lib()
     assert L.orc_air_num_columns(O.AIR_G1_EXP, 128) == 1676           # SURVEY Appendix A

@@ -181,6 +181,31 @@ def test_fq12_shape_tracegen_and_power(S, O, fq12exp_case, golden):
         assert acc == [0, 0], i
 
 
+def test_fqexp_shape_tracegen_and_power(S, O, fqexp_case, golden):
+    """FqExpStark(128) (src/fields/fq/exp.rs, the reference's test_fq_exp_raw size): shape constants, host witness
+    generation bit-equal to the oracle's, outputs = offset * x^e computed with Python integers (exp.rs:239-243)."""
+    stark = S.FqExpStark(128)
+    cfg = stark.config()
+    assert (stark.num_columns, stark.num_public_inputs, stark.num_permutation_zs(cfg)) == (960, 4096, 286)
+    trace, pi = stark.generate_trace_and_public_inputs(fqexp_case["ios"])
+    assert np.array_equal(trace, fqexp_case["trace"]) and np.array_equal(pi, fqexp_case["pi"])
+    g = golden["proof_digests"]["fqexp_io128_seed4"]
+    assert hashlib.sha256(trace.tobytes()).hexdigest() == g["trace_sha256"]
+    assert hashlib.sha256(pi.tobytes()).hexdigest() == g["pi_sha256"]
+    for k in (0, 1, 63, 127):
+        x, off, e = fqexp_case["native"][k]
+        out = sum(int(pi[32 * k + 24 + i]) << (32 * i) for i in range(8))
+        assert out == off * pow(x, e, O.BN_P) % O.BN_P
+    bad = fqexp_case["ios"].copy()
+    bad[3, 0:8] = 0xFFFFFFFF                                       # x >= p
+    with pytest.raises(S.SbnError) as e:
+        stark.generate_trace_and_public_inputs(bad)
+    assert e.value.code == -1
+    with pytest.raises(S.SbnError) as e:                           # fewer than 2^16 rows: u16 range check impossible
+        S.FqExpStark(64).generate_trace_and_public_inputs(fqexp_case["ios"][:64])
+    assert e.value.code == -7
+
+
 def test_generated_tables_and_instruction_streams_are_current(tmp_path):
     """Every committed *.inc under csrc/ (Poseidon constants, sparse partial-round tables, MDS / S-box / fold / multiply
     instruction streams) is what its generator in tools/ produces; the generators check their own algebra

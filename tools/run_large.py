@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Runs one large table end to end on the GPU: host witness -> H2D -> prove -> product verify.
-usage: run_large.py fq12 <num_io> | g2 <num_io> | g1 <num_io>     (prints one JSON line)"""
+usage: run_large.py fq12 <num_io> | fq <num_io> | g2 <num_io> | g1 <num_io>     (prints one JSON line)"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -21,6 +21,14 @@ if table == "fq12":
             ios[k, 8 * c:8 * c + 8] = [(v >> (32 * i)) & 0xFFFFFFFF for i in range(8)]
         e = int.from_bytes(rng.bytes(32), "little") % R
         ios[k, 192:200] = [(e >> (32 * i)) & 0xFFFFFFFF for i in range(8)]
+elif table == "fq":
+    stark = S.FqExpStark(num_io)
+    ios = np.zeros((num_io, 24), dtype=np.uint32)
+    for k in range(num_io):
+        for c in range(2):
+            v = int.from_bytes(rng.bytes(32), "little") % P
+            ios[k, 8 * c:8 * c + 8] = [(v >> (32 * i)) & 0xFFFFFFFF for i in range(8)]
+        ios[k, 16:24] = np.frombuffer(rng.bytes(32), dtype=np.uint32)
 else:
     sys.path.insert(0, ROOT)
     import bench
