@@ -53,17 +53,19 @@ typedef enum sbn_status {
 
 /* Table kinds.  G1_OP = reference `G1Stark` (src/curves/g1/muladd.rs:462-624);
  * G1_EXP = reference `G1ExpStark` (src/curves/g1/exp.rs:232-742). */
-typedef enum sbn_air_kind { SBN_AIR_G1_OP = 1, SBN_AIR_G1_EXP = 2, SBN_AIR_G2_EXP = 3, SBN_AIR_FQ12_EXP = 4, SBN_AIR_FQ_EXP = 5 } sbn_air_kind;
+typedef enum sbn_air_kind { SBN_AIR_G1_OP = 1, SBN_AIR_G1_EXP = 2, SBN_AIR_G2_EXP = 3, SBN_AIR_FQ12_EXP = 4, SBN_AIR_FQ_EXP = 5, SBN_AIR_FQ12_EXP_U64 = 6 } sbn_air_kind;
 /* G2_EXP = reference `G2ExpStark` (src/curves/g2/exp.rs:248-807): the same machine over Fq2 coordinates.
  * FQ12_EXP = reference `Fq12ExpStark` (src/fields/fq12/exp.rs:223-605): offset * x^e in Fq12 (flat basis of
  * plonky2-bn254 `MyFq12`: coefficient of w^k is c[k] + c[k+6]*i, w^6 = 9 + i), 512 rows per instance, num_io a
  * power of two between 1 and 512.
  * FQ_EXP = reference `FqExpStark` (src/fields/fq/exp.rs:193-582): offset * x^e in the base field Fq, the same
- * square-and-multiply machine over one coefficient (960 columns at num_io = 128), u32 public inputs, u16 range check. */
+ * square-and-multiply machine over one coefficient (960 columns at num_io = 128), u32 public inputs, u16 range check.
+ * FQ12_EXP_U64 = reference `Fq12ExpU64Stark` (src/fields/fq12_u64/exp_u64.rs:243-571): Fq12 exponentiation by a u64
+ * exponent, 128 rows per instance, 6-column flags (flags_u64.rs), the exponent is ONE public input (< p). */
 
 typedef struct sbn_air_desc {
   int32_t kind;    /* sbn_air_kind */
-  uint32_t num_io; /* G1_EXP / G2_EXP: number of scalar-mult instances (rows = 512*num_io); G1_OP: ignored */
+  uint32_t num_io; /* Exp tables: number of instances (rows = 512*num_io; FQ12_EXP_U64: 128*num_io); G1_OP: ignored */
 } sbn_air_desc;
 
 /* Mirrors starky `StarkConfig` + plonky2 `FriConfig` (reference: stark.config() ->
@@ -108,6 +110,10 @@ int sbn_generate_trace_g2_exp(const uint32_t* ios, size_t num_io, uint64_t* trac
  * ios: num_io x 200 u32 = x[12] offset[12] (flat-basis coefficients, 8 u32 limbs each) exp_val[8];
  * trace_out: [num_columns][512*num_io]; pi_out: [584*num_io]. */
 int sbn_generate_trace_fq12_exp(const uint32_t* ios, size_t num_io, uint64_t* trace_out, uint64_t* pi_out);
+/* Fq12ExpU64Stark::generate_trace / generate_public_inputs (src/fields/fq12_u64/exp_u64.rs:283-313).
+ * ios: num_io x 194 u32 = x[12] offset[12] (8 u32 limbs each) exp_val (low, high u32; value < 2^64 - 2^32 + 1);
+ * trace_out: [num_columns][128*num_io]; pi_out: [577*num_io]. */
+int sbn_generate_trace_fq12_exp_u64(const uint32_t* ios, size_t num_io, uint64_t* trace_out, uint64_t* pi_out);
 /* FqExpStark::generate_trace / generate_public_inputs (src/fields/fq/exp.rs:248-284).
  * ios: num_io x 24 u32 = x[8] offset[8] exp_val[8]; trace_out: [num_columns][512*num_io]; pi_out: [32*num_io]. */
 int sbn_generate_trace_fq_exp(const uint32_t* ios, size_t num_io, uint64_t* trace_out, uint64_t* pi_out);
@@ -134,7 +140,7 @@ uint64_t* sbn_prover_trace_device_ptr(sbn_prover* p);
  * src/fields/fq12/exp.rs:283-319) without the trace ever crossing PCIe.  Same `ios` layout and the same resulting trace /
  * public inputs, bit for bit, as sbn_generate_trace_{g1,g2,fq12}_exp; afterwards the prover is loaded and
  * sbn_prover_prove can run.  pi_out (optional): [num_public_inputs].  G1_EXP / G2_EXP / FQ_EXP: tables of exactly 2^16
- * rows (SBN_ERR_UNSUPPORTED otherwise: use the host generators + sbn_prover_load_trace); FQ12_EXP: any size. */
+ * rows (SBN_ERR_UNSUPPORTED otherwise: use the host generators + sbn_prover_load_trace); FQ12_EXP, FQ12_EXP_U64: any size. */
 int sbn_prover_generate_trace(sbn_prover* p, const uint32_t* ios, size_t num_io, uint64_t* pi_out);
 /* Device -> host copy of the loaded trace, column-major [num_columns][N] (tests, debugging). */
 int sbn_prover_read_trace(sbn_prover* p, uint64_t* trace_out);

@@ -1100,6 +1100,153 @@ struct Fq12ExpAir : AirBase<Fq12ExpAir> {
   }
 };
 
+// ---- Fq12ExpU64Stark: src/fields/fq12_u64/{flags_u64,exp_u64}.rs (offset * x^e in Fq12, e a u64: 128 rows per instance) ----
+static const int NUM_FLAGS_U64_COLS = 6;  // flags_u64.rs:21 : is_final, a, b, filtered_bit, bit, val
+static inline void generate_flags_u64_first_row(GF* lv, int s, uint64_t exp_val) {  // :34-55
+  uint64_t first_bit = exp_val & 1, rest = exp_val >> 1;
+  lv[s] = GF(); lv[s + 1] = GF(); lv[s + 2] = GF::one(); lv[s + 3] = GF(first_bit); lv[s + 4] = GF(first_bit); lv[s + 5] = GF(rest);
+}
+static inline void generate_flags_u64_next_row(const GF* lv, GF* nv, size_t cur_row, int s) {  // :57-94
+  nv[s + 1] = GF::one() - lv[s + 1];
+  nv[s + 2] = GF::one() - lv[s + 2];
+  nv[s] = cur_row == 2 * 64 - 2 ? GF::one() : GF();
+  if (lv[s + 1] == GF::one()) { uint64_t v = lv[s + 5].v; nv[s + 4] = GF(v & 1); nv[s + 5] = GF(v >> 1); }
+  else { nv[s + 4] = lv[s + 4]; nv[s + 5] = lv[s + 5]; }
+  nv[s + 3] = nv[s + 4] * nv[s + 2];
+}
+template <class P>
+static inline void eval_flags_u64(Consumer<P>& yc, const P* lv, const P* nv, int s) {  // :96-139
+  P one = cst<P>(1), two = cst<P>(2);
+  yc.constraint_first_row(lv[s + 1]);
+  yc.constraint_first_row(lv[s + 2] - one);
+  P bit = lv[s + 4];
+  yc.constraint(bit * bit - bit);
+  yc.constraint(bit * lv[s + 2] - lv[s + 3]);
+  yc.constraint_transition(lv[s + 1] + nv[s + 1] - one);
+  yc.constraint_transition(lv[s + 2] + nv[s + 2] - one);
+  P first_limb = lv[s + 5], next_first_limb = nv[s + 5], next_bit = nv[s + 4], is_split = lv[s + 1];
+  P is_not_final = one - lv[s], is_not_split = one - is_split;
+  yc.constraint_transition(is_not_final * is_split * (first_limb - two * next_first_limb - next_bit));
+  yc.constraint_transition(is_not_split * (next_bit - bit));
+  yc.constraint_transition(is_not_final * is_not_split * (first_limb - next_first_limb));
+}
+struct Fq12ExpU64IONative { U256 x[12], offset[12]; uint64_t exp_val; U256 output[12]; };  // exp_u64.rs:91-96
+struct Fq12ExpU64Air : AirBase<Fq12ExpU64Air> {
+  size_t num_io;
+  int start_flags_col, num_main_cols, start_io_pulses_col, start_lookups_col, start_range_check_col, num_range_check_cols;  // exp_u64.rs:19-45
+  size_t ncols, npi;
+  std::vector<size_t> pulse_positions;
+  static const int IO_LEN = 36 * N_LIMBS + 1;  // :98
+  static const size_t RPB = 2 * 64;
+  explicit Fq12ExpU64Air(size_t n) : num_io(n) {
+    start_flags_col = 108 * N_LIMBS;
+    num_main_cols = start_flags_col + NUM_FLAGS_U64_COLS;
+    start_io_pulses_col = num_main_cols;
+    start_lookups_col = start_io_pulses_col + 1 + 4 * (int)num_io;
+    start_range_check_col = 24 * N_LIMBS;
+    num_range_check_cols = 84 * N_LIMBS - 12;
+    ncols = start_lookups_col + 1 + 6 * num_range_check_cols;
+    npi = IO_LEN * num_io;
+    for (size_t i = 0; i < num_io; i++) { pulse_positions.push_back(i * RPB); pulse_positions.push_back(i * RPB + RPB - 1); }  // :230-241
+  }
+  size_t num_columns() const override { return ncols; }
+  size_t num_public_inputs() const override { return npi; }
+  std::vector<std::pair<size_t, size_t>> permutation_pairs() const override {  // :564-570, range_check.rs:230-246
+    std::vector<std::pair<size_t, size_t>> p;
+    size_t mc = start_lookups_col;
+    for (size_t i = mc + 1; i < mc + 1 + 6 * (size_t)num_range_check_cols; i += 6) {
+      p.push_back({mc, i + 2}); p.push_back({mc, i + 5}); p.push_back({i, i + 1}); p.push_back({i + 3, i + 4});
+    }
+    return p;
+  }
+  template <class P> void eval_t(const P* lv, const P* nv, const P* pi, Consumer<P>& yc) const {  // :321-413
+    int is_final_col = start_flags_col, is_sq_col = start_flags_col + 1, is_mul_col = start_flags_col + 3, exp_val_col = start_flags_col + 5;
+    P one = cst<P>(1);
+    int cur = 0;
+    Fq12Limbs<P> a = read_fq12(lv, cur), b = read_fq12(lv, cur);
+    Fq12Output<P> output = read_fq12_output(lv, cur);
+    P is_mul = lv[is_mul_col], is_sq = lv[is_sq_col], is_final = lv[is_final_col];
+    P is_not_final = one - is_final;
+    P sum_is_output = P();
+    for (size_t i = 1; i < 2 * num_io; i += 2) sum_is_output = sum_is_output + lv[get_pulse_col(start_io_pulses_col, (int)i)];
+    yc.constraint(is_final - sum_is_output);
+    {  // public inputs :351-367 ; layout x[12][16] offset[12][16] exp_val output[12][16] (read_fq12_exp_u64_io :130-145)
+      P recovered = lv[exp_val_col] * cst<P>(2) + is_mul;
+      size_t pc = 0;
+      for (size_t i = 0; i < 2 * num_io; i += 2) {
+        const P* io = pi + pc; pc += IO_LEN;
+        P is_in = lv[get_pulse_col(start_io_pulses_col, (int)i)], is_out = lv[get_pulse_col(start_io_pulses_col, (int)i + 1)];
+        for (int c = 0; c < 12; c++) {
+          for (int k = 0; k < 16; k++) yc.constraint(is_in * (io[16 * c + k] - a[c][k]));
+          for (int k = 0; k < 16; k++) yc.constraint(is_in * (io[192 + 16 * c + k] - b[c][k]));
+          for (int k = 0; k < 16; k++) yc.constraint(is_out * (io[385 + 16 * c + k] - b[c][k]));
+        }
+        yc.constraint(is_in * (io[384] - recovered));
+      }
+    }
+    cur = 0;
+    Fq12Limbs<P> next_a = read_fq12(nv, cur), next_b = read_fq12(nv, cur);
+    auto eqt = [&](P filter, const Fq12Limbs<P>& x, const Fq12Limbs<P>& y) { for (int c = 0; c < 12; c++) for (int k = 0; k < 16; k++) yc.constraint_transition(filter * (x[c][k] - y[c][k])); };
+    P fs = is_not_final * is_sq;
+    eqt(fs, next_a, output.output); eqt(fs, next_b, b);
+    P fm = is_not_final * is_mul;
+    eqt(fm, next_a, a); eqt(fm, next_b, output.output);
+    P fn = is_not_final * (one - is_sq - is_mul);
+    eqt(fn, next_a, a); eqt(fn, next_b, b);
+    eval_flags_u64(yc, lv, nv, start_flags_col);     // :388
+    eval_fq12_mul(yc, is_sq, a, a, output);          // :389
+    eval_fq12_mul(yc, is_mul, a, b, output);         // :390
+    eval_flags_u64(yc, lv, nv, start_flags_col);     // :393 (duplicate, kept)
+    eval_pulse(yc, lv, nv, start_io_pulses_col, pulse_positions);
+    eval_split_u16_range_check(yc, lv, nv, start_lookups_col, (size_t)start_range_check_col, (size_t)(start_range_check_col + num_range_check_cols));
+  }
+  void generate_block(const Fq12ExpU64IONative& in, std::vector<std::vector<GF>>& cols, size_t row0, U256* out) const {  // :147-228, :256-281
+    std::vector<GF> lv(num_main_cols, GF()), nvv(num_main_cols, GF());
+    int sf = start_flags_col;
+    Fq12Limbs<int64_t> a, b, prod;
+    for (int c = 0; c < 12; c++) { a[c] = u256_to_limbs16(in.x[c]); b[c] = u256_to_limbs16(in.offset[c]); }
+    auto put = [&](GF* r, int off, const Fq12Limbs<int64_t>& v) { for (int c = 0; c < 12; c++) for (int k = 0; k < 16; k++) r[off + 16 * c + k] = GF((u64)v[c][k]); };
+    generate_flags_u64_first_row(lv.data(), sf, in.exp_val);
+    put(lv.data(), 0, a); put(lv.data(), 192, b);
+    if (lv[sf + 3] == GF::one()) generate_fq12_mul(a, b, lv.data() + 384, prod); else write_fq12_output_default(lv.data() + 384);
+    for (int c = 0; c < num_main_cols; c++) cols[c][row0] = lv[c];
+    for (size_t i = 0; i + 1 < RPB; i++) {
+      std::fill(nvv.begin(), nvv.end(), GF());
+      generate_flags_u64_next_row(lv.data(), nvv.data(), i, sf);
+      if (lv[sf + 1] == GF::one()) a = prod; else if (lv[sf + 3] == GF::one()) b = prod;
+      put(nvv.data(), 0, a); put(nvv.data(), 192, b);
+      if (nvv[sf + 1] == GF::one()) generate_fq12_mul(a, a, nvv.data() + 384, prod);
+      else if (nvv[sf + 3] == GF::one()) generate_fq12_mul(a, b, nvv.data() + 384, prod);
+      else write_fq12_output_default(nvv.data() + 384);
+      for (int c = 0; c < num_main_cols; c++) cols[c][row0 + i + 1] = nvv[c];
+      lv.swap(nvv);
+    }
+    for (int c = 0; c < 12; c++) out[c] = limbs16_to_u256(b[c].data());
+  }
+  std::vector<std::vector<GF>> generate_trace(std::vector<Fq12ExpU64IONative>& inputs) const {  // :283-306
+    assert(inputs.size() == num_io);
+    size_t rows = RPB * num_io;
+    std::vector<std::vector<GF>> cols(num_main_cols, std::vector<GF>(rows));
+#pragma omp parallel for schedule(dynamic, 1)
+    for (size_t k = 0; k < num_io; k++) generate_block(inputs[k], cols, k * RPB, inputs[k].output);
+    generate_pulse(cols, pulse_positions);
+    generate_split_u16_range_check((size_t)start_range_check_col, (size_t)(start_range_check_col + num_range_check_cols), cols);
+    assert(cols.size() == ncols);
+    return cols;
+  }
+  std::vector<GF> generate_public_inputs(const std::vector<Fq12ExpU64IONative>& inputs) const {  // :100-128, :308-313
+    std::vector<GF> pi;
+    auto put = [&](const U256& v) { auto l = u256_to_limbs16(v); for (int k = 0; k < 16; k++) pi.push_back(GF((u64)l[k])); };
+    for (auto& in : inputs) {
+      for (int c = 0; c < 12; c++) put(in.x[c]);
+      for (int c = 0; c < 12; c++) put(in.offset[c]);
+      pi.push_back(GF(in.exp_val));
+      for (int c = 0; c < 12; c++) put(in.output[c]);
+    }
+    return pi;
+  }
+};
+
 // ---- FqExpStark: src/fields/fq/exp.rs (offset * x^e in Fq by square-and-multiply; u16 range check) --------------------
 // FqOutput (src/fields/fq/mul.rs:18-22, column layout :49-54): output[16], ModulusAux (95), quot_sign = 7*N_LIMBS columns.
 template <class T> struct FqOutput { Arr<T, 16> output; ModulusAux<T> aux; T quot_sign; };

@@ -14,6 +14,7 @@ static std::unique_ptr<Air> make_air(int kind, size_t num_io) {
   if (kind == 3) return std::unique_ptr<Air>(new G2ExpAir(num_io));
   if (kind == 4) return std::unique_ptr<Air>(new Fq12ExpAir(num_io));
   if (kind == 5) return std::unique_ptr<Air>(new FqExpAir(num_io));
+  if (kind == 6) return std::unique_ptr<Air>(new Fq12ExpU64Air(num_io));
   return nullptr;
 }
 static U256 u256_from_u32(const uint32_t* w) {
@@ -164,6 +165,22 @@ int orc_fq12exp_generate_trace(const uint32_t* ios, size_t num_io, uint64_t* tra
     const uint32_t* w = ios + 200 * k;
     for (int c = 0; c < 12; c++) { in[k].x[c] = u256_from_u32(w + 8 * c); in[k].offset[c] = u256_from_u32(w + 96 + 8 * c); }
     for (int i = 0; i < 8; i++) in[k].exp_val[i] = w[192 + i];
+  }
+  auto cols = air.generate_trace(in);
+  size_t n = cols[0].size();
+  for (size_t c = 0; c < cols.size(); c++) for (size_t i = 0; i < n; i++) trace_out[c * n + i] = cols[c][i].v;
+  auto pi = air.generate_public_inputs(in);
+  for (size_t i = 0; i < pi.size(); i++) pi_out[i] = pi[i].v;
+  return 0;
+}
+// ios: num_io x 194 u32 = x[12] (8 u32 each, flat basis) offset[12] exp_val (lo, hi)
+int orc_fq12expu64_generate_trace(const uint32_t* ios, size_t num_io, uint64_t* trace_out, uint64_t* pi_out) {
+  Fq12ExpU64Air air(num_io);
+  std::vector<Fq12ExpU64IONative> in(num_io);
+  for (size_t k = 0; k < num_io; k++) {
+    const uint32_t* w = ios + 194 * k;
+    for (int c = 0; c < 12; c++) { in[k].x[c] = u256_from_u32(w + 8 * c); in[k].offset[c] = u256_from_u32(w + 96 + 8 * c); }
+    in[k].exp_val = (uint64_t)w[192] | ((uint64_t)w[193] << 32);
   }
   auto cols = air.generate_trace(in);
   size_t n = cols[0].size();

@@ -15,6 +15,7 @@ AIR_G1_EXP = 2
 AIR_G2_EXP = 3
 AIR_FQ12_EXP = 4
 AIR_FQ_EXP = 5
+AIR_FQ12_EXP_U64 = 6
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
@@ -23,7 +24,7 @@ _LIB = None
 EXPORTS = [
     "sbn_version", "sbn_last_error", "sbn_device_count", "sbn_set_device", "sbn_standard_fast_config",
     "sbn_air_num_columns", "sbn_air_num_public_inputs", "sbn_air_num_permutation_zs", "sbn_air_num_constraints",
-    "sbn_generate_trace_g1_exp", "sbn_generate_trace_g2_exp", "sbn_generate_trace_fq12_exp", "sbn_generate_trace_fq_exp",
+    "sbn_generate_trace_g1_exp", "sbn_generate_trace_g2_exp", "sbn_generate_trace_fq12_exp", "sbn_generate_trace_fq_exp", "sbn_generate_trace_fq12_exp_u64",
     "sbn_generate_trace_g1_op",
     "sbn_prover_create", "sbn_prover_destroy", "sbn_prover_load_trace", "sbn_prover_load_trace_device",
     "sbn_prover_prove", "sbn_prover_stage_times", "sbn_prover_stage_name", "sbn_prover_trace_device_ptr",
@@ -76,6 +77,7 @@ def lib():
         L.sbn_generate_trace_g2_exp.argtypes = [vp, sz, vp, vp]
         L.sbn_generate_trace_fq12_exp.argtypes = [vp, sz, vp, vp]
         L.sbn_generate_trace_fq_exp.argtypes = [vp, sz, vp, vp]
+        L.sbn_generate_trace_fq12_exp_u64.argtypes = [vp, sz, vp, vp]
         L.sbn_generate_trace_g1_op.argtypes = [vp, sz, vp]
         L.sbn_prover_create.argtypes = [C.POINTER(_AirDesc), C.POINTER(_Config), u32, C.POINTER(vp)]
         L.sbn_prover_destroy.argtypes = [vp]
@@ -247,6 +249,28 @@ class FqExpStark(_Stark):
         trace = np.zeros((self.num_columns, 512 * self.num_io), dtype=np.uint64)
         pi = np.zeros(self.num_public_inputs, dtype=np.uint64)
         _check(lib().sbn_generate_trace_fq_exp(_ptr(ios), self.num_io, _ptr(trace), _ptr(pi)))
+        return trace, pi
+
+    def generate_trace(self, ios):
+        return self.generate_trace_and_public_inputs(ios)[0]
+
+    def generate_public_inputs(self, ios):
+        return self.generate_trace_and_public_inputs(ios)[1]
+
+
+class Fq12ExpU64Stark(_Stark):
+    """Reference `Fq12ExpU64Stark` (src/fields/fq12_u64/exp_u64.rs:243-571): offset * x^e in Fq12 for a u64 exponent,
+    128 rows per instance."""
+    kind = AIR_FQ12_EXP_U64
+    rows_per_instance = 128
+
+    def generate_trace_and_public_inputs(self, ios):
+        """ios: (num_io, 194) uint32 = x[12] offset[12] (8xu32 LE limbs each) exp_val (low, high)."""
+        ios = np.ascontiguousarray(ios, dtype=np.uint32)
+        assert ios.shape == (self.num_io, 194)
+        trace = np.zeros((self.num_columns, 128 * self.num_io), dtype=np.uint64)
+        pi = np.zeros(self.num_public_inputs, dtype=np.uint64)
+        _check(lib().sbn_generate_trace_fq12_exp_u64(_ptr(ios), self.num_io, _ptr(trace), _ptr(pi)))
         return trace, pi
 
     def generate_trace(self, ios):

@@ -193,6 +193,25 @@ GL_HD void flags_block(const Cons<P>& cs, const Row& row, int s, Horner2<P>& h) 
   for (int c = sl + 1; c < el; c++) h.push(cs, nrf * (row.n(c) - row.l(c)) * cs.z_last);
 }
 static constexpr int FLAGS_CONSTRAINTS = 26;
+// eval_flags_u64 (src/fields/fq12_u64/flags_u64.rs:96-139): 9 constraints; columns is_final, a, b, filtered_bit, bit, val.
+template <class P, class Row>
+GL_HD void flags_u64_block(const Cons<P>& cs, const Row& row, int s, Horner2<P>& h) {
+  const P one = lift<P>(1);
+  const int fin = s, a = s + 1, b = s + 2, fb = s + 3, bitc = s + 4, val = s + 5;
+  P la = row.l(a), lb = row.l(b), bit = row.l(bitc), lfin = row.l(fin);
+  h.push(cs, la * cs.l_first);
+  h.push(cs, (lb - one) * cs.l_first);
+  h.push(cs, bit * bit - bit);
+  h.push(cs, bit * lb - row.l(fb));
+  h.push(cs, (la + row.n(a) - one) * cs.z_last);
+  h.push(cs, (lb + row.n(b) - one) * cs.z_last);
+  P first_limb = row.l(val), next_first_limb = row.n(val), next_bit = row.n(bitc);
+  P is_not_final = one - lfin, is_not_split = one - la;
+  h.push(cs, is_not_final * la * (first_limb - (next_first_limb + next_first_limb) - next_bit) * cs.z_last);
+  h.push(cs, is_not_split * (next_bit - bit) * cs.z_last);
+  h.push(cs, is_not_final * is_not_split * (first_limb - next_first_limb) * cs.z_last);
+}
+static constexpr int FLAGS_U64_CONSTRAINTS = 9;
 
 // eval_lookups (src/utils/lookup.rs:13-34).
 template <class P, class Row>
@@ -457,14 +476,17 @@ GL_HD void fq_gadget(const Cons<P>& cs, const Row& row, P* h_sq, P* h_mul) {
 struct ExpShape {  // constants(num_io): g1/exp.rs:6-34, g2/exp.rs:6-34, fq12/exp.rs:6-34
   // E = 1: G1ExpStark, 2: G2ExpStark (curve tables), 12: Fq12ExpStark (offset * x^e, square-and-multiply),
   // 0: FqExpStark (the same square-and-multiply machine over one Fq coefficient; u32 public inputs, u16 range check;
-  //    constants(num_io): fq/exp.rs:6-34)
+  //    constants(num_io): fq/exp.rs:6-34),
+  // 13: Fq12ExpU64Stark (Fq12ExpStark with a u64 exponent: 128 rows per instance, the 6-column flags of
+  //    fq12_u64/flags_u64.rs, no rotation pulse, one public input for the exponent; constants: fq12_u64/exp_u64.rs:19-45)
   int E, num_io, W, L, pi_per_io, b_col, gadget_col, nx_col, gadget_cons, start_flags, num_main, start_periodic, start_io_pulses, start_lookups;
-  int rc_start, num_rc, split_rc, num_cols, num_pi;
+  int rc_start, num_rc, split_rc, num_cols, num_pi, rpb, n_exp_slots, flag_sq, flag_mul;
   GL_HD ExpShape(int e, int n) {
-    E = e; num_io = n;
-    if (e == 12) {
+    E = e; num_io = n; rpb = 512; n_exp_slots = 8; flag_sq = 2; flag_mul = 4;
+    if (e == 12 || e == 13) {
       W = 192; L = 192; gadget_col = 384; nx_col = 384; gadget_cons = 792; start_flags = 108 * 16;
       rc_start = 384; num_rc = 84 * 16 - 12; split_rc = 1;
+      if (e == 13) { rpb = 128; n_exp_slots = 1; flag_sq = 1; flag_mul = 3; }
     } else if (e == 0) {
       W = 16; L = 8; gadget_col = 32; nx_col = 32; gadget_cons = 66; start_flags = 9 * 16;
       rc_start = 0; num_rc = 9 * 16 - 1; split_rc = 0;
@@ -472,14 +494,16 @@ struct ExpShape {  // constants(num_io): g1/exp.rs:6-34, g2/exp.rs:6-34, fq12/ex
       W = 32 * e; L = 16 * e; gadget_col = 64 * e; nx_col = gadget_col + 16 * e; gadget_cons = 165 * e; start_flags = 384 * e;
       rc_start = 0; num_rc = 381 * e; split_rc = 0;
     }
-    pi_per_io = 3 * L + 8; b_col = W;
-    num_main = start_flags + 14; start_periodic = num_main;
-    start_io_pulses = start_periodic + 2; start_lookups = start_io_pulses + 1 + 4 * n;
+    pi_per_io = 3 * L + n_exp_slots; b_col = W;
+    if (e == 13) { num_main = start_flags + 6; start_periodic = -1; start_io_pulses = num_main; }
+    else { num_main = start_flags + 14; start_periodic = num_main; start_io_pulses = start_periodic + 2; }
+    start_lookups = start_io_pulses + 1 + 4 * n;
     num_cols = start_lookups + 1 + (split_rc ? 6 : 2) * num_rc; num_pi = pi_per_io * n;
   }
   GL_HD int num_pairs() const { return (split_rc ? 4 : 2) * num_rc; }
   GL_HD int num_constraints() const {
-    return 1 + num_pi + 3 * 2 * W + 26 + 2 * gadget_cons + 26 + 5 + 2 + 4 * num_io + (split_rc ? 5 * num_rc + 3 : 2 * num_rc + 3);
+    const int fc = E == 13 ? 9 : 26, pc = E == 13 ? 0 : 5;  // flags constraints, rotation-pulse constraints
+    return 1 + num_pi + 3 * 2 * W + fc + 2 * gadget_cons + fc + pc + 2 + 4 * num_io + (split_rc ? 5 * num_rc + 3 : 2 * num_rc + 3);
   }
   // u16_range_check_pairs (range_check.rs:96-113) / split_u16_range_check_pairs (:230-246)
   GL_HD void pair(int z, int& lhs, int& rhs) const {
@@ -501,20 +525,20 @@ struct ExpShape {  // constants(num_io): g1/exp.rs:6-34, g2/exp.rs:6-34, fq12/ex
   //    output); then exp_val (8, input).
   // Public inputs are stored x, offset, exp_val, output in every table.
   GL_HD int pi_index(int m) const {
-    if (E == 12) {
+    if (E == 12 || E == 13) {
       if (m >= 576) return 384 + (m - 576);
       int c = m / 48, w = m % 48;
-      return w < 16 ? 16 * c + w : (w < 32 ? 192 + 16 * c + (w - 16) : 392 + 16 * c + (w - 32));
+      return w < 16 ? 16 * c + w : (w < 32 ? 192 + 16 * c + (w - 16) : 384 + n_exp_slots + 16 * c + (w - 32));
     }
     return m < 2 * L ? m : (m < 3 * L ? 2 * L + 8 + (m - 2 * L) : 2 * L + (m - 3 * L));
   }
   GL_HD bool slot_is_out(int m) const {
-    if (E == 12) return m < 576 && (m % 48) >= 32;
+    if (E == 12 || E == 13) return m < 576 && (m % 48) >= 32;
     return m >= 2 * L && m < 3 * L;
   }
   // first column of the compared value (a u16 pair for curves, one u16 column for fq12); -1 for the exponent limbs
   GL_HD int slot_col(int m) const {
-    if (E == 12) {
+    if (E == 12 || E == 13) {
       if (m >= 576) return -1;
       int c = m / 48, w = m % 48;
       return w < 16 ? 16 * c + w : (w < 32 ? 192 + 16 * c + (w - 16) : 192 + 16 * c + (w - 32));
@@ -548,7 +572,8 @@ template <int E, class P, class Row>
 GL_HD void exp_eval(Cons<P>& cs, const Row& row, const ExpShape& sh, const ExpPiConsts<P>* pic) {
   const P one = lift<P>(1), base = lift<P>(65536);
   const int sf = sh.start_flags, S = sh.pi_per_io;
-  P is_final = row.l(sf), is_double = row.l(sf + 2), is_add = row.l(sf + 4);
+  constexpr bool F12 = E == 12 || E == 13;  // Fq12 operands (u16 public-input limbs, split range check)
+  P is_final = row.l(sf), is_double = row.l(sf + sh.flag_sq), is_add = row.l(sf + sh.flag_mul);
   P is_not_final = one - is_final;
   // [1] is_final - sum(output pulses)                                         g1/exp.rs:359-365
   // [2] public-input binding, regrouped                                       g1/exp.rs:368-392, g2/exp.rs:382-414
@@ -561,10 +586,10 @@ GL_HD void exp_eval(Cons<P>& cs, const Row& row, const ExpShape& sh, const ExpPi
       int col = sh.slot_col(m);
       if (col >= 0) {
         v = row.l(col);
-        if (E != 12) v = v + base * row.l(col + 1);  // u16_columns_to_u32_columns, utils.rs:56 (curve tables)
+        if (!F12) v = v + base * row.l(col + 1);  // u16_columns_to_u32_columns, utils.rs:56 (curve tables)
       } else {
         int k = m - 3 * sh.L;
-        v = row.l(sf + 6 + k);
+        v = row.l(sf + (E == 13 ? 5 : 6 + k));   // u64 table: the single running value (exp_u64.rs:364-366)
         if (k == 0) v = v + v + is_add;  // limbs[0]*2 + bit  (g1/exp.rs:389)
       }
       bool is_out = sh.slot_is_out(m);
@@ -598,7 +623,7 @@ GL_HD void exp_eval(Cons<P>& cs, const Row& row, const ExpShape& sh, const ExpPi
   }
   // [3] state transitions (fq_equal_transition / fq2_equal_transition x12)      g1/exp.rs:395-461, g2/exp.rs:416-473
   {
-    constexpr int W = E == 12 ? 192 : (E == 0 ? 16 : 32 * E);  // columns of one operand (point / Fq12 element / Fq element)
+    constexpr int W = F12 ? 192 : (E == 0 ? 16 : 32 * E);  // columns of one operand (point / Fq12 element / Fq element)
     Horner2<P> d_na_a, d_nb_b, d_na_new, d_nb_new;  // (next_a - a), (next_b - b), (next_a - new), (next_b - new)
 #pragma unroll
     for (int j = 0; j < SBN_NCH; j++) d_na_a.h[j] = d_nb_b.h[j] = d_na_new.h[j] = d_nb_new.h[j] = lift<P>(0);
@@ -626,20 +651,21 @@ GL_HD void exp_eval(Cons<P>& cs, const Row& row, const ExpShape& sh, const ExpPi
   Horner2<P> hf;
 #pragma unroll
   for (int j = 0; j < SBN_NCH; j++) hf.h[j] = lift<P>(0);
-  flags_block(cs, row, sf, hf);
-  cs.merge(hf.h, one, FLAGS_CONSTRAINTS);
+  constexpr int FC = E == 13 ? FLAGS_U64_CONSTRAINTS : FLAGS_CONSTRAINTS;
+  if (E == 13) flags_u64_block(cs, row, sf, hf); else flags_block(cs, row, sf, hf);
+  cs.merge(hf.h, one, FC);
   {
     P h_add[SBN_NCH], h_dbl[SBN_NCH];
     // curve tables: eval_g*_add (filter is_add) then eval_g*_double (is_double); fq12 / fq: eval_fq*_mul(is_sq, a, a)
     // then eval_fq*_mul(is_mul, a, b) -- is_sq shares the column of is_double, is_mul that of is_add.
     if (E == 1) g1_gadget(cs, row, h_add, h_dbl); else if (E == 2) g2_gadget(cs, row, h_add, h_dbl);
     else if (E == 0) fq_gadget(cs, row, h_dbl, h_add); else fq12_gadget(cs, row, h_dbl, h_add);
-    if (E == 12 || E == 0) { cs.merge(h_dbl, is_double, sh.gadget_cons); cs.merge(h_add, is_add, sh.gadget_cons); }
+    if (F12 || E == 0) { cs.merge(h_dbl, is_double, sh.gadget_cons); cs.merge(h_add, is_add, sh.gadget_cons); }
     else { cs.merge(h_add, is_add, sh.gadget_cons); cs.merge(h_dbl, is_double, sh.gadget_cons); }
   }
-  cs.merge(hf.h, one, FLAGS_CONSTRAINTS);
-  // [8] eval_periodic_pulse(pulse_col = is_rotate, period 64, first_pulse 62)   pulse.rs:146-170
-  {
+  cs.merge(hf.h, one, FC);
+  // [8] eval_periodic_pulse(pulse_col = is_rotate, period 64, first_pulse 62)   pulse.rs:146-170 (not in the u64 table)
+  if (E != 13) {
     const int st = sh.start_periodic;
     P counter = row.l(st), witness = row.l(st + 1), is_reset = row.l(sf + 1), next_counter = row.n(st);
     cs.cf(counter - lift<P>(1));  // period - first_pulse - 1 = 1
@@ -656,7 +682,7 @@ GL_HD void exp_eval(Cons<P>& cs, const Row& row, const ExpShape& sh, const ExpPi
     cs.cf(counter);
     cs.ct(row.n(st) - counter - one);
     for (int i = 0; i < 2 * sh.num_io; i++) {
-      u64 pos = (u64)(i >> 1) * 512 + ((i & 1) ? 511 : 0);  // get_pulse_positions, g1/exp.rs:153-163
+      u64 pos = (u64)(i >> 1) * sh.rpb + ((i & 1) ? sh.rpb - 1 : 0);  // get_pulse_positions, g1/exp.rs:153-163
       P cmp = counter - lift<P>(pos);
       P pulse = row.l(sh.pulse_col(i));
       cs.c(cmp * row.l(sh.witness_col(i)) + pulse - one);
@@ -664,7 +690,7 @@ GL_HD void exp_eval(Cons<P>& cs, const Row& row, const ExpShape& sh, const ExpPi
     }
   }
   // [10] eval_u16_range_check (range_check.rs:49-68) / eval_split_u16_range_check (:162-192)
-  if (E == 12) {
+  if (F12) {
     const P c256 = lift<P>(256);
     const int mc = sh.start_lookups;
     for (int i = 0; i < sh.num_rc; i++) cs.c(row.l(sh.rc_start + i) - (row.l(mc + 1 + 6 * i) + row.l(mc + 4 + 6 * i) * c256));

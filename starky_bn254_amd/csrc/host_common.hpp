@@ -60,14 +60,14 @@ struct AirShape {
   int kind; u32 num_io;
   size_t ncols, npi, npairs, nzs, nconstraints;
 };
-static inline int exp_e(int kind) { return kind == SBN_AIR_FQ12_EXP ? 12 : (kind == SBN_AIR_G2_EXP ? 2 : (kind == SBN_AIR_FQ_EXP ? 0 : 1)); }
+static inline int exp_e(int kind) { return kind == SBN_AIR_FQ12_EXP ? 12 : (kind == SBN_AIR_FQ12_EXP_U64 ? 13 : (kind == SBN_AIR_G2_EXP ? 2 : (kind == SBN_AIR_FQ_EXP ? 0 : 1))); }
 static inline bool air_shape(const sbn_air_desc* air, const sbn_config* cfg, AirShape& s) {
   if (!air) return false;
   s.kind = air->kind; s.num_io = air->num_io;
   u32 nch = cfg ? cfg->num_challenges : 2;
   if (air->kind == SBN_AIR_G1_OP) {
     s.ncols = G1OpShape::NUM_COLS; s.npi = 0; s.npairs = G1OpShape::NUM_PAIRS; s.nconstraints = G1OpShape::NUM_CONSTRAINTS;
-  } else if (air->kind == SBN_AIR_G1_EXP || air->kind == SBN_AIR_G2_EXP || air->kind == SBN_AIR_FQ12_EXP || air->kind == SBN_AIR_FQ_EXP) {
+  } else if (air->kind == SBN_AIR_G1_EXP || air->kind == SBN_AIR_G2_EXP || air->kind == SBN_AIR_FQ12_EXP || air->kind == SBN_AIR_FQ_EXP || air->kind == SBN_AIR_FQ12_EXP_U64) {
     if (air->num_io == 0 || air->num_io > (u32)G1EXP_MAX_IO || (air->num_io & (air->num_io - 1))) return false;
     ExpShape sh(exp_e(air->kind), (int)air->num_io);
     s.ncols = sh.num_cols; s.npi = sh.num_pi; s.npairs = sh.num_pairs(); s.nconstraints = sh.num_constraints();
@@ -76,7 +76,8 @@ static inline bool air_shape(const sbn_air_desc* air, const sbn_config* cfg, Air
   s.nzs = (s.npairs * nch + 1) / 2;
   return true;
 }
-static inline bool is_exp_air(int kind) { return kind == SBN_AIR_G1_EXP || kind == SBN_AIR_G2_EXP || kind == SBN_AIR_FQ12_EXP || kind == SBN_AIR_FQ_EXP; }
+static inline bool is_exp_air(int kind) { return kind == SBN_AIR_G1_EXP || kind == SBN_AIR_G2_EXP || kind == SBN_AIR_FQ12_EXP || kind == SBN_AIR_FQ_EXP || kind == SBN_AIR_FQ12_EXP_U64; }
+static inline size_t exp_rows_per_instance(int kind) { return kind == SBN_AIR_FQ12_EXP_U64 ? 128 : 512; }
 static inline ExpShape exp_shape(const AirShape& a) { return ExpShape(exp_e(a.kind), (int)a.num_io); }
 static inline bool config_supported(const sbn_config* c) {
   return c && c->num_challenges == SBN_NCH && c->rate_bits == 1 && c->cap_height >= 1 && c->cap_height <= 8 &&
@@ -86,8 +87,8 @@ static inline bool config_supported(const sbn_config* c) {
 
 // tracegen.hip: Jacobian curve chains of every G1ExpStark instance on host threads (layout: bn254w.cuh g1_chains)
 int tracegen_host_chains(int E, const uint32_t* ios, size_t K, u64* ja, u64* jb);
-// tracegen.hip: square-and-multiply chains of every Fq12ExpStark instance, standard form, [K][257][12][4] each
-int tracegen_host_chains_fq12(const uint32_t* ios, size_t K, u64* ca, u64* cb);
+// tracegen.hip: square-and-multiply chains of every Fq12ExpStark / Fq12ExpU64Stark instance, standard form, [K][steps+1][12][4] each
+int tracegen_host_chains_fq12(const uint32_t* ios, size_t iow, int steps, size_t K, u64* ca, u64* cb);
 // the same for FqExpStark: [K][257][4] each
 int tracegen_host_chains_fq(const uint32_t* ios, size_t K, u64* ca, u64* cb);
 

@@ -576,7 +576,7 @@ __global__ __launch_bounds__(256) void quotient_kernel(QuotientParams p) {
     g1op_eval(cs, row);
     permutation_checks(cs, row, zrow, G1OpShape(), p.num_zs, F(p.gamma0), F(p.gamma1));
   } else {
-    constexpr int E = KIND == 4 ? 12 : (KIND == 3 ? 2 : (KIND == 5 ? 0 : 1));
+    constexpr int E = KIND == 4 ? 12 : (KIND == 6 ? 13 : (KIND == 3 ? 2 : (KIND == 5 ? 0 : 1)));
     ExpShape sh(E, p.num_io);
     exp_eval<E>(cs, row, sh, (const ExpPiConsts<F>*)p.pic);
     permutation_checks(cs, row, zrow, sh, p.num_zs, F(p.gamma0), F(p.gamma1));

@@ -164,6 +164,18 @@ __global__ void flags_kernel(const uint32_t* __restrict__ ios, size_t iow, size_
   for (int i = 1; i < 8; i++) col(6 + i) = limb(q + i + sh);
 }
 
+// flags of the u64 table (fq12_u64/flags_u64.rs:34-94) in closed form: bit t of e is consumed on rows 2t, 2t+1 of the
+// 128-row instance.  Columns is_final, a, b, filtered_bit, bit, val.
+__global__ void flags_u64_kernel(const uint32_t* __restrict__ ios, size_t iow, size_t n, int sf, u64* __restrict__ trace) {
+  const size_t row = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (row >= n) return;
+  const size_t k = row >> 7; const unsigned r = (unsigned)(row & 127), t = r >> 1;
+  const u64 e = (u64)ios[iow * k + iow - 2] | ((u64)ios[iow * k + iow - 1] << 32);
+  const u64 a = r & 1, b = 1 - a, bit = (e >> t) & 1, val = t == 63 ? 0 : e >> (t + 1);
+  auto col = [&](int c) -> u64& { return trace[(size_t)(sf + c) * n + row]; };
+  col(0) = r == 127; col(1) = a; col(2) = b; col(3) = bit * b; col(4) = bit; col(5) = val;
+}
+
 // inv[i] = 1/i in Goldilocks for i = 1..n-1 (inv[0] = 0).
 __global__ void small_inverse_kernel(u64* __restrict__ inv, size_t n) {
   const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -176,17 +188,19 @@ __global__ void periodic_kernel(const u64* __restrict__ inv, size_t n, int start
   const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (i >= n) return;
   const u64 c = (i + 1) & 63;
-  trace[(size_t)start_periodic * n + i] = c;
-  trace[(size_t)(start_periodic + 1) * n + i] = c == 63 ? 0 : (-F(inv[63 - c])).v;
+  if (start_periodic >= 0) {  // the u64 table has no rotation pulse
+    trace[(size_t)start_periodic * n + i] = c;
+    trace[(size_t)(start_periodic + 1) * n + i] = c == 63 ? 0 : (-F(inv[63 - c])).v;
+  }
   trace[(size_t)start_io_pulses * n + i] = i;
   trace[(size_t)start_lookups * n + i] = i < table_max ? i : table_max;  // 0..table_max then table_max repeated
 }
-// io pulses (pulse.rs:20-43): pulse q sits at row pos(q) = 512*(q/2) + (q odd ? 511 : 0); witness = 1/(i - pos).
-__global__ void io_pulse_kernel(const u64* __restrict__ inv, size_t n, int first_col, u64* __restrict__ trace) {
+// io pulses (pulse.rs:20-43): pulse q sits at row pos(q) = rpb*(q/2) + (q odd ? rpb-1 : 0); witness = 1/(i - pos).
+__global__ void io_pulse_kernel(const u64* __restrict__ inv, size_t n, size_t rpb, int first_col, u64* __restrict__ trace) {
   const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int q = blockIdx.y;
-  const size_t pos = (size_t)(q >> 1) * 512 + ((q & 1) ? 511 : 0);
+  const size_t pos = (size_t)(q >> 1) * rpb + ((q & 1) ? rpb - 1 : 0);
   u64* w = trace + (size_t)(first_col + 2 * q) * n;  // witness_col(q); pulse_col(q) = witness_col(q) + 1
   w[i] = i > pos ? inv[i - pos] : (i < pos ? (-F(inv[pos - i])).v : 0);
   w[n + i] = i == pos;
@@ -197,15 +211,17 @@ __global__ void io_pulse_kernel(const u64* __restrict__ inv, size_t n, int first
 // (A[t] = x^(2^t), B[t]); row r of instance k: a = A[r>>1]; even rows: b = B[r>>1], multiply when the bit is set
 // (product B[(r>>1)+1]); odd rows: b = B[(r>>1)+1], square (product A[(r>>1)+1]).  Writes the 384 limb columns of
 // a and b and the 1344 Fq12Output columns (mul.rs:217-231) straight into the column-major trace.
-__global__ void __launch_bounds__(64) fq12_row_kernel(const uint32_t* __restrict__ ios, const u64* __restrict__ ca, const u64* __restrict__ cb, size_t n,
-                                                      u64* __restrict__ trace, int* __restrict__ err) {
+// Fq12ExpU64Stark (fq12_u64/exp_u64.rs) is the same with 128 rows per instance: log_rpb = 7, iow = 194, 65 chain entries.
+__global__ void __launch_bounds__(64) fq12_row_kernel(const uint32_t* __restrict__ ios, size_t iow, int log_rpb, const u64* __restrict__ ca, const u64* __restrict__ cb,
+                                                      size_t n, u64* __restrict__ trace, int* __restrict__ err) {
   const size_t row = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (row >= n) return;
-  const size_t k = row >> 9; const int r = (int)(row & 511), t = r >> 1; const bool sq = r & 1;
-  const bool bit = (ios[200 * k + 192 + (t >> 5)] >> (t & 31)) & 1;
+  const size_t k = row >> log_rpb, cl = ((size_t)1 << (log_rpb - 1)) + 1;  // chain entries per instance
+  const int r = (int)(row & (((size_t)1 << log_rpb) - 1)), t = r >> 1; const bool sq = r & 1;
+  const bool bit = (ios[iow * k + 192 + (t >> 5)] >> (t & 31)) & 1;
   const int op = sq ? 1 : (bit ? 2 : 0);  // 1 square, 2 multiply
-  const u64 (*a)[4] = reinterpret_cast<const u64 (*)[4]>(ca + ((k * 257 + t) * 12) * 4);
-  const u64 (*b)[4] = reinterpret_cast<const u64 (*)[4]>(cb + ((k * 257 + t + (sq ? 1 : 0)) * 12) * 4);
+  const u64 (*a)[4] = reinterpret_cast<const u64 (*)[4]>(ca + ((k * cl + t) * 12) * 4);
+  const u64 (*b)[4] = reinterpret_cast<const u64 (*)[4]>(cb + ((k * cl + t + (sq ? 1 : 0)) * 12) * 4);
   for (int c = 0; c < 12; c++)
     for (int i = 0; i < 16; i++) {
       trace[(size_t)(16 * c + i) * n + row] = (a[c][i >> 2] >> (16 * (i & 3))) & 0xffff;
@@ -213,7 +229,7 @@ __global__ void __launch_bounds__(64) fq12_row_kernel(const uint32_t* __restrict
     }
   u64* g = trace + (size_t)384 * n + row;
   if (op) {
-    const u64 (*prod)[4] = reinterpret_cast<const u64 (*)[4]>((op == 1 ? ca : cb) + ((k * 257 + t + 1) * 12) * 4);
+    const u64 (*prod)[4] = reinterpret_cast<const u64 (*)[4]>((op == 1 ? ca : cb) + ((k * cl + t + 1) * 12) * 4);
     if (!fq12_output_row(a, op == 1 ? a : b, prod, [&](int i, u64 v) { g[(size_t)i * n] = v; })) atomicOr(err, TG_ERR_WITNESS);
   } else {  // Fq12Output::default (mul.rs:179-187)
     for (int i = 0; i < 1332; i++) g[(size_t)i * n] = 0;

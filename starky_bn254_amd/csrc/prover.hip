@@ -272,8 +272,8 @@ extern "C" int sbn_prover_create(const sbn_air_desc* air, const sbn_config* cfg,
   if (!air_shape(air, cfg, as)) return fail(SBN_ERR_BAD_ARG, "unknown air kind / num_io");
   if (degree_bits < 9 || degree_bits > 22) return fail(SBN_ERR_UNSUPPORTED, "degree_bits out of range");
   if (is_exp_air(as.kind)) {
-    if (((size_t)512 * as.num_io) != ((size_t)1 << degree_bits)) return fail(SBN_ERR_BAD_ARG, "the Exp tables need 512*num_io rows");
-    if (as.kind != SBN_AIR_FQ12_EXP && degree_bits < 16)
+    if ((exp_rows_per_instance(as.kind) * as.num_io) != ((size_t)1 << degree_bits)) return fail(SBN_ERR_BAD_ARG, "the Exp tables need 512*num_io rows (FQ12_EXP_U64: 128*num_io)");
+    if (as.kind != SBN_AIR_FQ12_EXP && as.kind != SBN_AIR_FQ12_EXP_U64 && degree_bits < 16)
       return fail(SBN_ERR_UNSUPPORTED, "G1_EXP / G2_EXP / FQ_EXP need >= 2^16 rows (u16 range check, range_check.rs:26)");
   }
   int ndev = 0;
@@ -464,7 +464,7 @@ static int generate_trace_device(sbn_prover* P, const uint32_t* ios, size_t K, u
   hipLaunchKernelGGL(tg::flags_kernel, blocks(n, 256), dim3(256), 0, st, d_ios, IOW, n, sh.start_flags, P->d_trace);
   hipLaunchKernelGGL(tg::small_inverse_kernel, blocks(n, 256), dim3(256), 0, st, inv, n);
   hipLaunchKernelGGL(tg::periodic_kernel, blocks(n, 256), dim3(256), 0, st, inv, n, sh.start_periodic, sh.start_io_pulses, sh.start_lookups, (u64)65535, P->d_trace);
-  hipLaunchKernelGGL(tg::io_pulse_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)(2 * K)), dim3(256), 0, st, inv, n, sh.witness_col(0), P->d_trace);
+  hipLaunchKernelGGL(tg::io_pulse_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)(2 * K)), dim3(256), 0, st, inv, n, (size_t)sh.rpb, sh.witness_col(0), P->d_trace);
   mark();
   // the two 256-step curve chains per instance: host threads while the device writes the input-independent columns
   if (getenv("SBN_TRACEGEN_DEVICE_CHAIN")) hipLaunchKernelGGL(tg::chain_kernel<E>, blocks(K, 64), dim3(64), 0, st, d_ios, K, ja, jb, d_err);
@@ -520,7 +520,9 @@ static int generate_trace_device(sbn_prover* P, const uint32_t* ios, size_t K, u
 // Fq12ExpStark: the square-and-multiply chains (no inversion anywhere) on host threads in standard form, then one lane
 // per row for the limb columns and the twelve modular-gadget witnesses, and the split range check per target column.
 static int generate_trace_device_fq12(sbn_prover* P, const uint32_t* ios, size_t K, uint64_t* pi_out) {
-  const size_t n = P->n, IOW = 200;
+  const bool u64e = P->air.kind == SBN_AIR_FQ12_EXP_U64;        // 128-row instances, one-element exponent
+  const size_t n = P->n, IOW = u64e ? 194 : 200;
+  const int steps = u64e ? 64 : 256, log_rpb = u64e ? 7 : 9;
   for (size_t k = 0; k < K; k++)
     for (int v = 0; v < 24; v++) {
       u64 t[4]; for (int i = 0; i < 4; i++) t[i] = (u64)ios[IOW * k + 8 * v + 2 * i] | ((u64)ios[IOW * k + 8 * v + 2 * i + 1] << 32);
@@ -532,7 +534,10 @@ static int generate_trace_device_fq12(sbn_prover* P, const uint32_t* ios, size_t
   P->loaded = false;
   u64* w = P->d_lde;
   auto take = [&](size_t words) { u64* r = w; w += (words + 7) & ~(size_t)7; return r; };
-  const size_t cw = 257 * 48 * K;  // one chain of every instance, standard form
+  if (u64e)
+    for (size_t k = 0; k < K; k++)
+      if (((u64)ios[IOW * k + 192] | ((u64)ios[IOW * k + 193] << 32)) >= GLP) return fail(SBN_ERR_NON_CANONICAL, "exponent of instance %zu is not a canonical field element", k);
+  const size_t cw = (size_t)(steps + 1) * 48 * K;  // one chain of every instance, standard form
   u64* ca = take(cw); u64* cb = take(cw);
   u64* inv = take(n);
   uint32_t* d_ios = (uint32_t*)take(IOW * K / 2 + 1);
@@ -548,10 +553,11 @@ static int generate_trace_device_fq12(sbn_prover* P, const uint32_t* ios, size_t
   HIPC(hipMemsetAsync(d_err, 0, sizeof(int), st));
   auto blocks = [](size_t k, unsigned b) { return dim3((unsigned)((k + b - 1) / b)); };
   mark();
-  hipLaunchKernelGGL(tg::flags_kernel, blocks(n, 256), dim3(256), 0, st, d_ios, IOW, n, sh.start_flags, P->d_trace);
+  if (u64e) hipLaunchKernelGGL(tg::flags_u64_kernel, blocks(n, 256), dim3(256), 0, st, d_ios, IOW, n, sh.start_flags, P->d_trace);
+  else hipLaunchKernelGGL(tg::flags_kernel, blocks(n, 256), dim3(256), 0, st, d_ios, IOW, n, sh.start_flags, P->d_trace);
   hipLaunchKernelGGL(tg::small_inverse_kernel, blocks(n, 256), dim3(256), 0, st, inv, n);
   hipLaunchKernelGGL(tg::periodic_kernel, blocks(n, 256), dim3(256), 0, st, inv, n, sh.start_periodic, sh.start_io_pulses, sh.start_lookups, (u64)255, P->d_trace);
-  hipLaunchKernelGGL(tg::io_pulse_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)(2 * K)), dim3(256), 0, st, inv, n, sh.witness_col(0), P->d_trace);
+  hipLaunchKernelGGL(tg::io_pulse_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)(2 * K)), dim3(256), 0, st, inv, n, (size_t)sh.rpb, sh.witness_col(0), P->d_trace);
   mark();
   if (P->h_chain_words < 2 * cw) {
     if (P->h_chain) (void)hipHostFree(P->h_chain);
@@ -559,10 +565,10 @@ static int generate_trace_device_fq12(sbn_prover* P, const uint32_t* ios, size_t
     HIPC(hipHostMalloc((void**)&P->h_chain, 2 * cw * sizeof(u64), hipHostMallocDefault));
     P->h_chain_words = 2 * cw;
   }
-  tracegen_host_chains_fq12(ios, K, P->h_chain, P->h_chain + cw);
+  tracegen_host_chains_fq12(ios, IOW, steps, K, P->h_chain, P->h_chain + cw);
   HIPC(hipMemcpyAsync(ca, P->h_chain, 2 * cw * sizeof(u64), hipMemcpyHostToDevice, st));  // ca and cb are adjacent
   mark();
-  hipLaunchKernelGGL(tg::fq12_row_kernel, blocks(n, 64), dim3(64), 0, st, d_ios, ca, cb, n, P->d_trace, d_err);
+  hipLaunchKernelGGL(tg::fq12_row_kernel, blocks(n, 64), dim3(64), 0, st, d_ios, IOW, log_rpb, ca, cb, n, P->d_trace, d_err);
   mark();
   hipLaunchKernelGGL(tg::split_range_check_kernel, dim3((unsigned)sh.num_rc), dim3(256), 0, st, P->d_trace, n, sh.rc_start, sh.start_lookups, d_err);
   mark();
@@ -587,9 +593,11 @@ static int generate_trace_device_fq12(sbn_prover* P, const uint32_t* ios, size_t
     u64* p = P->pi.data() + (size_t)sh.pi_per_io * k;
     for (int c = 0; c < 24; c++)
       for (int i = 0; i < 16; i++) p[16 * c + i] = (ios[IOW * k + 8 * c + (i >> 1)] >> (16 * (i & 1))) & 0xffff;
-    for (int i = 0; i < 8; i++) p[384 + i] = ios[IOW * k + 192 + i];
-    const u64* out = P->h_chain + cw + ((k * 257 + 256) * 12) * 4;  // B[256]
-    for (int c = 0; c < 12; c++) for (int i = 0; i < 16; i++) p[392 + 16 * c + i] = (out[4 * c + (i >> 2)] >> (16 * (i & 3))) & 0xffff;
+    if (u64e) p[384] = (u64)ios[IOW * k + 192] | ((u64)ios[IOW * k + 193] << 32);
+    else for (int i = 0; i < 8; i++) p[384 + i] = ios[IOW * k + 192 + i];
+    const u64* out = P->h_chain + cw + ((k * (steps + 1) + steps) * 12) * 4;  // B[steps]
+    const int ob = 384 + sh.n_exp_slots;
+    for (int c = 0; c < 12; c++) for (int i = 0; i < 16; i++) p[ob + 16 * c + i] = (out[4 * c + (i >> 2)] >> (16 * (i & 3))) & 0xffff;
   }
   if (pi_out) memcpy(pi_out, P->pi.data(), P->pi.size() * sizeof(u64));
   P->loaded = true;
@@ -625,7 +633,7 @@ static int generate_trace_device_fq(sbn_prover* P, const uint32_t* ios, size_t K
   hipLaunchKernelGGL(tg::flags_kernel, blocks(n, 256), dim3(256), 0, st, d_ios, IOW, n, sh.start_flags, P->d_trace);
   hipLaunchKernelGGL(tg::small_inverse_kernel, blocks(n, 256), dim3(256), 0, st, inv, n);
   hipLaunchKernelGGL(tg::periodic_kernel, blocks(n, 256), dim3(256), 0, st, inv, n, sh.start_periodic, sh.start_io_pulses, sh.start_lookups, (u64)65535, P->d_trace);
-  hipLaunchKernelGGL(tg::io_pulse_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)(2 * K)), dim3(256), 0, st, inv, n, sh.witness_col(0), P->d_trace);
+  hipLaunchKernelGGL(tg::io_pulse_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)(2 * K)), dim3(256), 0, st, inv, n, (size_t)sh.rpb, sh.witness_col(0), P->d_trace);
   if (P->h_chain_words < 2 * cw) {
     if (P->h_chain) (void)hipHostFree(P->h_chain);
     P->h_chain = nullptr; P->h_chain_words = 0;
@@ -662,8 +670,8 @@ extern "C" int sbn_prover_generate_trace(sbn_prover* P, const uint32_t* ios, siz
   if (!P || !ios) return fail(SBN_ERR_BAD_ARG, "null argument");
   if (!is_exp_air(P->air.kind)) return fail(SBN_ERR_UNSUPPORTED, "device witness generation covers the Exp tables (use sbn_generate_trace_g1_op + sbn_prover_load_trace)");
   if (num_io != P->air.num_io) return fail(SBN_ERR_BAD_ARG, "prover was created for %u instances, got %zu", P->air.num_io, num_io);
-  if (P->n != 512 * num_io) return fail(SBN_ERR_BAD_ARG, "degree_bits does not match 512 rows per instance");
-  if (P->air.kind == SBN_AIR_FQ12_EXP) return generate_trace_device_fq12(P, ios, num_io, pi_out);
+  if (P->n != exp_rows_per_instance(P->air.kind) * num_io) return fail(SBN_ERR_BAD_ARG, "degree_bits does not match the rows per instance");
+  if (P->air.kind == SBN_AIR_FQ12_EXP || P->air.kind == SBN_AIR_FQ12_EXP_U64) return generate_trace_device_fq12(P, ios, num_io, pi_out);
   if (P->n != 65536) return fail(SBN_ERR_UNSUPPORTED, "device witness generation needs exactly 2^16 rows (u16 histogram in LDS)");
   if (P->air.kind == SBN_AIR_FQ_EXP) return generate_trace_device_fq(P, ios, num_io, pi_out);
   return P->air.kind == SBN_AIR_G1_EXP ? generate_trace_device<1>(P, ios, num_io, pi_out) : generate_trace_device<2>(P, ios, num_io, pi_out);
@@ -759,6 +767,7 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
     else if (P->air.kind == SBN_AIR_G1_EXP) hipLaunchKernelGGL(quotient_kernel<2>, blocks(m), dim3(256), 0, st, qp);
     else if (P->air.kind == SBN_AIR_G2_EXP) hipLaunchKernelGGL(quotient_kernel<3>, blocks(m), dim3(256), 0, st, qp);
     else if (P->air.kind == SBN_AIR_FQ_EXP) hipLaunchKernelGGL(quotient_kernel<5>, blocks(m), dim3(256), 0, st, qp);
+    else if (P->air.kind == SBN_AIR_FQ12_EXP_U64) hipLaunchKernelGGL(quotient_kernel<6>, blocks(m), dim3(256), 0, st, qp);
     else hipLaunchKernelGGL(quotient_kernel<4>, blocks(m), dim3(256), 0, st, qp);
     HIPC(hipGetLastError());
   }

@@ -165,13 +165,16 @@ static void fill_flags(uint64_t* trace, size_t n, int sf, size_t num_io, const s
     }
   }
 }
-// periodic pulse (pulse.rs:100-144: counter starts at 1, period 64, witness 1/(counter-63)) and io pulses (pulse.rs:20-43)
+// periodic pulse (pulse.rs:100-144: counter starts at 1, period 64, witness 1/(counter-63); absent in the u64 table) and
+// io pulses (pulse.rs:20-43) at the first and last row of every instance
 static void fill_pulses(uint64_t* trace, size_t n, const ExpShape& sh) {
   auto col = [&](int c) { return trace + (size_t)c * n; };
-  const size_t RPB = 512;
+  const size_t RPB = (size_t)sh.rpb;
   std::vector<u64> inv = small_inverses(n);
-  u64* cnt = col(sh.start_periodic); u64* wit = col(sh.start_periodic + 1);
-  for (size_t i = 0; i < n; i++) { u64 c = (i + 1) % 64; cnt[i] = c; wit[i] = c == 63 ? 0 : (-F(inv[63 - c])).v; }
+  if (sh.start_periodic >= 0) {
+    u64* cnt = col(sh.start_periodic); u64* wit = col(sh.start_periodic + 1);
+    for (size_t i = 0; i < n; i++) { u64 c = (i + 1) % 64; cnt[i] = c; wit[i] = c == 63 ? 0 : (-F(inv[63 - c])).v; }
+  }
   u64* cnt2 = col(sh.start_io_pulses);
   for (size_t i = 0; i < n; i++) cnt2[i] = i;
   parallel_for(2 * (size_t)sh.num_io, [&](size_t q) {
@@ -367,17 +370,17 @@ extern "C" int sbn_generate_trace_g1_op(const uint32_t* pts, size_t rows, uint64
 
 // Square-and-multiply chains of every Fq12ExpStark instance on host threads, in standard form:
 // A[t] = x^(2^t), B[0] = offset, B[t+1] = bit_t ? A[t] * B[t] : B[t]  (fq12/exp.rs:165-221: even rows multiply when the
-// bit is set, odd rows square).  ca / cb: [K][257][12][4] u64.
+// bit is set, odd rows square).  ca / cb: [K][steps+1][12][4] u64; steps = 256 (iow = 200) or, for the u64 table, 64 (iow = 194).
 namespace sbn {
-int tracegen_host_chains_fq12(const uint32_t* ios, size_t K, u64* ca, u64* cb) {
+int tracegen_host_chains_fq12(const uint32_t* ios, size_t iow, int steps, size_t K, u64* ca, u64* cb) {
   parallel_for(K, [&](size_t k) {
-    const uint32_t* io = ios + 200 * k;
+    const uint32_t* io = ios + iow * k;
     Fq a[12], b[12], prod[12];
     for (int c = 0; c < 12; c++) { u64 t[4]; u32x8_to_u64x4(io + 8 * c, t); a[c] = to_m(t); u32x8_to_u64x4(io + 96 + 8 * c, t); b[c] = to_m(t); }
     for (int t = 0;; t++) {
-      u64* pa = ca + ((k * 257 + t) * 12) * 4; u64* pb = cb + ((k * 257 + t) * 12) * 4;
+      u64* pa = ca + ((k * (steps + 1) + t) * 12) * 4; u64* pb = cb + ((k * (steps + 1) + t) * 12) * 4;
       for (int c = 0; c < 12; c++) { from_m(a[c], pa + 4 * c); from_m(b[c], pb + 4 * c); }
-      if (t == 256) break;
+      if (t == steps) break;
       if ((io[192 + (t >> 5)] >> (t & 31)) & 1) { fq12_mul_m(a, b, prod); memcpy(b, prod, sizeof b); }
       fq12_mul_m(a, a, prod); memcpy(a, prod, sizeof a);
     }
@@ -507,6 +510,59 @@ extern "C" int sbn_generate_trace_fq_exp(const uint32_t* ios, size_t num_io, uin
     });
     if (bad) return fail(SBN_ERR_WITNESS, "range-checked column holds a value >= 2^16");
   }
+  return SBN_OK;
+}
+
+// ---- Fq12ExpU64Stark (src/fields/fq12_u64/exp_u64.rs:147-313, flags_u64.rs:34-94) -----------------------------------
+extern "C" int sbn_generate_trace_fq12_exp_u64(const uint32_t* ios, size_t num_io, uint64_t* trace, uint64_t* pi_out) {
+  if (!ios || !trace || !pi_out || num_io == 0 || num_io > (size_t)G1EXP_MAX_IO || (num_io & (num_io - 1))) return fail(SBN_ERR_BAD_ARG, "bad arguments");
+  const ExpShape sh(13, (int)num_io);
+  const size_t RPB = 128, n = RPB * num_io, IOW = 194;
+  if (n < 512) return fail(SBN_ERR_UNSUPPORTED, "the prover needs >= 2^9 rows (num_io >= 4)");
+  const int sf = sh.start_flags;
+  auto col = [&](int c) { return trace + (size_t)c * n; };
+  for (size_t k = 0; k < num_io; k++) {
+    for (int c = 0; c < 24; c++) { u64 t[4]; from_u32(ios + IOW * k + 8 * c, t); if (geq_p(t)) return fail(SBN_ERR_BAD_ARG, "coefficient >= p (instance %zu)", k); }
+    const u64 e = (u64)ios[IOW * k + 192] | ((u64)ios[IOW * k + 193] << 32);
+    if (e >= GLP) return fail(SBN_ERR_NON_CANONICAL, "exponent of instance %zu is not a canonical field element", k);
+  }
+  std::atomic<int> bad(0);
+  parallel_for(num_io, [&](size_t k) {
+    const u64 e = (u64)ios[IOW * k + 192] | ((u64)ios[IOW * k + 193] << 32);
+    Fq a[12], b[12], prod[12];
+    u64 as[12][4], bs[12][4], ps[12][4];
+    for (int c = 0; c < 12; c++) { u64 t[4]; from_u32(ios + IOW * k + 8 * c, t); a[c] = to_m(t); from_u32(ios + IOW * k + 96 + 8 * c, t); b[c] = to_m(t); }
+    int prev_op = 0;  // 0 none, 1 square (a <- prod), 2 multiply (b <- prod)
+    std::vector<u64> lv(1344);
+    for (size_t r = 0; r < RPB; r++) {
+      const size_t row = k * RPB + r;
+      // flags (flags_u64.rs:34-94) in closed form: bit t of e is consumed on rows 2t, 2t+1
+      const unsigned t = (unsigned)(r >> 1);
+      const u64 fa = r & 1, fb = 1 - fa, bit = (e >> t) & 1, val = t == 63 ? 0 : e >> (t + 1);
+      col(sf)[row] = r == RPB - 1; col(sf + 1)[row] = fa; col(sf + 2)[row] = fb; col(sf + 3)[row] = bit * fb; col(sf + 4)[row] = bit; col(sf + 5)[row] = val;
+      if (prev_op == 1) memcpy(a, prod, sizeof a); else if (prev_op == 2) memcpy(b, prod, sizeof b);
+      for (int c = 0; c < 12; c++) { from_m(a[c], as[c]); from_m(b[c], bs[c]); put_limbs(col(16 * c) + row, n, as[c]); put_limbs(col(192 + 16 * c) + row, n, bs[c]); }
+      const int op = fa ? 1 : (bit ? 2 : 0);  // odd rows square, even rows multiply when the bit is set
+      if (op) {
+        fq12_mul_m(a, op == 1 ? a : b, prod);
+        for (int c = 0; c < 12; c++) from_m(prod[c], ps[c]);
+        if (!fq12_output_row(as, op == 1 ? as : bs, ps, [&](int i, u64 v) { lv[i] = v; })) { bad = 1; return; }
+      } else {  // Fq12Output::default (mul.rs:179-187)
+        for (int i = 0; i < 1332; i++) lv[i] = 0;
+        for (int i = 1332; i < 1344; i++) lv[i] = 1;
+      }
+      for (int c = 0; c < 1344; c++) col(384 + c)[row] = lv[c];
+      prev_op = op;
+    }
+    // public inputs: x, offset as 16-bit limbs, exp_val (one element), output = b at the last row (exp_u64.rs:100-128)
+    u64* p = pi_out + (size_t)sh.pi_per_io * k;
+    for (int c = 0; c < 24; c++) { u64 t[4]; from_u32(ios + IOW * k + 8 * c, t); for (int i = 0; i < 16; i++) p[16 * c + i] = (t[i / 4] >> (16 * (i % 4))) & 0xffff; }
+    p[384] = e;
+    for (int c = 0; c < 12; c++) for (int i = 0; i < 16; i++) p[385 + 16 * c + i] = (bs[c][i / 4] >> (16 * (i % 4))) & 0xffff;
+  });
+  if (bad) return fail(SBN_ERR_WITNESS, "modular witness generation failed");
+  fill_pulses(trace, n, sh);
+  if (!fill_split_range_check(trace, n, sh.start_lookups, sh.rc_start, sh.num_rc)) return fail(SBN_ERR_WITNESS, "range-checked column holds a value >= 2^16");
   return SBN_OK;
 }
 

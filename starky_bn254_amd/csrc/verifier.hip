@@ -89,7 +89,7 @@ extern "C" int sbn_verify(const sbn_air_desc* air, const sbn_config* cfg, const 
   if (ncol != as.ncols || nz != as.nzs || nq != 2 * cfg->num_challenges || npi != as.npi || cap_h != cfg->cap_height || rate_bits != cfg->rate_bits ||
       nlayers != fs.arity_bits.size() || arity_bits != cfg->fri_arity_bits || fpl != fs.final_poly_len() || nqueries != cfg->num_query_rounds)
     return fail(SBN_ERR_MALFORMED_PROOF, "proof shape does not match the table / config");
-  if (is_exp_air(as.kind) && ((u64)512 * as.num_io) != ((u64)1 << degree_bits)) return fail(SBN_ERR_MALFORMED_PROOF, "degree_bits does not match num_io");
+  if (is_exp_air(as.kind) && ((u64)exp_rows_per_instance(as.kind) * as.num_io) != ((u64)1 << degree_bits)) return fail(SBN_ERR_MALFORMED_PROOF, "degree_bits does not match num_io");
   const u32 lde_bits = (u32)degree_bits + cfg->rate_bits;
   if (lde_bits < cfg->cap_height + fs.total_arity()) return fail(SBN_ERR_MALFORMED_PROOF, "degree too small for the FRI parameters");
   const size_t capn = (size_t)1 << cfg->cap_height;
@@ -181,7 +181,7 @@ extern "C" int sbn_verify(const sbn_air_desc* air, const sbn_config* cfg, const 
     static thread_local ExpPiConsts<E2> pic;
     const E2* app[SBN_NCH] = {apow[0].data(), apow[1].data()};
     exp_pi_consts<E2>(sh, app, epi.data(), pic);
-    if (sh.E == 1) exp_eval<1>(cs, row, sh, &pic); else if (sh.E == 2) exp_eval<2>(cs, row, sh, &pic); else if (sh.E == 0) exp_eval<0>(cs, row, sh, &pic); else exp_eval<12>(cs, row, sh, &pic);
+    if (sh.E == 1) exp_eval<1>(cs, row, sh, &pic); else if (sh.E == 2) exp_eval<2>(cs, row, sh, &pic); else if (sh.E == 0) exp_eval<0>(cs, row, sh, &pic); else if (sh.E == 13) exp_eval<13>(cs, row, sh, &pic); else exp_eval<12>(cs, row, sh, &pic);
     permutation_checks(cs, row, zrow, sh, (int)nz, g0, g1);
   }
   for (u32 i = 0; i < cfg->num_challenges; i++) {

@@ -79,3 +79,11 @@ def fqexp_case(O):
     trace, pi = O.fqexp_trace(ios)
     return {"ios": ios, "native": native, "trace": trace, "pi": pi}
 
+
+@pytest.fixture(scope="session")
+def fq12expu64_case(O):
+    """Seeded Fq12ExpU64Stark(16) trace (2^11 rows x 9792 columns), the size of the reference's test_fq12_exp_u64_raw."""
+    ios, native = O.fq12expu64_inputs(16, 5)
+    trace, pi = O.fq12expu64_trace(ios)
+    return {"ios": ios, "native": native, "trace": trace, "pi": pi}
+

@@ -12,7 +12,7 @@ What pins what (the reference itself has NO golden vectors -- SURVEY.md section 
   flags_native.json      the reference's test_flag_native property inputs (flags.rs:334-369) for one exponent.
   proof_digests.json     sha256 of the ORACLE's canonical proof words for seeded G1Stark-512 / G1ExpStark-2^16
                          traces: pins GPU == oracle without re-running the 100 s CPU prover.
-Run from the repo root:  python3 tests/golden/make_golden.py [--with-g1exp] [--with-g2exp] [--with-fq12exp] [--with-fqexp]
+Run from the repo root:  python3 tests/golden/make_golden.py [--with-g1exp] [--with-g2exp] [--with-fq12exp] [--with-fqexp] [--with-fq12expu64]
 """
 import hashlib, json, os, sys
 import numpy as np
@@ -208,6 +208,15 @@ def main():
         w, secs = O.prove(O.AIR_FQ_EXP, 128, tr, pi)
         assert O.verify(O.AIR_FQ_EXP, 128, w)[0] == 0
         digests["fqexp_io128_seed4"] = {
+            "trace_sha256": hashlib.sha256(tr.tobytes()).hexdigest(), "pi_sha256": hashlib.sha256(pi.tobytes()).hexdigest(),
+            "proof_words": int(len(w)), "proof_sha256": hashlib.sha256(w.astype("<u8").tobytes()).hexdigest(),
+            "trace_cap0": [int(x) for x in w[12:16]], "pow_witness": int(w[-1 - len(pi)]), "oracle_prove_seconds_8core": secs}
+    if "--with-fq12expu64" in sys.argv:     # ~20 s on 8 cores
+        ios, _ = O.fq12expu64_inputs(16, 5)
+        tr, pi = O.fq12expu64_trace(ios)
+        w, secs = O.prove(O.AIR_FQ12_EXP_U64, 16, tr, pi)
+        assert O.verify(O.AIR_FQ12_EXP_U64, 16, w)[0] == 0
+        digests["fq12expu64_io16_seed5"] = {
             "trace_sha256": hashlib.sha256(tr.tobytes()).hexdigest(), "pi_sha256": hashlib.sha256(pi.tobytes()).hexdigest(),
             "proof_words": int(len(w)), "proof_sha256": hashlib.sha256(w.astype("<u8").tobytes()).hexdigest(),
             "trace_cap0": [int(x) for x in w[12:16]], "pow_witness": int(w[-1 - len(pi)]), "oracle_prove_seconds_8core": secs}

@@ -478,3 +478,39 @@ def fqexp_trace(ios):
     L.orc_fqexp_generate_trace.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     L.orc_fqexp_generate_trace(ptr(ios), num_io, ptr(trace), ptr(pi))
     return trace, pi
+
+
+# ---- Fq12ExpU64Stark (src/fields/fq12_u64/exp_u64.rs) ------------------------------------------------------------------
+AIR_FQ12_EXP_U64 = 6
+GL_P = 0xFFFFFFFF00000001
+
+
+def fq12expu64_inputs(num_io, seed):
+    """Mirror of src/fields/fq12_u64/exp_u64.rs:607-621 with seeded randomness: random Fq12 x, offset; the exponent is a
+    canonical Goldilocks element (F::sample(..).to_canonical_u64())."""
+    rng = np.random.default_rng(seed)
+    ios = np.zeros((num_io, 194), dtype=np.uint32)
+    native = []
+    for k in range(num_io):
+        x = [int.from_bytes(rng.bytes(32), "little") % BN_P for _ in range(12)]
+        off = [int.from_bytes(rng.bytes(32), "little") % BN_P for _ in range(12)]
+        e = int.from_bytes(rng.bytes(8), "little") % GL_P
+        for c in range(12):
+            ios[k, 8 * c:8 * c + 8] = u32_limbs(x[c])
+            ios[k, 96 + 8 * c:96 + 8 * c + 8] = u32_limbs(off[c])
+        ios[k, 192:194] = [e & 0xFFFFFFFF, e >> 32]
+        native.append((x, off, e))
+    return ios, native
+
+
+def fq12expu64_trace(ios):
+    num_io = ios.shape[0]
+    L = lib()
+    ncols = L.orc_air_num_columns(AIR_FQ12_EXP_U64, num_io)
+    npi = L.orc_air_num_public_inputs(AIR_FQ12_EXP_U64, num_io)
+    trace = np.zeros((ncols, 128 * num_io), dtype=np.uint64)
+    pi = np.zeros(npi, dtype=np.uint64)
+    ios = np.ascontiguousarray(ios, dtype=np.uint32)
+    L.orc_fq12expu64_generate_trace.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    L.orc_fq12expu64_generate_trace(ptr(ios), num_io, ptr(trace), ptr(pi))
+    return trace, pi

@@ -346,3 +346,33 @@ def test_fqexp_proof_and_device_witness_match_oracle(gpu, O, fqexp_case, golden)
     finally:
         prover.close()
 
+
+def test_fq12expu64_proof_matches_oracle_digest_and_verifies(gpu, O, fq12expu64_case, golden):
+    """Fq12ExpU64Stark(16), 2^11 rows x 9792 columns (the reference's test_fq12_exp_u64_raw): GPU proof bytes == the CPU
+    oracle's (committed sha256), both verifiers accept, tampering rejected."""
+    stark = gpu.Fq12ExpU64Stark(16)
+    cfg = stark.config()
+    prover = gpu.Prover(stark, cfg, 11)
+    try:
+        prover.load_trace(fq12expu64_case["trace"], fq12expu64_case["pi"])
+        proof = prover.prove()
+        # the same instances with the witness generated on the device
+        assert np.array_equal(prover.generate_trace(fq12expu64_case["ios"]), fq12expu64_case["pi"])
+        bad = np.nonzero((prover.read_trace() != fq12expu64_case["trace"]).any(axis=1))[0]
+        assert bad.size == 0, f"first differing columns: {bad[:8].tolist()}"
+        assert np.array_equal(prover.prove().words, proof.words)
+    finally:
+        prover.close()
+    g = golden["proof_digests"]["fq12expu64_io16_seed5"]
+    assert len(proof.words) == g["proof_words"]
+    assert [int(x) for x in proof.words[12:16]] == g["trace_cap0"]
+    assert hashlib.sha256(proof.to_bytes()).hexdigest() == g["proof_sha256"]
+    assert O.verify(O.AIR_FQ12_EXP_U64, 16, proof.words) == (0, "")
+    gpu.verify_stark_proof(stark, proof, cfg)
+    assert proof.recover_degree_bits(cfg) == 11
+    t = proof.words.copy()
+    t[12 + 3 * 64 + 9] = (int(t[12 + 3 * 64 + 9]) + 1) % P
+    assert O.verify(O.AIR_FQ12_EXP_U64, 16, t)[0] != 0
+    with pytest.raises(gpu.SbnError):
+        gpu.verify_stark_proof(stark, gpu.Proof(t, 11), cfg)
+

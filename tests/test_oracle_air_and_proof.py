@@ -71,6 +71,23 @@ def test_fqexp_constraints_vanish_on_trace_and_power(O, fqexp_case):
     assert O.eval_constraints(O.AIR_FQ_EXP, 128, bad, tr[:, 8], pi, alphas, zl, lf, ll) != [0, 0]
 
 
+def test_fq12expu64_constraints_vanish_on_trace(O, fq12expu64_case):
+    """Fq12ExpU64Stark (src/fields/fq12_u64/exp_u64.rs, flags_u64.rs): every constraint vanishes on the generated trace
+    (multiply / square / idle rows, instance boundaries at multiples of 128, wrap-around); a wrong exponent is caught."""
+    tr, pi = fq12expu64_case["trace"], fq12expu64_case["pi"]
+    n = tr.shape[1]
+    L = O.lib()
+    assert (L.orc_air_num_columns(O.AIR_FQ12_EXP_U64, 16), L.orc_air_num_public_inputs(O.AIR_FQ12_EXP_U64, 16), L.orc_air_num_permutation_zs(O.AIR_FQ12_EXP_U64, 16)) == (9792, 9232, 5328)
+    alphas = [0x0f0e0d0c0b0a0908, 0x1020304050607080]
+    for i in [0, 1, 2, 3, 126, 127, 128, 129, 1000, n - 2, n - 1]:
+        zl, lf, ll = _trace_domain_consumer_args(n, i)
+        assert O.eval_constraints(O.AIR_FQ12_EXP_U64, 16, tr[:, i], tr[:, (i + 1) % n], pi, alphas, zl, lf, ll) == [0, 0], f"row {i}"
+    pi2 = pi.copy()
+    pi2[384] = (int(pi2[384]) + 2) % O.GL_P                         # instance 0 exponent
+    zl, lf, ll = _trace_domain_consumer_args(n, 0)
+    assert O.eval_constraints(O.AIR_FQ12_EXP_U64, 16, tr[:, 0], tr[:, 1], pi2, alphas, zl, lf, ll) != [0, 0]
+
+
 def test_g1exp_shape(O):
     L = O.lib()
     assert L.orc_air_num_columns(O.AIR_G1_EXP, 128) == 1676           # SURVEY Appendix A

@@ -206,6 +206,28 @@ def test_fqexp_shape_tracegen_and_power(S, O, fqexp_case, golden):
     assert e.value.code == -7
 
 
+def test_fq12expu64_shape_tracegen_and_power(S, O, fq12expu64_case, golden):
+    """Fq12ExpU64Stark(16) (src/fields/fq12_u64/exp_u64.rs, the reference's test_fq12_exp_u64_raw size): shape constants,
+    host witness generation bit-equal to the oracle's, outputs = offset * x^e in Fq12 with Python integers."""
+    stark = S.Fq12ExpU64Stark(16)
+    cfg = stark.config()
+    assert (stark.num_columns, stark.num_public_inputs, stark.num_permutation_zs(cfg)) == (9792, 9232, 5328)
+    trace, pi = stark.generate_trace_and_public_inputs(fq12expu64_case["ios"])
+    assert np.array_equal(trace, fq12expu64_case["trace"]) and np.array_equal(pi, fq12expu64_case["pi"])
+    g = golden["proof_digests"]["fq12expu64_io16_seed5"]
+    assert hashlib.sha256(trace.tobytes()).hexdigest() == g["trace_sha256"]
+    assert hashlib.sha256(pi.tobytes()).hexdigest() == g["pi_sha256"]
+    for k in (0, 9, 15):
+        x, off, e = fq12expu64_case["native"][k]
+        got = [sum(int(pi[577 * k + 385 + 16 * c + i]) << (16 * i) for i in range(16)) for c in range(12)]
+        assert got == O.fq12_mul(off, O.fq12_pow(x, e)) and int(pi[577 * k + 384]) == e
+    bad = fq12expu64_case["ios"].copy()
+    bad[2, 192:194] = 0xFFFFFFFF                                   # exponent >= the Goldilocks modulus
+    with pytest.raises(S.SbnError) as e:
+        stark.generate_trace_and_public_inputs(bad)
+    assert e.value.code == -2
+
+
 def test_generated_tables_and_instruction_streams_are_current(tmp_path):
     """Every committed *.inc under csrc/ (Poseidon constants, sparse partial-round tables, MDS / S-box / fold / multiply
     instruction streams) is what its generator in tools/ produces; the generators check their own algebra
