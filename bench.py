@@ -128,36 +128,24 @@ def main():
     S.verify_stark_proof(stark, proof, cfg)
 
     # batch mode, reported beside the single-proof line: 3 independent proofs in flight on this GPU (one prover context
-    # and one host thread each), which fills the latency-bound tails and the host-transcript gaps of one proof with the
-    # kernels of the others.  Outside the timed region; rank 0 of a single-GPU run only.
+    # and one host thread each, include/sbn.h sbn_batch_prover_*), which fills the latency-bound tails and the
+    # host-transcript gaps of one proof with the kernels of the others.  Units are instance lists: witness generation
+    # (on the device) is part of the measured work.  Outside the timed region; rank 0 of a single-GPU run only.
     batch = None
     if rank == 0 and world == 1 and max(args.concurrency, 1) == 1 and not args.no_batch_mode:
-        import threading
-        inflight, reps = 3, max(4, min(args.steps, 10))
-        provers = [prover]
-        for _ in range(inflight - 1):
-            p2 = S.Prover(stark, cfg, DEGREE_BITS)
-            p2.load_trace(trace, pi)
-            provers.append(p2)
-        for p in provers:
-            p.prove()
+        inflight, units = 3, 3 * max(4, min(args.steps, 10))
+        bp = S.BatchProver(stark, cfg, DEGREE_BITS, inflight)          # C ABI: sbn_batch_prover_*
+        ios_units = np.broadcast_to(ios, (units,) + ios.shape)
+        bp.prove_ios(ios_units[:inflight])                             # warm-up
         torch.cuda.synchronize()
-
-        def run(p):
-            for _ in range(reps):
-                p.prove()
         t0 = time.perf_counter()
-        ths = [threading.Thread(target=run, args=(p,)) for p in provers]
-        for th in ths:
-            th.start()
-        for th in ths:
-            th.join()
+        proofs = bp.prove_ios(ios_units)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        batch = {"proofs_in_flight": inflight, "proofs": inflight * reps, "proofs_per_s": inflight * reps / dt,
-                 "ms_per_proof_throughput": dt / (inflight * reps) * 1e3}
-        for p in provers[1:]:
-            p.close()
+        batch = {"proofs_in_flight": inflight, "proofs": units, "proofs_per_s": units / dt, "ms_per_proof_throughput": dt / units * 1e3,
+                 "from": "instance lists (witness generated on the device inside the timed region)",
+                 "same_proofs_as_single": bool(all((p.words == proof.words).all() for p in proofs))}
+        bp.close()
 
     # instance list -> proof with the witness generated on the device (outside the timed region, reported
     # beside the host-generator + PCIe path): wall clock of generate_trace + prove, 5 repetitions after one warm-up

@@ -150,6 +150,16 @@ int sbn_prover_read_trace(sbn_prover* p, uint64_t* trace_out);
 int sbn_prove(const sbn_air_desc* air, const sbn_config* cfg, const uint64_t* trace_col_major, uint32_t degree_bits,
               const uint64_t* public_inputs, size_t n_pi, sbn_proof** out);
 
+/* Batch mode (BASELINE config "batch of independent proofs"): `inflight` prover contexts on the current GPU with one
+ * host thread each.  Every unit is one instance list of the table (`num_io` instances, `ios_words_per_unit` u32 words,
+ * layouts as for sbn_generate_trace_*): its witness is generated on the device and proved; proofs_out[count] receives
+ * the proofs in unit order (all freed and an error returned if any unit fails).  The reference counterpart is the loop
+ * of `G1ExpStarkyProofGenerator::run_once` calls over chunks of 128 instances (src/curves/g1/circuit.rs:161-202). */
+typedef struct sbn_batch_prover sbn_batch_prover;
+int sbn_batch_prover_create(const sbn_air_desc* air, const sbn_config* cfg, uint32_t degree_bits, uint32_t inflight, sbn_batch_prover** out);
+int sbn_batch_prover_prove_ios(sbn_batch_prover* b, const uint32_t* ios, size_t ios_words_per_unit, size_t num_io, size_t count, sbn_proof** proofs_out);
+void sbn_batch_prover_destroy(sbn_batch_prover* b);
+
 /* Proof object ---------------------------------------------------------------------------------- */
 size_t sbn_proof_num_words(const sbn_proof* proof);
 const uint64_t* sbn_proof_words(const sbn_proof* proof);

@@ -29,6 +29,7 @@ EXPORTS = [
     "sbn_prover_create", "sbn_prover_destroy", "sbn_prover_load_trace", "sbn_prover_load_trace_device",
     "sbn_prover_prove", "sbn_prover_stage_times", "sbn_prover_stage_name", "sbn_prover_trace_device_ptr",
     "sbn_prover_generate_trace", "sbn_prover_read_trace",
+    "sbn_batch_prover_create", "sbn_batch_prover_prove_ios", "sbn_batch_prover_destroy",
     "sbn_prove", "sbn_proof_num_words", "sbn_proof_words", "sbn_proof_serialize", "sbn_proof_degree_bits",
     "sbn_proof_free", "sbn_verify", "sbn_commit_values", "sbn_poseidon_permute_batch", "sbn_poseidon_permute_host",
 ]
@@ -89,6 +90,9 @@ def lib():
         L.sbn_prover_trace_device_ptr.argtypes = [vp]
         L.sbn_prover_generate_trace.argtypes = [vp, vp, sz, vp]
         L.sbn_prover_read_trace.argtypes = [vp, vp]
+        L.sbn_batch_prover_create.argtypes = [C.POINTER(_AirDesc), C.POINTER(_Config), u32, u32, C.POINTER(vp)]
+        L.sbn_batch_prover_prove_ios.argtypes = [vp, vp, sz, sz, sz, C.POINTER(vp)]
+        L.sbn_batch_prover_destroy.argtypes = [vp]
         L.sbn_prove.argtypes = [C.POINTER(_AirDesc), C.POINTER(_Config), vp, u32, vp, sz, C.POINTER(vp)]
         L.sbn_proof_num_words.restype = sz
         L.sbn_proof_num_words.argtypes = [vp]
@@ -348,6 +352,34 @@ class Prover:
     def close(self):
         if self._h:
             lib().sbn_prover_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class BatchProver:
+    """`inflight` prover contexts on one GPU: proves a batch of instance lists (witness generated on the device)."""
+
+    def __init__(self, stark, config, degree_bits, inflight=3):
+        self.stark, self.config, self.degree_bits = stark, config, degree_bits
+        self._h = C.c_void_p()
+        _check(lib().sbn_batch_prover_create(C.byref(stark._d), C.byref(config._c), degree_bits, inflight, C.byref(self._h)))
+
+    def prove_ios(self, ios_units):
+        """ios_units: (count, num_io, words_per_instance) uint32 -> list of Proof, in unit order."""
+        ios = np.ascontiguousarray(ios_units, dtype=np.uint32)
+        count, num_io, w = ios.shape
+        out = (C.c_void_p * count)()
+        _check(lib().sbn_batch_prover_prove_ios(self._h, _ptr(ios), num_io * w, num_io, count, out))
+        return [_take_proof(C.c_void_p(h)) for h in out]
+
+    def close(self):
+        if self._h:
+            lib().sbn_batch_prover_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

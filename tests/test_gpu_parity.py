@@ -376,3 +376,28 @@ def test_fq12expu64_proof_matches_oracle_digest_and_verifies(gpu, O, fq12expu64_
     with pytest.raises(gpu.SbnError):
         gpu.verify_stark_proof(stark, gpu.Proof(t, 11), cfg)
 
+
+def test_batch_prover_matches_single_proofs(gpu, g1exp_case, g1exp_gpu_proof):
+    """sbn_batch_prover_* (batch mode, 3 proofs in flight, witness generated on the device): every unit's proof equals
+    the proof of the same instance list proved alone; a failing unit fails the batch and frees everything."""
+    stark, cfg, p1, _, _ = g1exp_gpu_proof
+    ios = g1exp_case["ios"]
+    other = ios.copy()
+    other[:, 32:40] = np.random.default_rng(3).integers(0, 1 << 32, size=(128, 8), dtype=np.uint64).astype(np.uint32)
+    bp = gpu.BatchProver(stark, cfg, 16, 3)
+    try:
+        proofs = bp.prove_ios(np.stack([ios, other, ios, other, ios]))
+        assert len(proofs) == 5
+        for k in (0, 2, 4):
+            assert np.array_equal(proofs[k].words, p1.words)
+        assert np.array_equal(proofs[1].words, proofs[3].words) and not np.array_equal(proofs[1].words, p1.words)
+        gpu.verify_stark_proof(stark, proofs[1], cfg)
+        bad = ios.copy()
+        bad[5, 16:32] = bad[5, 0:16]
+        bad[5, 32] |= 1                                            # x1 == x2 in the first addition of instance 5
+        with pytest.raises(gpu.SbnError) as e:
+            bp.prove_ios(np.stack([ios, bad, ios]))
+        assert e.value.code == -8
+    finally:
+        bp.close()
+
