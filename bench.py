@@ -146,6 +146,28 @@ def main():
                  "from": "instance lists (witness generated on the device inside the timed region)",
                  "same_proofs_as_single": bool(all((p.words == proof.words).all() for p in proofs))}
         bp.close()
+        # the same with the traces already resident in HBM (one prover context and host thread per proof in flight)
+        import threading
+        provers = [prover] + [S.Prover(stark, cfg, DEGREE_BITS) for _ in range(inflight - 1)]
+        for p in provers[1:]:
+            p.load_trace(trace, pi)
+            p.prove()
+        reps = units // inflight
+
+        def run(p):
+            for _ in range(reps):
+                p.prove()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ths = [threading.Thread(target=run, args=(p,)) for p in provers]
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        torch.cuda.synchronize()
+        batch["resident_traces_proofs_per_s"] = inflight * reps / (time.perf_counter() - t0)
+        for p in provers[1:]:
+            p.close()
 
     # instance list -> proof with the witness generated on the device (outside the timed region, reported
     # beside the host-generator + PCIe path): wall clock of generate_trace + prove, 5 repetitions after one warm-up
