@@ -235,6 +235,7 @@ def main():
         print(json.dumps(line), flush=True)
     prover.close()
     if dist is not None:
+        dist.barrier()                  # rank 0 did the extra end-to-end leg: leave together
         dist.destroy_process_group()
 
 

@@ -141,9 +141,9 @@ static int ntt_columns(sbn_prover* P, const u64* in, size_t in_cs, u64* out, siz
 
 static u64 host_inv_pow2(u32 k) { return f_inv(F((u64)1 << k)).v; }
 // the R = 512 fast pass needs 69,632 bytes of dynamic LDS (> the 64 KiB default)
-static int ntt_fast_setup() {
-  static bool done = false;
-  if (!done) { HIPC(hipFuncSetAttribute((const void*)ntt_fast_pass_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 32 * 272 * 8)); done = true; }
+static int ntt_fast_setup() {  // idempotent, so a race between prover threads is harmless; the flag only saves the call
+  static std::atomic<bool> done(false);
+  if (!done.load()) { HIPC(hipFuncSetAttribute((const void*)ntt_fast_pass_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 32 * 272 * 8)); done.store(true); }
   return 0;
 }
 
@@ -424,6 +424,12 @@ extern "C" int sbn_prover_load_trace_device(sbn_prover* P, const uint64_t* d_tra
 // ---- on-device witness generation (kernels_tracegen.cuh) ----------------------------------------------------------
 // Scratch lives in the (not yet used) LDE buffer; the only host traffic is the instance list in (20 KB) and the
 // instance outputs + error word back (8 KB).
+// the u16 range-check kernel keeps 156 KB in LDS (> the 64 KiB default); idempotent, see ntt_fast_setup
+static int range_check_setup() {
+  static std::atomic<bool> done(false);
+  if (!done.load()) { HIPC(hipFuncSetAttribute((const void*)tg::range_check_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tg::RC_LDS_BYTES)); done.store(true); }
+  return 0;
+}
 template <int E>
 static int generate_trace_device(sbn_prover* P, const uint32_t* ios, size_t K, uint64_t* pi_out) {
   const size_t n = P->n;
@@ -449,8 +455,7 @@ static int generate_trace_device(sbn_prover* P, const uint32_t* ios, size_t K, u
   uint32_t* d_ios = (uint32_t*)take(IOW * K / 2 + 1);
   int* d_err = (int*)take(1);
   if ((size_t)(w - P->d_lde) > P->air.ncols * P->m) return fail(SBN_ERR_UNSUPPORTED, "scratch does not fit");
-  static bool attr_done = false;
-  if (!attr_done) { HIPC(hipFuncSetAttribute((const void*)tg::range_check_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tg::RC_LDS_BYTES)); attr_done = true; }
+  if (int rc = range_check_setup()) return rc;
 
   const bool timing = getenv("SBN_TRACE_TIMING") != nullptr;
   hipEvent_t e0 = P->abs_ev[0], e1 = P->abs_ev[1];
@@ -623,8 +628,7 @@ static int generate_trace_device_fq(sbn_prover* P, const uint32_t* ios, size_t K
   u64* inv = take(n);
   uint32_t* d_ios = (uint32_t*)take(IOW * K / 2 + 1);
   int* d_err = (int*)take(1);
-  static bool attr_done = false;
-  if (!attr_done) { HIPC(hipFuncSetAttribute((const void*)tg::range_check_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tg::RC_LDS_BYTES)); attr_done = true; }
+  if (int rc = range_check_setup()) return rc;
   hipEvent_t e0 = P->abs_ev[0], e1 = P->abs_ev[1];
   HIPC(hipEventRecord(e0, st));
   HIPC(hipMemcpyAsync(d_ios, ios, IOW * K * sizeof(uint32_t), hipMemcpyHostToDevice, st));
