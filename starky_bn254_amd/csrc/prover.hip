@@ -84,6 +84,7 @@ struct sbn_prover {
   u64* d_sponge = nullptr;                   // [12][m] sponge state carried between column chunks
   u64* h_chain = nullptr;                    // pinned staging for the host-computed curve chains (device tracegen)
   size_t h_chain_words = 0;
+  u64* h_open = nullptr;                     // pinned landing buffer of the opened values [(ncols + nzs + 4)][4]
 };
 
 static int dmalloc(u64** p, size_t words) {
@@ -309,6 +310,7 @@ extern "C" int sbn_prover_create(const sbn_air_desc* air, const sbn_config* cfg,
   P->apow_n = apow_len(as.npi, as.nzs);
   rc |= dmalloc(&P->d_apow, (size_t)SBN_NCH * P->apow_n);
   rc |= dmalloc(&P->d_zpow, 4 * n); rc |= dmalloc(&P->d_open, (C + Z + 4) * 4);
+  if (hipHostMalloc((void**)&P->h_open, (C + Z + 4) * 4 * sizeof(u64), hipHostMallocDefault) != hipSuccess) rc |= 1;
   rc |= dmalloc(&P->d_part, 2 * 32 * n); rc |= dmalloc(&P->d_w, 4096); rc |= dmalloc(&P->d_sponge, 12 * m);
   rc |= dmalloc(&P->d_fa, 4 * n); rc |= dmalloc(&P->d_fcoef, 2 * m); rc |= dmalloc(&P->d_fcoef2, 2 * m);
   rc |= dmalloc(&P->d_pow, 1);
@@ -379,6 +381,7 @@ extern "C" void sbn_prover_destroy(sbn_prover* P) {
   (void)hipEventDestroy(P->hash_done);
   if (P->d_sponge) (void)hipFree(P->d_sponge);
   if (P->h_chain) (void)hipHostFree(P->h_chain);
+  if (P->h_open) (void)hipHostFree(P->h_open);
   (void)hipStreamDestroy(P->hstream);
   (void)hipStreamDestroy(P->stream);
   delete P;
@@ -792,16 +795,33 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
   E2 zeta_next = zeta * g;
   hipLaunchKernelGGL(ext_pow_table_kernel, blocks(n), dim3(256), 0, st, P->d_zpow, P->d_zpow + n, n, zeta.a.v, zeta.b.v);
   hipLaunchKernelGGL(ext_pow_table_kernel, blocks(n), dim3(256), 0, st, P->d_zpow + 2 * n, P->d_zpow + 3 * n, n, zeta_next.a.v, zeta_next.b.v);
-  hipLaunchKernelGGL(openings_kernel, dim3((unsigned)C), dim3(256), 0, st, P->d_coef, n, P->d_zpow, P->d_zpow + n, P->d_zpow + 2 * n, P->d_zpow + 3 * n, P->d_open);
+  // The trace openings are copied to pinned memory behind their own event, so that the host hashes the local values (a
+  // third of the 1,220 transcript permutations) while the device computes the Z and quotient openings.  Slicing the trace
+  // columns further (hashing after a quarter of them) was measured: every extra copy + event costs ~0.1 ms of stream
+  // time, more than the earlier start buys.
+  const u64* open = P->h_open;
+  constexpr int OPEN_SLICES = 1;
+  size_t slice_end[OPEN_SLICES];
+  for (int k = 0; k < OPEN_SLICES; k++) {
+    const size_t c0 = C * k / OPEN_SLICES, c1 = C * (k + 1) / OPEN_SLICES;
+    slice_end[k] = c1;
+    hipLaunchKernelGGL(openings_kernel, dim3((unsigned)(c1 - c0)), dim3(256), 0, st, P->d_coef + c0 * n, n, P->d_zpow, P->d_zpow + n, P->d_zpow + 2 * n, P->d_zpow + 3 * n,
+                       P->d_open + c0 * 4);
+    HIPC(hipMemcpyAsync(P->h_open + c0 * 4, P->d_open + c0 * 4, (c1 - c0) * 4 * sizeof(u64), hipMemcpyDeviceToHost, st));
+    HIPC(hipEventRecord(P->chunk_ready[k], st));  // (the commit pipeline's chunk events are idle here)
+  }
   hipLaunchKernelGGL(openings_kernel, dim3((unsigned)Z), dim3(256), 0, st, P->d_zcoef, n, P->d_zpow, P->d_zpow + n, P->d_zpow + 2 * n, P->d_zpow + 3 * n, P->d_open + C * 4);
   hipLaunchKernelGGL(openings_kernel, dim3(4), dim3(256), 0, st, P->d_q, n, P->d_zpow, P->d_zpow + n, P->d_zpow + 2 * n, P->d_zpow + 3 * n, P->d_open + (C + Z) * 4);
   HIPC(hipGetLastError());
-  std::vector<u64> open((C + Z + 4) * 4);
-  HIPC(hipMemcpyAsync(open.data(), P->d_open, open.size() * sizeof(u64), hipMemcpyDeviceToHost, st));
+  HIPC(hipMemcpyAsync(P->h_open + C * 4, P->d_open + C * 4, (Z + 4) * 4 * sizeof(u64), hipMemcpyDeviceToHost, st));
   HIPC(hipEventRecord(P->ev[ST_FRI_COMBINE], st));
-  HIPC(hipStreamSynchronize(st));
   // observe_openings: batch zeta = local ++ perm_zs ++ quotient ; batch g*zeta = next ++ perm_zs_next
-  for (size_t p = 0; p < C + Z + 4; p++) { ch.observe(F(open[4 * p])); ch.observe(F(open[4 * p + 1])); }
+  for (int k = 0; k < OPEN_SLICES; k++) {
+    HIPC(hipEventSynchronize(P->chunk_ready[k]));
+    for (size_t p = k ? slice_end[k - 1] : 0; p < slice_end[k]; p++) { ch.observe(F(open[4 * p])); ch.observe(F(open[4 * p + 1])); }
+  }
+  HIPC(hipStreamSynchronize(st));
+  for (size_t p = C; p < C + Z + 4; p++) { ch.observe(F(open[4 * p])); ch.observe(F(open[4 * p + 1])); }
   for (size_t p = 0; p < C + Z; p++) { ch.observe(F(open[4 * p + 2])); ch.observe(F(open[4 * p + 3])); }
 
   // P5 FRI ------------------------------------------------------------------------------------------
@@ -959,7 +979,7 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
   sbn_proof* pr = new sbn_proof();
   pr->degree_bits = P->degree_bits;
   std::vector<u64>& w = pr->words;
-  w.reserve(12 + 3 * capw + open.size() + fri_caps.size() * capw + qwords.size() + final_poly.size() + 1 + P->pi.size());
+  w.reserve(12 + 3 * capw + (C + Z + 4) * 4 + fri_caps.size() * capw + qwords.size() + final_poly.size() + 1 + P->pi.size());
   u64 hdr[12] = {PROOF_MAGIC, P->degree_bits, C, Z, 4, P->pi.size(), cfg.cap_height, cfg.rate_bits, fri_caps.size(), cfg.fri_arity_bits,
                  final_poly.size() / 2, nq};
   w.insert(w.end(), hdr, hdr + 12);
