@@ -82,16 +82,16 @@ def sbox(s, x0, x1, out):
 
 
 def fold(s, al0, al1, ah0, ah1, out):
-    """out = al + ah*2^32 (al, ah < 2^42) as a weak u64: (al1 + ah0 : al0) + (ah1 + carry)*(2^32 - 1)."""
+    """out = al + ah*2^32 (al, ah < 2^42) as a weak u64: (al1 + ah0 : al0) + (ah1 + carry)*(2^32 - 1); the carry of that
+    last product-sum is repaid by one more multiply-add with (2^32 - 1), which needs no zero-extended register pair."""
     c = s.c
-    W, R, M = 0, 1, 2
+    W, R = 0, 1
     s.emit(f"v_add_co_u32_e64 {s.hi(W)}, {c}, {al1}, {ah0}", wr=True)
     s.emit(f"v_mov_b32 {s.lo(W)}, {al0}")
-    s.emit(f"v_mov_b32 {s.hi(M)}, 0")
-    s.emit(f"v_addc_co_u32_e64 {s.lo(3)}, {c}, {ah1}, 0, {c}", rd=True, wr=True)
-    s.emit(f"v_mad_u64_u32 {s.pair(R)}, {c}, {s.lo(3)}, -1, {s.pair(W)}", wr=True)
-    s.emit(f"v_cndmask_b32_e64 {s.lo(M)}, 0, -1, {c}", rd=True)
-    s.emit(f"v_lshl_add_u64 {out}, {s.pair(R)}, 0, {s.pair(M)}")
+    s.emit(f"v_addc_co_u32_e64 {s.lo(2)}, {c}, {ah1}, 0, {c}", rd=True, wr=True)
+    s.emit(f"v_mad_u64_u32 {s.pair(R)}, {c}, {s.lo(2)}, -1, {s.pair(W)}", wr=True)
+    s.emit(f"v_cndmask_b32_e64 {s.hi(2)}, 0, 1, {c}", rd=True)
+    s.emit(f"v_mad_u64_u32 {out}, {c}, {s.hi(2)}, -1, {s.pair(R)}", wr=True)
 
 
 def schedule(streams):
@@ -136,7 +136,7 @@ write("poseidon_sbox3_asm.inc", schedule(st),
 s1 = Stream(SB_BASE[2], "%1")
 sbox(s1, "%2", "%3", "%0")
 write("poseidon_sbox1_asm.inc", schedule([s1]), ["one x^7 S-box; %0 out (u64), %1 carry SGPR pair, %2,%3 in halves; clobbers v106-v127"])
-# fold3: %0..%2 out (u64), %3..%5 carry pairs, %6..%17 = al0,al1,ah0,ah1 x3; windows of 8 VGPRs at v104, v112, v120
+# fold3: %0..%2 out (u64), %3..%5 carry pairs, %6..%17 = al0,al1,ah0,ah1 x3; windows of 6 VGPRs inside v104..v127
 FB = [104, 112, 120]
 sf = [Stream(FB[k], f"%{3 + k}") for k in range(3)]
 for k in range(3):
