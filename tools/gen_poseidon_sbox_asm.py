@@ -156,7 +156,12 @@ sm.emit(f"v_cndmask_b32_e64 %0, {sm.lo(X)}, {sm.lo(P0)}, {c}", rd=True)
 sm.emit(f"v_cndmask_b32_e64 %1, {sm.hi(X)}, {sm.hi(P0)}, {c}", rd=True)
 write("gl_mul_asm.inc", schedule([sm]), ["canonical Goldilocks multiply; %0,%1 out halves, %2 carry SGPR pair, %3,%4 = a, %5,%6 = b; clobbers v112-v127"])
 
+# fold1: one output (the single row of the fused partial rounds): %0 out, %1 carry pair, %2..%5 = al0 al1 ah0 ah1
+s1f = Stream(120, "%1")
+fold(s1f, "%2", "%3", "%4", "%5", "%0")
+write("poseidon_fold1_asm.inc", schedule([s1f]), ["one MDS output fold; %0 out (u64), %1 carry SGPR pair, %2-%5 = al.lo al.hi ah.lo ah.hi; clobbers v120-v127"])
+
 with open(os.path.join(CSRC, "poseidon_asm_clobbers.inc"), "w") as f:
     f.write("// Generated by tools/gen_poseidon_sbox_asm.py -- do not edit.\n")
-    for name, lo in (("PW_CLOBBER_SBOX3", 62), ("PW_CLOBBER_SBOX1", 106), ("PW_CLOBBER_FOLD3", 104), ("GL_CLOBBER_MUL", 112)):
+    for name, lo in (("PW_CLOBBER_SBOX3", 62), ("PW_CLOBBER_SBOX1", 106), ("PW_CLOBBER_FOLD3", 104), ("PW_CLOBBER_FOLD1", 120), ("GL_CLOBBER_MUL", 112)):
         f.write("#define %s %s\n" % (name, ", ".join('"v%d"' % r for r in range(lo, 128))))
