@@ -297,6 +297,50 @@ class Proof:
     def recover_degree_bits(self, config=None):
         return self.degree_bits
 
+    def fields(self):
+        """The proof as the reference's struct tree (starky proof.rs `StarkProof` / `StarkOpeningSet`, plonky2
+        fri/proof.rs `FriProof`): a dict of numpy views into the words, read in the order include/sbn.h documents.
+        The Rust shim's `proof_from_words` (integration/rust/starky-bn254-amd/src/convert.rs) reads the same way."""
+        w = self.words
+        if len(w) < 12 or int(w[0]) != 0x31564F5250424E53:
+            raise ValueError("not a proof of this library")
+        (degree_bits, ncol, nz, nq, npi, cap_h, rate_bits, nlayers, arity_bits, fpl, nqueries) = (int(x) for x in w[1:12])
+        pos = [12]
+
+        def take(n, shape=None):
+            if pos[0] + n > len(w):
+                raise ValueError("proof words truncated")
+            v = w[pos[0]:pos[0] + n]
+            pos[0] += n
+            return v.reshape(shape) if shape else v
+
+        capn, lde_bits = 1 << cap_h, degree_bits + rate_bits
+        out = {"degree_bits": degree_bits, "trace_cap": take(4 * capn, (capn, 4))}
+        out["permutation_zs_cap"] = take(4 * capn, (capn, 4)) if nz else None
+        out["quotient_polys_cap"] = take(4 * capn, (capn, 4))
+        op = {"local_values": take(2 * ncol, (ncol, 2)), "next_values": take(2 * ncol, (ncol, 2))}
+        op["permutation_zs"] = take(2 * nz, (nz, 2)) if nz else None
+        op["permutation_zs_next"] = take(2 * nz, (nz, 2)) if nz else None
+        op["quotient_polys"] = take(2 * nq, (nq, 2))
+        out["openings"] = op
+        fri = {"commit_phase_merkle_caps": [take(4 * capn, (capn, 4)) for _ in range(nlayers)], "query_round_proofs": []}
+        widths = [ncol] + ([nz] if nz else []) + [nq]
+        for _ in range(nqueries):
+            initial = [(take(wd), take(4 * (lde_bits - cap_h), (lde_bits - cap_h, 4))) for wd in widths]
+            steps, bits = [], lde_bits
+            for _ in range(nlayers):
+                evals = take(2 << arity_bits, (1 << arity_bits, 2))
+                bits -= arity_bits
+                steps.append({"evals": evals, "merkle_proof": take(4 * (bits - cap_h), (bits - cap_h, 4))})
+            fri["query_round_proofs"].append({"initial_trees_proof": initial, "steps": steps})
+        fri["final_poly"] = take(2 * fpl, (fpl, 2))
+        fri["pow_witness"] = int(take(1)[0])
+        out["opening_proof"] = fri
+        out["public_inputs"] = take(npi)
+        if pos[0] != len(w):
+            raise ValueError("trailing words after the proof")
+        return out
+
 
 def _take_proof(h):
     L = lib()

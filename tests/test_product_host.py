@@ -244,3 +244,60 @@ def test_generated_tables_and_instruction_streams_are_current(tmp_path):
     for f in produced:
         assert open(os.path.join(tmp_path, f)).read() == open(os.path.join(csrc, f)).read(), f
 
+
+
+def test_proof_fields_follow_the_documented_layout(S, g1op_case):
+    """Proof.fields() (the struct view of include/sbn.h's word order, which the Rust shim's proof_from_words mirrors)
+    consumes an oracle proof exactly and lands every field where the verifier reads it."""
+    w = g1op_case["proof"]
+    f = S.Proof(w, 9).fields()
+    assert f["degree_bits"] == 9 and f["trace_cap"].shape == (16, 4) and f["permutation_zs_cap"].shape == (16, 4)
+    op = f["openings"]
+    assert op["local_values"].shape == (2283, 2) and op["permutation_zs_next"].shape == (1264, 2) and op["quotient_polys"].shape == (4, 2)
+    fri = f["opening_proof"]
+    assert len(fri["commit_phase_merkle_caps"]) == 1 and len(fri["query_round_proofs"]) == 84
+    q = fri["query_round_proofs"][0]
+    assert [len(v) for v, _ in q["initial_trees_proof"]] == [2283, 1264, 4]
+    assert all(sib.shape == (10 - 4, 4) for _, sib in q["initial_trees_proof"])
+    assert q["steps"][0]["evals"].shape == (16, 2) and q["steps"][0]["merkle_proof"].shape == (10 - 4 - 4, 4)
+    assert fri["final_poly"].shape == (32, 2) and fri["pow_witness"] == int(w[-1]) and len(f["public_inputs"]) == 0
+    assert np.array_equal(f["trace_cap"].ravel(), w[12:12 + 64])
+    # the views alias the words: flipping a field through the view is what the verifier then rejects
+    t = S.Proof(w.copy(), 9)
+    t.fields()["opening_proof"]["final_poly"][3, 1] ^= 1
+    with pytest.raises(S.SbnError):
+        S.verify_stark_proof(S.G1Stark(), t, S.G1Stark().config())
+    S.verify_stark_proof(S.G1Stark(), S.Proof(w, 9), S.G1Stark().config())
+    with pytest.raises(ValueError):
+        S.Proof(w[:-1], 9).fields()
+
+
+def test_rust_shim_declarations_match_the_header():
+    """integration/rust (source only, no Rust toolchain here): every `extern "C"` declaration names an entry point of
+    include/sbn.h with the same number of arguments, the struct fields and table kinds agree, and the proof reader
+    takes the fields in the header's documented order."""
+    hdr = open(os.path.join(ROOT, "include", "sbn.h")).read()
+    hdr_nc = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    shim = os.path.join(ROOT, "integration", "rust", "starky-bn254-amd", "src")
+    ffi = open(os.path.join(shim, "ffi.rs")).read()
+    decls = re.findall(r"pub fn (sbn_[a-z0-9_]+)\(([^)]*)\)", ffi)
+    assert len(decls) >= 15
+    for name, args in decls:
+        m = re.search(r"\b%s\s*\(([^)]*)\)" % name, hdr_nc)
+        assert m, name
+        c_args = [a for a in m.group(1).split(",") if a.strip() and a.strip() != "void"]
+        r_args = [a for a in args.split(",") if a.strip()]
+        assert len(c_args) == len(r_args), (name, c_args, r_args)
+    cfg_c = re.findall(r"uint32_t (\w+);", re.search(r"typedef struct sbn_config \{(.*?)\}", hdr_nc, re.S).group(1))
+    cfg_r = re.findall(r"pub (\w+): u32", re.search(r"pub struct sbn_config \{(.*?)\}", ffi, re.S).group(1))
+    assert cfg_c == cfg_r
+    kinds_c = dict((k, int(v)) for k, v in re.findall(r"(SBN_AIR_\w+) = (\d+)", hdr_nc))
+    kinds_r = dict((k, int(v)) for k, v in re.findall(r"pub const (SBN_AIR_\w+): i32 = (\d+);", ffi))
+    assert kinds_c == kinds_r
+    conv = open(os.path.join(shim, "convert.rs")).read()
+    order = ["trace_cap = ", "permutation_zs_cap = ", "quotient_polys_cap = ", "local_values = ", "next_values = ",
+             "(permutation_zs, permutation_zs_next) = ", "quotient_polys = ", "commit_phase_merkle_caps = ", "evals_proofs.push",
+             "steps.push", "final_poly = ", "pow_witness = ", "public_inputs = "]
+    at = [conv.index(s) for s in order]
+    assert at == sorted(at)
+    assert 'from_le_bytes(*b"SNBPROV1")' in conv and int.from_bytes(b"SNBPROV1", "little") == 0x31564F5250424E53
