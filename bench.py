@@ -242,7 +242,9 @@ def main():
 def committed_pmc(kernel, key="hbm_bytes_per_launch_corrected"):
     """A per-launch figure of `kernel` from the newest committed PMC summary (tools/summarize_pmc.py)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")),
+                   key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))])   # r1_v10 after r1_v9
     if not files:
         return None
     d = json.load(open(files[-1]))
