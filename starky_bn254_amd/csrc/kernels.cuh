@@ -442,6 +442,25 @@ __global__ __launch_bounds__(256) void fri_leaf_hash_kernel(const u64* __restric
   for (int i = 0; i < 4; i++) digests[leaf * 4 + i] = s[i].v;
 }
 
+// The same with 16 lanes per leaf (poseidon_permute_coop16): a FRI layer has few leaves and four dependent permutations
+// per leaf, so the one-lane-per-leaf form is bound by the latency of a permutation (34 us) rather than by work.
+__global__ __launch_bounds__(256) void fri_leaf_hash_coop_kernel(const u64* __restrict__ va, const u64* __restrict__ vb, u32 log_m, u32 arity_bits,
+                                                                 u64* __restrict__ digests) {
+  const size_t leaf = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  const size_t nleaf = (size_t)1 << (log_m - arity_bits);
+  const u32 lane = threadIdx.x & 15, e = lane < 12 ? lane : lane - 12;  // lanes 12..15 mirror elements 0..3
+  const u32 arity = 1u << arity_bits;
+  u64 st = 0;
+  for (u32 t = 0; t < arity; t += 4) {
+    if (leaf < nleaf && e < 8) {
+      const u32 nat = bitrev32((u32)(leaf * arity + t + (e >> 1)), log_m);
+      st = (e & 1) ? vb[nat] : va[nat];
+    }
+    st = poseidon_permute_coop16(st, lane);   // every lane of the row takes part (DPP rotations)
+  }
+  if (leaf < nleaf && lane < 4) digests[leaf * 4 + lane] = st;
+}
+
 __global__ void poseidon_batch_kernel(u64* states, size_t count) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
@@ -624,16 +643,29 @@ __device__ __forceinline__ F block_sum(F v, u64* sh) {
   for (unsigned w = 0; w < blockDim.x / 64; w++) t = t + F(sh[w]);
   return t;
 }
-// evaluates at two points at once: tables (pa0,pb0) for z and (pa1,pb1) for g*z; out: [npoly][4]
-__global__ __launch_bounds__(256) void openings_kernel(const u64* __restrict__ coeffs, size_t n, const u64* pa0, const u64* pb0,
-                                                       const u64* pa1, const u64* pb1, u64* __restrict__ out) {
+// evaluates at two points at once: tables (pa0,pb0) for z and (pa1,pb1) for g*z; out: [npoly][4].  The kernel is bound
+// by load latency, not bandwidth or ALU (one coefficient + four table words per ~110 instructions), so every lane has
+// OPEN_UNROLL iterations' loads in flight before it multiplies (4 from 1,024 rows up).
+template <u32 OPEN_UNROLL>   // n must be a multiple of 256 * OPEN_UNROLL
+__global__ __launch_bounds__(256) void openings_kernel(const u64* __restrict__ coeffs, size_t n, const u64* __restrict__ pa0, const u64* __restrict__ pb0,
+                                                       const u64* __restrict__ pa1, const u64* __restrict__ pb1, u64* __restrict__ out) {
   __shared__ u64 sh[4];
   const u64* c = coeffs + (size_t)blockIdx.x * n;
   F a0(0), b0(0), a1(0), b1(0);
-  for (size_t i = threadIdx.x; i < n; i += blockDim.x) {
-    F v{c[i]};
-    a0 += v * F(pa0[i]); b0 += v * F(pb0[i]);
-    a1 += v * F(pa1[i]); b1 += v * F(pb1[i]);
+  for (size_t i = threadIdx.x; i < n; i += 256 * OPEN_UNROLL) {
+    u64 cv[OPEN_UNROLL], t0[OPEN_UNROLL], t1[OPEN_UNROLL], t2[OPEN_UNROLL], t3[OPEN_UNROLL];
+#pragma unroll
+    for (u32 k = 0; k < OPEN_UNROLL; k++) {
+      const size_t ik = i + 256 * k;
+      cv[k] = c[ik]; t0[k] = pa0[ik]; t1[k] = pb0[ik]; t2[k] = pa1[ik]; t3[k] = pb1[ik];
+    }
+    __builtin_amdgcn_sched_barrier(0);   // all the loads first
+#pragma unroll
+    for (u32 k = 0; k < OPEN_UNROLL; k++) {
+      const F v{cv[k]};
+      a0 += v * F(t0[k]); b0 += v * F(t1[k]);
+      a1 += v * F(t2[k]); b1 += v * F(t3[k]);
+    }
   }
   a0 = block_sum(a0, sh); b0 = block_sum(b0, sh); a1 = block_sum(a1, sh); b1 = block_sum(b1, sh);
   if (threadIdx.x == 0) {
@@ -685,33 +717,56 @@ __global__ __launch_bounds__(256) void divide_by_linear_pass1(const u64* __restr
   ha[t] = h.a.v; hb[t] = h.b.v;
 }
 // in place: (ha, hb)[t] <- carry_t.  One workgroup; nchunks is a power of two, min(256, nchunks) lanes own
-// nchunks/lanes consecutive chunks each.
-__global__ __launch_bounds__(256) void divide_by_linear_pass2(u64* __restrict__ ha, u64* __restrict__ hb, size_t nchunks, u64 z0, u64 z1) {
-  __shared__ u64 sa[256], sb[256];
-  const int tid = threadIdx.x;
-  const int lanes = nchunks < 256 ? (int)nchunks : 256;
-  const size_t per = tid < lanes ? nchunks / lanes : 0, base = (size_t)tid * per;
-  const E2 zl = e2_pow(E2{F(z0), F(z1)}, DBL_CHUNK);
-  E2 g{F(0), F(0)};  // value of this lane's chunks with a zero carry-in
-  for (size_t j = per; j-- > 0;) g = E2(F(ha[base + j]), F(hb[base + j])) + zl * g;
-  sa[tid] = g.a.v; sb[tid] = g.b.v;
-  __syncthreads();
-  if (tid == 0) {
-    const E2 zg = e2_pow(zl, per);
-    E2 carry{F(0), F(0)};
-    for (int t = lanes - 1; t >= 0; t--) {
-      const E2 gt{F(sa[t]), F(sb[t])};
-      sa[t] = carry.a.v; sb[t] = carry.b.v;
-      carry = gt + zg * carry;
+// nchunks/lanes consecutive chunks each: a lane folds its own chunks (loads issued eight at a time: the kernel is
+// latency-bound), the lanes' values go through a log-step suffix scan of x -> g + zg x in LDS, then every lane replays
+// its chunks from its carry.
+template <u32 U> __device__ __forceinline__ void dbl_fold(const u64* ha, const u64* hb, size_t base, size_t per, const E2 zl, E2& g) {
+  for (size_t j0 = per; j0 > 0; j0 -= U) {
+    u64 va[U], vb[U];
+#pragma unroll
+    for (u32 k = 0; k < U; k++) { va[k] = ha[base + j0 - 1 - k]; vb[k] = hb[base + j0 - 1 - k]; }
+#pragma unroll
+    for (u32 k = 0; k < U; k++) g = E2(F(va[k]), F(vb[k])) + zl * g;
+  }
+}
+template <u32 U> __device__ __forceinline__ void dbl_replay(u64* ha, u64* hb, size_t base, size_t per, const E2 zl, E2 carry) {
+  for (size_t j0 = per; j0 > 0; j0 -= U) {
+    u64 va[U], vb[U];
+#pragma unroll
+    for (u32 k = 0; k < U; k++) { va[k] = ha[base + j0 - 1 - k]; vb[k] = hb[base + j0 - 1 - k]; }
+#pragma unroll
+    for (u32 k = 0; k < U; k++) {
+      ha[base + j0 - 1 - k] = carry.a.v; hb[base + j0 - 1 - k] = carry.b.v;
+      carry = E2(F(va[k]), F(vb[k])) + zl * carry;
     }
   }
+}
+__global__ __launch_bounds__(256) void divide_by_linear_pass2(u64* __restrict__ ha, u64* __restrict__ hb, size_t nchunks, u64 z0, u64 z1) {
+  __shared__ u64 sa[2][256], sb[2][256];
+  const int tid = threadIdx.x;
+  const int lanes = nchunks < 256 ? (int)nchunks : 256;
+  const size_t per = nchunks / lanes, base = (size_t)tid * per;
+  const bool live = tid < lanes;
+  const E2 zl = e2_pow(E2{F(z0), F(z1)}, DBL_CHUNK);
+  E2 g{F(0), F(0)};  // value of this lane's chunks with a zero carry-in
+  if (live) { if (per % 8 == 0) dbl_fold<8>(ha, hb, base, per, zl, g); else dbl_fold<1>(ha, hb, base, per, zl, g); }
+  // inclusive suffix scan S_t = g_t + zg S_{t+1} over the lanes (Hillis-Steele; the multiplier zg^(2^k) is uniform)
+  E2 m = e2_pow(zl, per);
+  int cur = 0;
+  sa[0][tid] = g.a.v; sb[0][tid] = g.b.v;
   __syncthreads();
-  E2 carry{F(sa[tid]), F(sb[tid])};
-  for (size_t j = per; j-- > 0;) {
-    const E2 h{F(ha[base + j]), F(hb[base + j])};
-    ha[base + j] = carry.a.v; hb[base + j] = carry.b.v;
-    carry = h + zl * carry;
+  for (int d = 1; d < lanes; d <<= 1) {
+    E2 v{F(sa[cur][tid]), F(sb[cur][tid])};
+    if (tid + d < lanes) v = v + m * E2(F(sa[cur][tid + d]), F(sb[cur][tid + d]));
+    sa[cur ^ 1][tid] = v.a.v; sb[cur ^ 1][tid] = v.b.v;
+    m = m * m;
+    cur ^= 1;
+    __syncthreads();
   }
+  // carry into lane t = S_{t+1}
+  E2 carry{F(0), F(0)};
+  if (tid + 1 < lanes) carry = E2(F(sa[cur][tid + 1]), F(sb[cur][tid + 1]));
+  if (live) { if (per % 8 == 0) dbl_replay<8>(ha, hb, base, per, zl, carry); else dbl_replay<1>(ha, hb, base, per, zl, carry); }
 }
 __global__ __launch_bounds__(256) void divide_by_linear_pass3(const u64* __restrict__ ca, const u64* __restrict__ cb, size_t nchunks, u64 z0, u64 z1,
                                                               const u64* __restrict__ ha, const u64* __restrict__ hb, u64 mul0, u64 mul1,

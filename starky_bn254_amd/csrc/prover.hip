@@ -800,18 +800,19 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
   // columns further (hashing after a quarter of them) was measured: every extra copy + event costs ~0.1 ms of stream
   // time, more than the earlier start buys.
   const u64* open = P->h_open;
+  auto open_k = (n % 1024 == 0) ? openings_kernel<4> : openings_kernel<1>;
   constexpr int OPEN_SLICES = 1;
   size_t slice_end[OPEN_SLICES];
   for (int k = 0; k < OPEN_SLICES; k++) {
     const size_t c0 = C * k / OPEN_SLICES, c1 = C * (k + 1) / OPEN_SLICES;
     slice_end[k] = c1;
-    hipLaunchKernelGGL(openings_kernel, dim3((unsigned)(c1 - c0)), dim3(256), 0, st, P->d_coef + c0 * n, n, P->d_zpow, P->d_zpow + n, P->d_zpow + 2 * n, P->d_zpow + 3 * n,
+    hipLaunchKernelGGL(open_k, dim3((unsigned)(c1 - c0)), dim3(256), 0, st, P->d_coef + c0 * n, n, P->d_zpow, P->d_zpow + n, P->d_zpow + 2 * n, P->d_zpow + 3 * n,
                        P->d_open + c0 * 4);
     HIPC(hipMemcpyAsync(P->h_open + c0 * 4, P->d_open + c0 * 4, (c1 - c0) * 4 * sizeof(u64), hipMemcpyDeviceToHost, st));
     HIPC(hipEventRecord(P->chunk_ready[k], st));  // (the commit pipeline's chunk events are idle here)
   }
-  hipLaunchKernelGGL(openings_kernel, dim3((unsigned)Z), dim3(256), 0, st, P->d_zcoef, n, P->d_zpow, P->d_zpow + n, P->d_zpow + 2 * n, P->d_zpow + 3 * n, P->d_open + C * 4);
-  hipLaunchKernelGGL(openings_kernel, dim3(4), dim3(256), 0, st, P->d_q, n, P->d_zpow, P->d_zpow + n, P->d_zpow + 2 * n, P->d_zpow + 3 * n, P->d_open + (C + Z) * 4);
+  hipLaunchKernelGGL(open_k, dim3((unsigned)Z), dim3(256), 0, st, P->d_zcoef, n, P->d_zpow, P->d_zpow + n, P->d_zpow + 2 * n, P->d_zpow + 3 * n, P->d_open + C * 4);
+  hipLaunchKernelGGL(open_k, dim3(4), dim3(256), 0, st, P->d_q, n, P->d_zpow, P->d_zpow + n, P->d_zpow + 2 * n, P->d_zpow + 3 * n, P->d_open + (C + Z) * 4);
   HIPC(hipGetLastError());
   HIPC(hipMemcpyAsync(P->h_open + C * 4, P->d_open + C * 4, (Z + 4) * 4 * sizeof(u64), hipMemcpyDeviceToHost, st));
   HIPC(hipEventRecord(P->ev[ST_FRI_COMBINE], st));
@@ -887,7 +888,8 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
       hipLaunchKernelGGL(scale_pow_kernel, blocks(clen), dim3(256), 0, st, vb, clen, shift.v);
       if ((rc = ntt_columns(P, va, clen, va, clen, P->d_tmp, m, 2, bits, false, clen, nullptr, nullptr, 1))) return rc;
       DevTree& t = P->fri_trees[li];
-      hipLaunchKernelGGL(fri_leaf_hash_kernel, blocks(t.nleaf), dim3(256), 0, st, va, vb, bits, ab, t.d);
+      if (t.nleaf <= 16384) hipLaunchKernelGGL(fri_leaf_hash_coop_kernel, blocks(t.nleaf * 16), dim3(256), 0, st, va, vb, bits, ab, t.d);
+      else hipLaunchKernelGGL(fri_leaf_hash_kernel, blocks(t.nleaf), dim3(256), 0, st, va, vb, bits, ab, t.d);
       if ((rc = tree_build_inner(P, t, st))) return rc;
       std::vector<u64> cap;
       if ((rc = tree_cap_to_host(P, t, cap))) return rc;
