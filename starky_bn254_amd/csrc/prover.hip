@@ -463,7 +463,7 @@ static int generate_trace_device(sbn_prover* P, const uint32_t* ios, size_t K, u
   const bool timing = getenv("SBN_TRACE_TIMING") != nullptr;
   hipEvent_t e0 = P->abs_ev[0], e1 = P->abs_ev[1];
   std::vector<hipEvent_t> kev;
-  auto mark = [&]() { if (timing) { hipEvent_t e; hipEventCreate(&e); hipEventRecord(e, st); kev.push_back(e); } };
+  auto mark = [&]() { if (timing) { hipEvent_t e; if (hipEventCreate(&e) == hipSuccess && hipEventRecord(e, st) == hipSuccess) kev.push_back(e); } };
   HIPC(hipEventRecord(e0, st));
   HIPC(hipMemcpyAsync(d_ios, ios, IOW * K * sizeof(uint32_t), hipMemcpyHostToDevice, st));
   HIPC(hipMemsetAsync(d_err, 0, sizeof(int), st));
@@ -506,8 +506,8 @@ static int generate_trace_device(sbn_prover* P, const uint32_t* ios, size_t K, u
   P->stage_ms[ST_COUNT + EX_TRACEGEN_MS] = ms;
   if (timing) {
     static const char* names[] = {"flags+pulses", "chains", "affine", "lambda", "row_witness", "range_check"};
-    for (size_t i = 0; i + 1 < kev.size(); i++) { float t = 0; hipEventElapsedTime(&t, kev[i], kev[i + 1]); fprintf(stderr, "[device tracegen] %-14s %8.3f ms\n", names[i], t); }
-    for (auto e : kev) hipEventDestroy(e);
+    for (size_t i = 0; i + 1 < kev.size(); i++) { float t = 0; (void)hipEventElapsedTime(&t, kev[i], kev[i + 1]); fprintf(stderr, "[device tracegen] %-14s %8.3f ms\n", names[i], t); }
+    for (auto e : kev) (void)hipEventDestroy(e);
     fprintf(stderr, "[device tracegen] %-14s %8.3f ms\n", "total", ms);
   }
   if (err & tg::TG_ERR_DEGENERATE) return fail(SBN_ERR_WITNESS, "degenerate affine operation (x1 == x2 or y == 0)");
@@ -555,7 +555,7 @@ static int generate_trace_device_fq12(sbn_prover* P, const uint32_t* ios, size_t
   const bool timing = getenv("SBN_TRACE_TIMING") != nullptr;
   hipEvent_t e0 = P->abs_ev[0], e1 = P->abs_ev[1];
   std::vector<hipEvent_t> kev;
-  auto mark = [&]() { if (timing) { hipEvent_t e; hipEventCreate(&e); hipEventRecord(e, st); kev.push_back(e); } };
+  auto mark = [&]() { if (timing) { hipEvent_t e; if (hipEventCreate(&e) == hipSuccess && hipEventRecord(e, st) == hipSuccess) kev.push_back(e); } };
   HIPC(hipEventRecord(e0, st));
   HIPC(hipMemcpyAsync(d_ios, ios, IOW * K * sizeof(uint32_t), hipMemcpyHostToDevice, st));
   HIPC(hipMemsetAsync(d_err, 0, sizeof(int), st));
@@ -589,8 +589,8 @@ static int generate_trace_device_fq12(sbn_prover* P, const uint32_t* ios, size_t
   P->stage_ms[ST_COUNT + EX_TRACEGEN_MS] = ms;
   if (timing) {
     static const char* names[] = {"flags+pulses", "chains", "row_witness", "range_check"};
-    for (size_t i = 0; i + 1 < kev.size(); i++) { float t = 0; hipEventElapsedTime(&t, kev[i], kev[i + 1]); fprintf(stderr, "[device tracegen] %-14s %8.3f ms\n", names[i], t); }
-    for (auto e : kev) hipEventDestroy(e);
+    for (size_t i = 0; i + 1 < kev.size(); i++) { float t = 0; (void)hipEventElapsedTime(&t, kev[i], kev[i + 1]); fprintf(stderr, "[device tracegen] %-14s %8.3f ms\n", names[i], t); }
+    for (auto e : kev) (void)hipEventDestroy(e);
     fprintf(stderr, "[device tracegen] %-14s %8.3f ms\n", "total", ms);
   }
   if (err & tg::TG_ERR_WITNESS) return fail(SBN_ERR_WITNESS, "modular witness generation failed");
