@@ -576,12 +576,19 @@ struct QuotientParams {
   int num_zs, num_io;
   const void* pic;  // ExpPiConsts<F>*
   u64* qout;        // [SBN_NCH][m]
+  u64* part;        // [2 segments][SBN_NCH][m] partial accumulators
+  u64 perm_shift[SBN_NCH];  // alpha_j^(number of permutation-check constraints)
 };
 
+// The constraint stream is one Horner sum in alpha, so it splits exactly: grid.y = 0 evaluates the AIR constraints,
+// grid.y = 1 the permutation checks (about half of the multiplies each), and quotient_combine_kernel joins them as
+// acc_air * alpha^(number of permutation constraints) + acc_perm.  With one lane per LDE point there are only two waves
+// per SIMD at 2^17 points; the split doubles them and halves every lane's dependent chain.
 template <int KIND>
 __global__ __launch_bounds__(256) void quotient_kernel(QuotientParams p) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= p.m) return;
+  const u32 seg = blockIdx.y;
   size_t inext = (i + p.next_step) & (p.m - 1);
   Cons<F> cs;
 #pragma unroll
@@ -592,17 +599,26 @@ __global__ __launch_bounds__(256) void quotient_kernel(QuotientParams p) {
   DevRow row{p.lde, p.m, i, inext};
   DevZRow zrow{p.zlde, p.m, i, inext};
   if (KIND == 1) {
-    g1op_eval(cs, row);
-    permutation_checks(cs, row, zrow, G1OpShape(), p.num_zs, F(p.gamma0), F(p.gamma1));
+    if (seg == 0) g1op_eval(cs, row);
+    else permutation_checks(cs, row, zrow, G1OpShape(), p.num_zs, F(p.gamma0), F(p.gamma1));
   } else {
     constexpr int E = KIND == 4 ? 12 : (KIND == 6 ? 13 : (KIND == 3 ? 2 : (KIND == 5 ? 0 : 1)));
     ExpShape sh(E, p.num_io);
-    exp_eval<E>(cs, row, sh, (const ExpPiConsts<F>*)p.pic);
-    permutation_checks(cs, row, zrow, sh, p.num_zs, F(p.gamma0), F(p.gamma1));
+    if (seg == 0) exp_eval<E>(cs, row, sh, (const ExpPiConsts<F>*)p.pic);
+    else permutation_checks(cs, row, zrow, sh, p.num_zs, F(p.gamma0), F(p.gamma1));
   }
+#pragma unroll
+  for (int j = 0; j < SBN_NCH; j++) p.part[((size_t)seg * SBN_NCH + j) * p.m + i] = cs.acc[j].v;
+}
+__global__ __launch_bounds__(256) void quotient_combine_kernel(QuotientParams p) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p.m) return;
   F dinv(p.zh_inv[i & 1]);
 #pragma unroll
-  for (int j = 0; j < SBN_NCH; j++) p.qout[(size_t)j * p.m + i] = (cs.acc[j] * dinv).v;
+  for (int j = 0; j < SBN_NCH; j++) {
+    const F air(p.part[(size_t)j * p.m + i]), perm(p.part[((size_t)SBN_NCH + j) * p.m + i]);
+    p.qout[(size_t)j * p.m + i] = ((air * F(p.perm_shift[j]) + perm) * dinv).v;
+  }
 }
 
 // Coset points and Lagrange selectors on the LDE domain (prover.rs: lagrange_first/last

@@ -770,12 +770,16 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
     qp.last = f_inv(f_root_of_unity(P->degree_bits)).v;
     for (int j = 0; j < SBN_NCH; j++) { qp.alpha[j] = alphas[j].v; qp.apow[j] = P->d_apow + (size_t)j * P->apow_n; }
     qp.gamma0 = gamma0.v; qp.gamma1 = gamma1.v; qp.num_zs = (int)Z; qp.num_io = (int)P->air.num_io; qp.pic = P->d_pic; qp.qout = P->d_q;
-    if (P->air.kind == SBN_AIR_G1_OP) hipLaunchKernelGGL(quotient_kernel<1>, blocks(m), dim3(256), 0, st, qp);
-    else if (P->air.kind == SBN_AIR_G1_EXP) hipLaunchKernelGGL(quotient_kernel<2>, blocks(m), dim3(256), 0, st, qp);
-    else if (P->air.kind == SBN_AIR_G2_EXP) hipLaunchKernelGGL(quotient_kernel<3>, blocks(m), dim3(256), 0, st, qp);
-    else if (P->air.kind == SBN_AIR_FQ_EXP) hipLaunchKernelGGL(quotient_kernel<5>, blocks(m), dim3(256), 0, st, qp);
-    else if (P->air.kind == SBN_AIR_FQ12_EXP_U64) hipLaunchKernelGGL(quotient_kernel<6>, blocks(m), dim3(256), 0, st, qp);
-    else hipLaunchKernelGGL(quotient_kernel<4>, blocks(m), dim3(256), 0, st, qp);
+    qp.part = P->d_part;   // 2 x SBN_NCH planes of m words (the FRI combine's scratch, idle here)
+    for (int j = 0; j < SBN_NCH; j++) qp.perm_shift[j] = f_pow(alphas[j], 2 * (u64)Z).v;   // permutation_checks emits 2 constraints per Z
+    const dim3 qgrid((unsigned)((m + 255) / 256), 2);
+    if (P->air.kind == SBN_AIR_G1_OP) hipLaunchKernelGGL(quotient_kernel<1>, qgrid, dim3(256), 0, st, qp);
+    else if (P->air.kind == SBN_AIR_G1_EXP) hipLaunchKernelGGL(quotient_kernel<2>, qgrid, dim3(256), 0, st, qp);
+    else if (P->air.kind == SBN_AIR_G2_EXP) hipLaunchKernelGGL(quotient_kernel<3>, qgrid, dim3(256), 0, st, qp);
+    else if (P->air.kind == SBN_AIR_FQ_EXP) hipLaunchKernelGGL(quotient_kernel<5>, qgrid, dim3(256), 0, st, qp);
+    else if (P->air.kind == SBN_AIR_FQ12_EXP_U64) hipLaunchKernelGGL(quotient_kernel<6>, qgrid, dim3(256), 0, st, qp);
+    else hipLaunchKernelGGL(quotient_kernel<4>, qgrid, dim3(256), 0, st, qp);
+    hipLaunchKernelGGL(quotient_combine_kernel, blocks(m), dim3(256), 0, st, qp);
     HIPC(hipGetLastError());
   }
   HIPC(hipEventRecord(P->ev[ST_QUOTIENT_COMMIT], st));
