@@ -501,6 +501,8 @@ struct ExpShape {  // constants(num_io): g1/exp.rs:6-34, g2/exp.rs:6-34, fq12/ex
     num_cols = start_lookups + 1 + (split_rc ? 6 : 2) * num_rc; num_pi = pi_per_io * n;
   }
   GL_HD int num_pairs() const { return (split_rc ? 4 : 2) * num_rc; }
+  // constraints of sections [9] and [10] of exp_eval (io pulses, range check): the tail when the evaluation is split
+  GL_HD int num_tail_constraints() const { return 2 + 4 * num_io + (split_rc ? 5 * num_rc + 3 : 2 * num_rc + 3); }
   GL_HD int num_constraints() const {
     const int fc = E == 13 ? 9 : 26, pc = E == 13 ? 0 : 5;  // flags constraints, rotation-pulse constraints
     return 1 + num_pi + 3 * 2 * W + fc + 2 * gadget_cons + fc + pc + 2 + 4 * num_io + (split_rc ? 5 * num_rc + 3 : 2 * num_rc + 3);
@@ -568,13 +570,17 @@ static inline void exp_pi_consts(const ExpShape& sh, const P* const apow[SBN_NCH
     }
 }
 
+// `part`: 0 = all constraints, 1 = sections [1]-[8] only, 2 = sections [9]-[10] only (sh.num_tail_constraints() of them).
+// The stream is a Horner sum in alpha, so the quotient kernel evaluates the parts in different workgroups and joins
+// them as head * alpha^(tail count) + tail.
 template <int E, class P, class Row>
-GL_HD void exp_eval(Cons<P>& cs, const Row& row, const ExpShape& sh, const ExpPiConsts<P>* pic) {
+GL_HD void exp_eval(Cons<P>& cs, const Row& row, const ExpShape& sh, const ExpPiConsts<P>* pic, int part = 0) {
   const P one = lift<P>(1), base = lift<P>(65536);
   const int sf = sh.start_flags, S = sh.pi_per_io;
   constexpr bool F12 = E == 12 || E == 13;  // Fq12 operands (u16 public-input limbs, split range check)
   P is_final = row.l(sf), is_double = row.l(sf + sh.flag_sq), is_add = row.l(sf + sh.flag_mul);
   P is_not_final = one - is_final;
+  if (part != 2) {
   // [1] is_final - sum(output pulses)                                         g1/exp.rs:359-365
   // [2] public-input binding, regrouped                                       g1/exp.rs:368-392, g2/exp.rs:382-414
   {
@@ -675,6 +681,8 @@ GL_HD void exp_eval(Cons<P>& cs, const Row& row, const ExpShape& sh, const ExpPi
     cs.c(delta * witness + is_reset - one);
     cs.c(delta * is_reset);
   }
+  }  // part != 2
+  if (part == 1) return;
   // [9] eval_pulse over 2*num_io positions                                      pulse.rs:45-63
   {
     const int st = sh.start_io_pulses;
@@ -705,15 +713,21 @@ GL_HD void exp_eval(Cons<P>& cs, const Row& row, const ExpShape& sh, const ExpPi
 // starky permutation.rs `eval_permutation_checks` for singleton pairs with batch size 2:
 // Z index z <-> pair z; instance 0 uses challenge_sets[0].challenges[0].gamma, instance 1 uses
 // challenge_sets[1].challenges[1].gamma.  ZRow: zl(z) / zn(z) = local / next Z values.
+// `first_row` selects the num_zs first-row constraints, [z0, z1) the range of transition constraints: the whole stream is
+// (true, 0, num_zs); the quotient kernel splits it over two workgroups.
 template <class P, class Row, class ZRow, class Shape>
-GL_HD void permutation_checks(Cons<P>& cs, const Row& row, const ZRow& zrow, const Shape& sh, int num_zs, P gamma0, P gamma1) {
+GL_HD void permutation_checks(Cons<P>& cs, const Row& row, const ZRow& zrow, const Shape& sh, int num_zs, P gamma0, P gamma1, bool first_row = true,
+                              int z0 = 0, int z1 = -1) {
   const P one = lift<P>(1);
-  Horner2<P> h;
+  if (z1 < 0) z1 = num_zs;
+  if (first_row) {
+    Horner2<P> h;
 #pragma unroll
-  for (int j = 0; j < SBN_NCH; j++) h.h[j] = lift<P>(0);
-  for (int z = 0; z < num_zs; z++) h.push(cs, zrow.zl(z) - one);
-  cs.merge(h.h, cs.l_first, num_zs);
-  for (int z = 0; z < num_zs; z++) {
+    for (int j = 0; j < SBN_NCH; j++) h.h[j] = lift<P>(0);
+    for (int z = 0; z < num_zs; z++) h.push(cs, zrow.zl(z) - one);
+    cs.merge(h.h, cs.l_first, num_zs);
+  }
+  for (int z = z0; z < z1; z++) {
     int lc, rc;
     sh.pair(z, lc, rc);
     P l = row.l(lc), r = row.l(rc);

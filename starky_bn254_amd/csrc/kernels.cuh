@@ -576,14 +576,18 @@ struct QuotientParams {
   int num_zs, num_io;
   const void* pic;  // ExpPiConsts<F>*
   u64* qout;        // [SBN_NCH][m]
-  u64* part;        // [2 segments][SBN_NCH][m] partial accumulators
-  u64 perm_shift[SBN_NCH];  // alpha_j^(number of permutation-check constraints)
+  u64* part;        // [QSEG segments][SBN_NCH][m] partial accumulators
+  u64 seg_shift[4][SBN_NCH];  // alpha_j^(number of constraints that follow the segment)
+  int zsplit;       // permutation transition constraints [0, zsplit) go with segment 2, [zsplit, num_zs) with segment 3
 };
 
-// The constraint stream is one Horner sum in alpha, so it splits exactly: grid.y = 0 evaluates the AIR constraints,
-// grid.y = 1 the permutation checks (about half of the multiplies each), and quotient_combine_kernel joins them as
-// acc_air * alpha^(number of permutation constraints) + acc_perm.  With one lane per LDE point there are only two waves
-// per SIMD at 2^17 points; the split doubles them and halves every lane's dependent chain.
+// The constraint stream is one Horner sum in alpha, so it splits exactly.  grid.y = segment: 0 = AIR sections [1]-[8]
+// (public inputs, transitions, flags, the add / double gadget), 1 = AIR sections [9]-[10] (io pulses, range check),
+// 2 = the permutation checks' first-row constraints and the first half of their transitions, 3 = the second half;
+// quotient_combine_kernel joins them as sum_s acc_s * alpha^(constraints after segment s).  With one lane per LDE point
+// there are only two waves per SIMD at 2^17 points; the split gives eight and quarters every lane's dependent chain
+// (2.65 -> 1.8 ms with two segments).
+static constexpr u32 QSEG = 4;
 template <int KIND>
 __global__ __launch_bounds__(256) void quotient_kernel(QuotientParams p) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -600,12 +604,14 @@ __global__ __launch_bounds__(256) void quotient_kernel(QuotientParams p) {
   DevZRow zrow{p.zlde, p.m, i, inext};
   if (KIND == 1) {
     if (seg == 0) g1op_eval(cs, row);
-    else permutation_checks(cs, row, zrow, G1OpShape(), p.num_zs, F(p.gamma0), F(p.gamma1));
+    else if (seg == 2) permutation_checks(cs, row, zrow, G1OpShape(), p.num_zs, F(p.gamma0), F(p.gamma1), true, 0, p.zsplit);
+    else if (seg == 3) permutation_checks(cs, row, zrow, G1OpShape(), p.num_zs, F(p.gamma0), F(p.gamma1), false, p.zsplit, p.num_zs);
   } else {
     constexpr int E = KIND == 4 ? 12 : (KIND == 6 ? 13 : (KIND == 3 ? 2 : (KIND == 5 ? 0 : 1)));
     ExpShape sh(E, p.num_io);
-    if (seg == 0) exp_eval<E>(cs, row, sh, (const ExpPiConsts<F>*)p.pic);
-    else permutation_checks(cs, row, zrow, sh, p.num_zs, F(p.gamma0), F(p.gamma1));
+    if (seg < 2) exp_eval<E>(cs, row, sh, (const ExpPiConsts<F>*)p.pic, 1 + (int)seg);
+    else if (seg == 2) permutation_checks(cs, row, zrow, sh, p.num_zs, F(p.gamma0), F(p.gamma1), true, 0, p.zsplit);
+    else permutation_checks(cs, row, zrow, sh, p.num_zs, F(p.gamma0), F(p.gamma1), false, p.zsplit, p.num_zs);
   }
 #pragma unroll
   for (int j = 0; j < SBN_NCH; j++) p.part[((size_t)seg * SBN_NCH + j) * p.m + i] = cs.acc[j].v;
@@ -616,8 +622,10 @@ __global__ __launch_bounds__(256) void quotient_combine_kernel(QuotientParams p)
   F dinv(p.zh_inv[i & 1]);
 #pragma unroll
   for (int j = 0; j < SBN_NCH; j++) {
-    const F air(p.part[(size_t)j * p.m + i]), perm(p.part[((size_t)SBN_NCH + j) * p.m + i]);
-    p.qout[(size_t)j * p.m + i] = ((air * F(p.perm_shift[j]) + perm) * dinv).v;
+    F acc(p.part[((size_t)(QSEG - 1) * SBN_NCH + j) * p.m + i]);   // nothing follows the last segment
+#pragma unroll
+    for (u32 sgm = 0; sgm + 1 < QSEG; sgm++) acc += F(p.part[((size_t)sgm * SBN_NCH + j) * p.m + i]) * F(p.seg_shift[sgm][j]);
+    p.qout[(size_t)j * p.m + i] = (acc * dinv).v;
   }
 }
 

@@ -770,9 +770,15 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
     qp.last = f_inv(f_root_of_unity(P->degree_bits)).v;
     for (int j = 0; j < SBN_NCH; j++) { qp.alpha[j] = alphas[j].v; qp.apow[j] = P->d_apow + (size_t)j * P->apow_n; }
     qp.gamma0 = gamma0.v; qp.gamma1 = gamma1.v; qp.num_zs = (int)Z; qp.num_io = (int)P->air.num_io; qp.pic = P->d_pic; qp.qout = P->d_q;
-    qp.part = P->d_part;   // 2 x SBN_NCH planes of m words (the FRI combine's scratch, idle here)
-    for (int j = 0; j < SBN_NCH; j++) qp.perm_shift[j] = f_pow(alphas[j], 2 * (u64)Z).v;   // permutation_checks emits 2 constraints per Z
-    const dim3 qgrid((unsigned)((m + 255) / 256), 2);
+    qp.part = P->d_part;   // QSEG x SBN_NCH planes of m words (the FRI combine's scratch, idle here)
+    {
+      // constraints that follow each segment: [AIR head][AIR tail][first-row + transitions < zsplit][transitions >= zsplit]
+      qp.zsplit = (int)(Z / 3);   // a first-row constraint costs about a third of a transition
+      const u64 n_tail = is_exp_air(P->air.kind) ? (u64)ExpShape(exp_e(P->air.kind), (int)P->air.num_io).num_tail_constraints() : 0;
+      const u64 after[4] = {n_tail + 2 * (u64)Z, 2 * (u64)Z, (u64)Z - (u64)qp.zsplit, 0};
+      for (int sgm = 0; sgm < 4; sgm++) for (int j = 0; j < SBN_NCH; j++) qp.seg_shift[sgm][j] = f_pow(alphas[j], after[sgm]).v;
+    }
+    const dim3 qgrid((unsigned)((m + 255) / 256), QSEG);
     if (P->air.kind == SBN_AIR_G1_OP) hipLaunchKernelGGL(quotient_kernel<1>, qgrid, dim3(256), 0, st, qp);
     else if (P->air.kind == SBN_AIR_G1_EXP) hipLaunchKernelGGL(quotient_kernel<2>, qgrid, dim3(256), 0, st, qp);
     else if (P->air.kind == SBN_AIR_G2_EXP) hipLaunchKernelGGL(quotient_kernel<3>, qgrid, dim3(256), 0, st, qp);
