@@ -489,6 +489,9 @@ __device__ __forceinline__ F wave_scan_mul(F x, int lane) {  // inclusive prefix
   return x;
 }
 
+// Every lane takes PZ_E consecutive rows per sweep step (a serial product inside the lane, then one wave scan over the
+// lanes' totals), which amortises the scan and the two barriers over PZ_E rows.  n must be a multiple of 256 * PZ_E.
+template <int PZ_E>
 __global__ __launch_bounds__(256) void permutation_z_kernel(const u64* __restrict__ trace, size_t n, const PairCols* __restrict__ pairs,
                                                             u64 gamma0, u64 gamma1, u64* __restrict__ zout) {
   __shared__ u64 wtot[4];
@@ -501,20 +504,29 @@ __global__ __launch_bounds__(256) void permutation_z_kernel(const u64* __restric
   const F g0(gamma0), g1(gamma1);
   // forward sweep: exclusive prefix product of num -> zc ; running product of den
   F carry(1), dprod(1);
-  for (size_t base = 0; base < n; base += 256) {
-    size_t i = base + tid;
-    F l{lhs[i]}, r(rhs[i]);
-    F num = (l + g0) * (l + g1);
-    dprod = dprod * ((r + g0) * (r + g1));
-    F inc = wave_scan_mul(num, lane);
+  for (size_t base = 0; base < n; base += 256 * PZ_E) {
+    const size_t i0 = base + (size_t)tid * PZ_E;
+    u64 lv[PZ_E], rv[PZ_E];
+#pragma unroll
+    for (int e = 0; e < PZ_E; e++) { lv[e] = lhs[i0 + e]; rv[e] = rhs[i0 + e]; }
+    F pr[PZ_E];   // inclusive products of num inside the lane
+#pragma unroll
+    for (int e = 0; e < PZ_E; e++) {
+      const F l(lv[e]), r(rv[e]);
+      const F num = (l + g0) * (l + g1);
+      pr[e] = e ? pr[e - 1] * num : num;
+      dprod = dprod * ((r + g0) * (r + g1));
+    }
+    F inc = wave_scan_mul(pr[PZ_E - 1], lane);
     if (lane == 63) wtot[wv] = inc.v;
     __syncthreads();
     F pre = carry;
     for (int w = 0; w < wv; w++) pre = pre * F(wtot[w]);
-    // exclusive = pre * inclusive_of_previous_lane
-    u64 prev = __shfl_up((unsigned long long)inc.v, 1, 64);
-    F excl = lane == 0 ? pre : pre * F(prev);
-    zc[i] = excl.v;
+    const u64 prev = __shfl_up((unsigned long long)inc.v, 1, 64);
+    const F excl = lane == 0 ? pre : pre * F(prev);   // product of everything before this lane's first row
+    zc[i0] = excl.v;
+#pragma unroll
+    for (int e = 1; e < PZ_E; e++) zc[i0 + e] = (excl * pr[e - 1]).v;
     carry = carry * F(wtot[0]) * F(wtot[1]) * F(wtot[2]) * F(wtot[3]);
     __syncthreads();
   }
@@ -528,21 +540,30 @@ __global__ __launch_bounds__(256) void permutation_z_kernel(const u64* __restric
     if (tid == 0) carry_s = f_inv(F(wtot[0]) * F(wtot[1]) * F(wtot[2]) * F(wtot[3])).v;
     __syncthreads();
   }
-  // backward sweep: inclusive suffix product of den, times 1/prod(den)
+  // backward sweep: inclusive suffix product of den, times 1/prod(den); lane t takes rows base-1-t*PZ_E-e, scanning from the top
   carry = F(carry_s);
   __syncthreads();
-  for (size_t base = n; base > 0; base -= 256) {
-    // element handled by this thread, scanning from the top: position rev = tid counts from the end
-    size_t i = base - 1 - tid;
-    F r{rhs[i]};
-    F den = (r + g0) * (r + g1);
-    F inc = wave_scan_mul(den, lane);
+  for (size_t base = n; base > 0; base -= 256 * PZ_E) {
+    const size_t i0 = base - 1 - (size_t)tid * PZ_E;
+    u64 rv[PZ_E], zv[PZ_E];
+#pragma unroll
+    for (int e = 0; e < PZ_E; e++) { rv[e] = rhs[i0 - e]; zv[e] = zc[i0 - e]; }
+    F pr[PZ_E];   // inclusive products of den inside the lane, from the top
+#pragma unroll
+    for (int e = 0; e < PZ_E; e++) {
+      const F r(rv[e]);
+      const F den = (r + g0) * (r + g1);
+      pr[e] = e ? pr[e - 1] * den : den;
+    }
+    F inc = wave_scan_mul(pr[PZ_E - 1], lane);
     if (lane == 63) wtot[wv] = inc.v;
     __syncthreads();
     F pre = carry;
     for (int w = 0; w < wv; w++) pre = pre * F(wtot[w]);
-    F suf = pre * inc;  // = Dinv * prod_{k>=i} den_k
-    zc[i] = (F(zc[i]) * suf).v;
+    const u64 prev = __shfl_up((unsigned long long)inc.v, 1, 64);
+    const F excl = lane == 0 ? pre : pre * F(prev);
+#pragma unroll
+    for (int e = 0; e < PZ_E; e++) zc[i0 - e] = (F(zv[e]) * (excl * pr[e])).v;   // = Dinv * prod_{k>=i} den_k
     carry = carry * F(wtot[0]) * F(wtot[1]) * F(wtot[2]) * F(wtot[3]);
     __syncthreads();
   }
