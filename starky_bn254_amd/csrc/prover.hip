@@ -729,7 +729,8 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
   F gam[2][2];
   for (int s = 0; s < 2; s++) for (int c = 0; c < (int)cfg.num_challenges; c++) { (void)ch.challenge(); gam[s][c] = ch.challenge(); }
   const F gamma0 = gam[0][0], gamma1 = gam[1][1];  // instance i of a batch uses sets[i].challenges[chal]
-  if (n % 1024 == 0) hipLaunchKernelGGL(permutation_z_kernel<4>, dim3((unsigned)Z), dim3(256), 0, st, P->d_trace, n, P->d_pairs, gamma0.v, gamma1.v, P->d_zval);
+  if (n % 2048 == 0) hipLaunchKernelGGL(permutation_z_kernel<8>, dim3((unsigned)Z), dim3(256), 0, st, P->d_trace, n, P->d_pairs, gamma0.v, gamma1.v, P->d_zval);
+  else if (n % 1024 == 0) hipLaunchKernelGGL(permutation_z_kernel<4>, dim3((unsigned)Z), dim3(256), 0, st, P->d_trace, n, P->d_pairs, gamma0.v, gamma1.v, P->d_zval);
   else hipLaunchKernelGGL(permutation_z_kernel<2>, dim3((unsigned)Z), dim3(256), 0, st, P->d_trace, n, P->d_pairs, gamma0.v, gamma1.v, P->d_zval);   // n = 512
   HIPC(hipGetLastError());
   HIPC(hipEventRecord(P->ev[ST_Z_COMMIT], st));
