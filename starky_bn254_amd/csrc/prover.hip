@@ -249,6 +249,17 @@ static int commit_pipeline(sbn_prover* P, const u64* vals, u64* coef, u64* lde, 
   (void)ex_ms;
   return 0;
 }
+// Host waits inside prove(): polling keeps the wake-up out of the 10+ host round trips of a proof.
+static inline hipError_t stream_wait(hipStream_t st) {
+  hipError_t e;
+  while ((e = hipStreamQuery(st)) == hipErrorNotReady) __builtin_ia32_pause();
+  return e;
+}
+static inline hipError_t event_wait(hipEvent_t ev) {
+  hipError_t e;
+  while ((e = hipEventQuery(ev)) == hipErrorNotReady) __builtin_ia32_pause();
+  return e;
+}
 static int absorb_times(sbn_prover* P, size_t ncols, int ex_ms) {
   size_t nchunks = (ncols + P->ntt_chunk - 1) / P->ntt_chunk;
   float tot = 0;
@@ -260,7 +271,7 @@ static int tree_cap_to_host(sbn_prover* P, const DevTree& t, std::vector<u64>& c
   size_t capn = (size_t)1 << P->cfg.cap_height;
   cap.resize(capn * 4);
   HIPC(hipMemcpyAsync(cap.data(), t.level(t.nlevels), capn * 4 * sizeof(u64), hipMemcpyDeviceToHost, P->stream));
-  HIPC(hipStreamSynchronize(P->stream));
+  HIPC(stream_wait(P->stream));
   return 0;
 }
 
@@ -721,7 +732,6 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
   if ((rc = commit_pipeline(P, P->d_trace, P->d_coef, P->d_lde, C, P->tree_t, EX_TRACE_ABSORB_MS, EX_TRACE_ABSORB_LAUNCHES))) return rc;
   HIPC(hipEventRecord(P->ev[ST_PERM_Z], st));
   if ((rc = tree_cap_to_host(P, P->tree_t, trace_cap))) return rc;
-  if ((rc = absorb_times(P, C, EX_TRACE_ABSORB_MS))) return rc;
   ch.observe_words(trace_cap.data(), capw);
 
   // P2 permutation argument -------------------------------------------------------------------------
@@ -734,10 +744,10 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
   else hipLaunchKernelGGL(permutation_z_kernel<2>, dim3((unsigned)Z), dim3(256), 0, st, P->d_trace, n, P->d_pairs, gamma0.v, gamma1.v, P->d_zval);   // n = 512
   HIPC(hipGetLastError());
   HIPC(hipEventRecord(P->ev[ST_Z_COMMIT], st));
+  if ((rc = absorb_times(P, C, EX_TRACE_ABSORB_MS))) return rc;   // (27 event queries: behind the Z kernel, not in front of it)
   if ((rc = commit_pipeline(P, P->d_zval, P->d_zcoef, P->d_zlde, Z, P->tree_z, EX_Z_ABSORB_MS, EX_Z_ABSORB_LAUNCHES))) return rc;
   HIPC(hipEventRecord(P->ev[ST_QUOTIENT_EVAL], st));
   if ((rc = tree_cap_to_host(P, P->tree_z, z_cap))) return rc;
-  if ((rc = absorb_times(P, Z, EX_Z_ABSORB_MS))) return rc;
   ch.observe_words(z_cap.data(), capw);
 
   // P3 quotient -------------------------------------------------------------------------------------
@@ -761,7 +771,7 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
       exp_pi_consts<F>(exp_shape(P->air), app, pif.data(), pic);
       HIPC(hipMemcpyAsync(P->d_pic, &pic, sizeof(pic), hipMemcpyHostToDevice, st));
     }
-    HIPC(hipStreamSynchronize(st));
+    HIPC(stream_wait(st));
   }
   {
     QuotientParams qp{};
@@ -789,6 +799,7 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
     else hipLaunchKernelGGL(quotient_kernel<4>, qgrid, dim3(256), 0, st, qp);
     hipLaunchKernelGGL(quotient_combine_kernel, blocks(m), dim3(256), 0, st, qp);
     HIPC(hipGetLastError());
+    if ((rc = absorb_times(P, Z, EX_Z_ABSORB_MS))) return rc;   // behind the quotient kernel
   }
   HIPC(hipEventRecord(P->ev[ST_QUOTIENT_COMMIT], st));
   // coset_ifft(7) of the 2 quotient value vectors (size m), in place via tmp; the result viewed as
@@ -830,10 +841,10 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
   HIPC(hipEventRecord(P->ev[ST_FRI_COMBINE], st));
   // observe_openings: batch zeta = local ++ perm_zs ++ quotient ; batch g*zeta = next ++ perm_zs_next
   for (int k = 0; k < OPEN_SLICES; k++) {
-    HIPC(hipEventSynchronize(P->chunk_ready[k]));
+    HIPC(event_wait(P->chunk_ready[k]));
     for (size_t p = k ? slice_end[k - 1] : 0; p < slice_end[k]; p++) { ch.observe(F(open[4 * p])); ch.observe(F(open[4 * p + 1])); }
   }
-  HIPC(hipStreamSynchronize(st));
+  HIPC(stream_wait(st));
   for (size_t p = C; p < C + Z + 4; p++) { ch.observe(F(open[4 * p])); ch.observe(F(open[4 * p + 1])); }
   for (size_t p = 0; p < C + Z; p++) { ch.observe(F(open[4 * p + 2])); ch.observe(F(open[4 * p + 3])); }
 
@@ -867,7 +878,7 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
     if (Z) if ((rc = combine(P->d_zcoef, (u32)Z, w_z, f1a, f1b, 1))) return rc;
     HIPC(hipMemcpyAsync(f0a, f1a, 2 * n * sizeof(u64), hipMemcpyDeviceToDevice, st));
     if ((rc = combine(P->d_q, 4, w_q, f0a, f0b, 1))) return rc;
-    HIPC(hipStreamSynchronize(st));  // `wall` (pageable host memory) must outlive its upload
+    HIPC(stream_wait(st));  // `wall` (pageable host memory) must outlive its upload
     // final_poly = alpha^(C+Z) * (F0 / (X - zeta)) + F1 / (X - g zeta), padded back to n, then lde -> m
     HIPC(hipMemsetAsync(P->d_fcoef, 0, 2 * m * sizeof(u64), st));
     E2 shift2 = e2_pow(fri_alpha, C + Z);
@@ -920,7 +931,7 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
     std::vector<u64> fa(fl), fb(fl);
     HIPC(hipMemcpyAsync(fa.data(), coef, fl * sizeof(u64), hipMemcpyDeviceToHost, st));
     HIPC(hipMemcpyAsync(fb.data(), coef + clen, fl * sizeof(u64), hipMemcpyDeviceToHost, st));
-    HIPC(hipStreamSynchronize(st));
+    HIPC(stream_wait(st));
     for (size_t i = 0; i < fl; i++) { final_poly[2 * i] = fa[i]; final_poly[2 * i + 1] = fb[i]; ch.observe(F(fa[i])); ch.observe(F(fb[i])); }
   }
   HIPC(hipEventRecord(P->ev[ST_POW], st));
@@ -942,7 +953,7 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
       pp.base = base; pp.count = BATCH;
       hipLaunchKernelGGL(pow_kernel, blocks(BATCH), dim3(256), 0, st, pp);
       HIPC(hipMemcpyAsync(&pow_witness, P->d_pow, sizeof(u64), hipMemcpyDeviceToHost, st));
-      HIPC(hipStreamSynchronize(st));
+      HIPC(stream_wait(st));
       base += BATCH;
     }
     ch.observe(F(pow_witness));
@@ -986,7 +997,7 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
     HIPC(hipMemcpyAsync(qwords.data(), P->d_qbuf, qwords.size() * sizeof(u64), hipMemcpyDeviceToHost, st));
   }
   HIPC(hipEventRecord(P->ev[ST_COUNT], st));
-  HIPC(hipStreamSynchronize(st));
+  HIPC(stream_wait(st));
   for (int i = 0; i < ST_COUNT; i++) HIPC(hipEventElapsedTime(&P->stage_ms[i], P->ev[i], P->ev[i + 1]));
 
   // assemble canonical proof words (layout: include/sbn.h) -----------------------------------------
