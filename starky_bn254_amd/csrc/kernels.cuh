@@ -719,6 +719,35 @@ __global__ __launch_bounds__(256) void openings_kernel(const u64* __restrict__ c
   }
 }
 
+// One point only (tables pa, pb), written to out[4 * poly + off .. + 1]: the trace openings at zeta go first so that the
+// host can start hashing them into the transcript while the device evaluates everything else.
+template <u32 OPEN_UNROLL>
+__global__ __launch_bounds__(256) void openings1_kernel(const u64* __restrict__ coeffs, size_t n, const u64* __restrict__ pa, const u64* __restrict__ pb,
+                                                        u64* __restrict__ out, u32 off) {
+  __shared__ u64 sh[4];
+  const u64* c = coeffs + (size_t)blockIdx.x * n;
+  F a0(0), b0(0);
+  for (size_t i = threadIdx.x; i < n; i += 256 * OPEN_UNROLL) {
+    u64 cv[OPEN_UNROLL], t0[OPEN_UNROLL], t1[OPEN_UNROLL];
+#pragma unroll
+    for (u32 k = 0; k < OPEN_UNROLL; k++) {
+      const size_t ik = i + 256 * k;
+      cv[k] = c[ik]; t0[k] = pa[ik]; t1[k] = pb[ik];
+    }
+    __builtin_amdgcn_sched_barrier(0);   // all the loads first
+#pragma unroll
+    for (u32 k = 0; k < OPEN_UNROLL; k++) {
+      const F v{cv[k]};
+      a0 += v * F(t0[k]); b0 += v * F(t1[k]);
+    }
+  }
+  a0 = block_sum(a0, sh); b0 = block_sum(b0, sh);
+  if (threadIdx.x == 0) {
+    u64* o = out + (size_t)blockIdx.x * 4 + off;
+    o[0] = a0.v; o[1] = b0.v;
+  }
+}
+
 // =================================================================================================
 // K7  FRI batch combine (fri/oracle.rs `prove_openings`: alpha.reduce_polys_base; P5)
 // part[g][i] = sum_{j in group g} alpha^(j - j0_g) * f_j[i]  (Horner from the group's last poly);

@@ -85,6 +85,7 @@ struct sbn_prover {
   u64* h_chain = nullptr;                    // pinned staging for the host-computed curve chains (device tracegen)
   size_t h_chain_words = 0;
   u64* h_open = nullptr;                     // pinned landing buffer of the opened values [(ncols + nzs + 4)][4]
+  u64* h_open2 = nullptr;                    // second landing buffer of the trace rows (their values at g*zeta arrive last)
 };
 
 static int dmalloc(u64** p, size_t words) {
@@ -322,6 +323,7 @@ extern "C" int sbn_prover_create(const sbn_air_desc* air, const sbn_config* cfg,
   rc |= dmalloc(&P->d_apow, (size_t)SBN_NCH * P->apow_n);
   rc |= dmalloc(&P->d_zpow, 4 * n); rc |= dmalloc(&P->d_open, (C + Z + 4) * 4);
   if (hipHostMalloc((void**)&P->h_open, (C + Z + 4) * 4 * sizeof(u64), hipHostMallocDefault) != hipSuccess) rc |= 1;
+  if (hipHostMalloc((void**)&P->h_open2, C * 4 * sizeof(u64), hipHostMallocDefault) != hipSuccess) rc |= 1;
   rc |= dmalloc(&P->d_part, 2 * 32 * n); rc |= dmalloc(&P->d_w, 4096); rc |= dmalloc(&P->d_sponge, 12 * m);
   rc |= dmalloc(&P->d_fa, 4 * n); rc |= dmalloc(&P->d_fcoef, 2 * m); rc |= dmalloc(&P->d_fcoef2, 2 * m);
   rc |= dmalloc(&P->d_pow, 1);
@@ -393,6 +395,7 @@ extern "C" void sbn_prover_destroy(sbn_prover* P) {
   if (P->d_sponge) (void)hipFree(P->d_sponge);
   if (P->h_chain) (void)hipHostFree(P->h_chain);
   if (P->h_open) (void)hipHostFree(P->h_open);
+  if (P->h_open2) (void)hipHostFree(P->h_open2);
   (void)hipStreamDestroy(P->hstream);
   (void)hipStreamDestroy(P->stream);
   delete P;
@@ -818,35 +821,36 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
   E2 zeta_next = zeta * g;
   hipLaunchKernelGGL(ext_pow_table_kernel, blocks(n), dim3(256), 0, st, P->d_zpow, P->d_zpow + n, n, zeta.a.v, zeta.b.v);
   hipLaunchKernelGGL(ext_pow_table_kernel, blocks(n), dim3(256), 0, st, P->d_zpow + 2 * n, P->d_zpow + 3 * n, n, zeta_next.a.v, zeta_next.b.v);
-  // The trace openings are copied to pinned memory behind their own event, so that the host hashes the local values (a
-  // third of the 1,220 transcript permutations) while the device computes the Z and quotient openings.  Slicing the trace
-  // columns further (hashing after a quarter of them) was measured: every extra copy + event costs ~0.1 ms of stream
-  // time, more than the earlier start buys.
+  // Transcript order: local (trace at zeta), Z at zeta, quotient at zeta, then next (trace at g*zeta), Z at g*zeta.  The
+  // 1,220 sequential permutations that hash them are the longest host stretch of a proof, so the device produces the
+  // values in that order behind three events: trace at zeta alone first (the host starts hashing after half an opening
+  // pass), then Z and quotient at both points, then trace at g*zeta -- the coefficients are read twice, in time the
+  // device would otherwise spend waiting for the host.
   const u64* open = P->h_open;
-  auto open_k = (n % 1024 == 0) ? openings_kernel<4> : openings_kernel<1>;
-  constexpr int OPEN_SLICES = 1;
-  size_t slice_end[OPEN_SLICES];
-  for (int k = 0; k < OPEN_SLICES; k++) {
-    const size_t c0 = C * k / OPEN_SLICES, c1 = C * (k + 1) / OPEN_SLICES;
-    slice_end[k] = c1;
-    hipLaunchKernelGGL(open_k, dim3((unsigned)(c1 - c0)), dim3(256), 0, st, P->d_coef + c0 * n, n, P->d_zpow, P->d_zpow + n, P->d_zpow + 2 * n, P->d_zpow + 3 * n,
-                       P->d_open + c0 * 4);
-    HIPC(hipMemcpyAsync(P->h_open + c0 * 4, P->d_open + c0 * 4, (c1 - c0) * 4 * sizeof(u64), hipMemcpyDeviceToHost, st));
-    HIPC(hipEventRecord(P->chunk_ready[k], st));  // (the commit pipeline's chunk events are idle here)
-  }
-  hipLaunchKernelGGL(open_k, dim3((unsigned)Z), dim3(256), 0, st, P->d_zcoef, n, P->d_zpow, P->d_zpow + n, P->d_zpow + 2 * n, P->d_zpow + 3 * n, P->d_open + C * 4);
-  hipLaunchKernelGGL(open_k, dim3(4), dim3(256), 0, st, P->d_q, n, P->d_zpow, P->d_zpow + n, P->d_zpow + 2 * n, P->d_zpow + 3 * n, P->d_open + (C + Z) * 4);
-  HIPC(hipGetLastError());
+  const bool u4 = n % 1024 == 0;
+  auto open_k = u4 ? openings_kernel<4> : openings_kernel<1>;
+  auto open1_k = u4 ? openings1_kernel<4> : openings1_kernel<1>;
+  const u64 *zp0 = P->d_zpow, *zp1 = P->d_zpow + n, *zp2 = P->d_zpow + 2 * n, *zp3 = P->d_zpow + 3 * n;
+  hipLaunchKernelGGL(open1_k, dim3((unsigned)C), dim3(256), 0, st, P->d_coef, n, zp0, zp1, P->d_open, 0u);
+  HIPC(hipMemcpyAsync(P->h_open, P->d_open, C * 4 * sizeof(u64), hipMemcpyDeviceToHost, st));
+  HIPC(hipEventRecord(P->chunk_ready[0], st));  // (the commit pipeline's chunk events are idle here)
+  hipLaunchKernelGGL(open_k, dim3((unsigned)Z), dim3(256), 0, st, P->d_zcoef, n, zp0, zp1, zp2, zp3, P->d_open + C * 4);
+  hipLaunchKernelGGL(open_k, dim3(4), dim3(256), 0, st, P->d_q, n, zp0, zp1, zp2, zp3, P->d_open + (C + Z) * 4);
   HIPC(hipMemcpyAsync(P->h_open + C * 4, P->d_open + C * 4, (Z + 4) * 4 * sizeof(u64), hipMemcpyDeviceToHost, st));
+  HIPC(hipEventRecord(P->chunk_ready[1], st));
+  hipLaunchKernelGGL(open1_k, dim3((unsigned)C), dim3(256), 0, st, P->d_coef, n, zp2, zp3, P->d_open, 2u);
+  HIPC(hipGetLastError());
+  HIPC(hipMemcpyAsync(P->h_open2, P->d_open, C * 4 * sizeof(u64), hipMemcpyDeviceToHost, st));   // a second buffer: the host is reading the first
   HIPC(hipEventRecord(P->ev[ST_FRI_COMBINE], st));
   // observe_openings: batch zeta = local ++ perm_zs ++ quotient ; batch g*zeta = next ++ perm_zs_next
-  for (int k = 0; k < OPEN_SLICES; k++) {
-    HIPC(event_wait(P->chunk_ready[k]));
-    for (size_t p = k ? slice_end[k - 1] : 0; p < slice_end[k]; p++) { ch.observe(F(open[4 * p])); ch.observe(F(open[4 * p + 1])); }
-  }
-  HIPC(stream_wait(st));
+  HIPC(event_wait(P->chunk_ready[0]));
+  for (size_t p = 0; p < C; p++) { ch.observe(F(open[4 * p])); ch.observe(F(open[4 * p + 1])); }
+  HIPC(event_wait(P->chunk_ready[1]));
   for (size_t p = C; p < C + Z + 4; p++) { ch.observe(F(open[4 * p])); ch.observe(F(open[4 * p + 1])); }
-  for (size_t p = 0; p < C + Z; p++) { ch.observe(F(open[4 * p + 2])); ch.observe(F(open[4 * p + 3])); }
+  HIPC(stream_wait(st));
+  const u64* open2 = P->h_open2;
+  for (size_t p = 0; p < C; p++) { ch.observe(F(open2[4 * p + 2])); ch.observe(F(open2[4 * p + 3])); }
+  for (size_t p = C; p < C + Z; p++) { ch.observe(F(open[4 * p + 2])); ch.observe(F(open[4 * p + 3])); }
 
   // P5 FRI ------------------------------------------------------------------------------------------
   E2 fri_alpha = ch.ext_challenge();
@@ -1012,7 +1016,7 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
   if (Z) w.insert(w.end(), z_cap.begin(), z_cap.end());
   w.insert(w.end(), q_cap.begin(), q_cap.end());
   for (size_t p = 0; p < C; p++) { w.push_back(open[4 * p]); w.push_back(open[4 * p + 1]); }          // local_values
-  for (size_t p = 0; p < C; p++) { w.push_back(open[4 * p + 2]); w.push_back(open[4 * p + 3]); }      // next_values
+  for (size_t p = 0; p < C; p++) { w.push_back(open2[4 * p + 2]); w.push_back(open2[4 * p + 3]); }    // next_values
   for (size_t p = C; p < C + Z; p++) { w.push_back(open[4 * p]); w.push_back(open[4 * p + 1]); }      // permutation_zs
   for (size_t p = C; p < C + Z; p++) { w.push_back(open[4 * p + 2]); w.push_back(open[4 * p + 3]); }  // permutation_zs_next
   for (size_t p = C + Z; p < C + Z + 4; p++) { w.push_back(open[4 * p]); w.push_back(open[4 * p + 1]); }  // quotient_polys
