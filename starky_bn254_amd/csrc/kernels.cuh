@@ -754,15 +754,28 @@ __global__ __launch_bounds__(256) void openings1_kernel(const u64* __restrict__ 
 // the host-side combine multiplies by alpha^(j0_g).  Thread per coefficient index, groups on
 // blockIdx.y for parallelism.  Algorithmic bytes: 8*N per polynomial, read once.
 // =================================================================================================
+// (pa, pb)[k] = the two coordinates of alpha^k, k < group_size (ext_pow_table_kernel): a base-field coefficient times an
+// extension power is two multiplies, where the Horner step acc * alpha + f is a full extension product; the table index is
+// uniform, so the powers arrive through scalar loads.
 __global__ __launch_bounds__(256) void fri_combine_partial_kernel(const u64* __restrict__ coeffs, size_t n, u32 npoly, u32 group_size,
-                                                                  u64 al0, u64 al1, u64* __restrict__ part_a, u64* __restrict__ part_b) {
+                                                                  const u64* __restrict__ pa, const u64* __restrict__ pb, u64* __restrict__ part_a,
+                                                                  u64* __restrict__ part_b) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  u32 g = blockIdx.y;
-  u32 j0 = g * group_size, j1 = j0 + group_size < npoly ? j0 + group_size : npoly;
-  E2 alpha{F(al0), F(al1)}, acc(F(0), F(0));
-  for (u32 j = j1; j-- > j0;) acc = acc * alpha + F(coeffs[(size_t)j * n + i]);
-  part_a[(size_t)g * n + i] = acc.a.v; part_b[(size_t)g * n + i] = acc.b.v;
+  const u32 g = blockIdx.y;
+  const u32 j0 = g * group_size, cnt = j0 + group_size < npoly ? group_size : npoly - j0;
+  const u64* c = coeffs + (size_t)j0 * n + i;
+  F a(0), b(0);
+  u32 k = 0;
+  for (; k + 8 <= cnt; k += 8) {
+    u64 f[8];
+#pragma unroll
+    for (u32 u = 0; u < 8; u++) f[u] = c[(size_t)(k + u) * n];
+#pragma unroll
+    for (u32 u = 0; u < 8; u++) { const F v(f[u]); a += v * F(pa[k + u]); b += v * F(pb[k + u]); }
+  }
+  for (; k < cnt; k++) { const F v(c[(size_t)k * n]); a += v * F(pa[k]); b += v * F(pb[k]); }
+  part_a[(size_t)g * n + i] = a.v; part_b[(size_t)g * n + i] = b.v;
 }
 // out[i] (+)= sum_g w_g * part[g][i]   (w_g given as ext pairs)
 __global__ void fri_combine_reduce_kernel(const u64* part_a, const u64* part_b, size_t n, u32 ngroups, const u64* w, u64* out_a, u64* out_b, int accumulate) {

@@ -871,12 +871,14 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
     size_t w_t = plan((u32)C, one), w_z = Z ? plan((u32)Z, e2_pow(fri_alpha, C)) : 0, w_q = plan(4, e2_pow(fri_alpha, C + Z));
     if (wall.size() > 4096) return fail(SBN_ERR_UNSUPPORTED, "too many FRI combine groups");
     HIPC(hipMemcpyAsync(P->d_w, wall.data(), wall.size() * sizeof(u64), hipMemcpyHostToDevice, st));
+    // alpha^k, k < GS, as two planes in the quotient's alpha-power buffer (idle now; it holds at least 1,025 words per plane)
+    hipLaunchKernelGGL(ext_pow_table_kernel, dim3(1), dim3(GS), 0, st, P->d_apow, P->d_apow + GS, (size_t)GS, fri_alpha.a.v, fri_alpha.b.v);
     auto combine = [&](const u64* coeffs, u32 npoly, size_t woff, u64* oa, u64* ob, int accumulate) -> int {
       u32 ng = (npoly + GS - 1) / GS;
       for (u32 g0 = 0; g0 < ng; g0 += 32) {
         u32 gc = std::min<u32>(32, ng - g0);
         hipLaunchKernelGGL(fri_combine_partial_kernel, dim3((unsigned)((n + 255) / 256), gc), dim3(256), 0, st, coeffs + (size_t)g0 * GS * n, n,
-                           npoly - g0 * GS, GS, fri_alpha.a.v, fri_alpha.b.v, P->d_part, P->d_part + 32 * n);
+                           npoly - g0 * GS, GS, P->d_apow, P->d_apow + GS, P->d_part, P->d_part + 32 * n);
         hipLaunchKernelGGL(fri_combine_reduce_kernel, blocks(n), dim3(256), 0, st, P->d_part, P->d_part + 32 * n, n, gc, P->d_w + woff + 2 * g0, oa, ob,
                            (accumulate || g0 > 0) ? 1 : 0);
       }
