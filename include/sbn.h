@@ -79,6 +79,12 @@ typedef struct sbn_config {
   uint32_t fri_arity_bits;     /* 4   (FriReductionStrategy::ConstantArityBits(4, 5)) */
   uint32_t fri_final_poly_bits;/* 5   */
   uint32_t num_query_rounds;   /* 84  */
+  /* Not a StarkConfig field: which plonky2 FRI this library speaks.  1 (default) = the 0.1.x line the reference pins
+   * (plonky2 0.1.3 @ 541e127, Cargo.lock:529-531): fri/oracle.rs `prove_openings` multiplies the final polynomial by X
+   * (`final_poly.coeffs.insert(0, ZERO)`, mir-protocol/plonky2 PR #436) and fri/verifier.rs `fri_combine_initial` returns
+   * `sum * subgroup_x`.  0 = later upstream versions, which dropped the step (the quotients are zero-padded at the end).
+   * The dependency is un-vendored, so the default is recalled ([DEP-RECALL]); both forms are tested. */
+  uint32_t fri_final_poly_times_x;
 } sbn_config;
 
 typedef struct sbn_prover sbn_prover; /* device context: buffers sized for one (air, degree_bits) */
@@ -159,6 +165,42 @@ typedef struct sbn_batch_prover sbn_batch_prover;
 int sbn_batch_prover_create(const sbn_air_desc* air, const sbn_config* cfg, uint32_t degree_bits, uint32_t inflight, sbn_batch_prover** out);
 int sbn_batch_prover_prove_ios(sbn_batch_prover* b, const uint32_t* ios, size_t ios_words_per_unit, size_t num_io, size_t count, sbn_proof** proofs_out);
 void sbn_batch_prover_destroy(sbn_batch_prover* b);
+
+/* One oversized trace split over the GPUs of a node (BASELINE config "Single Fq12 exponentiation proof, trace height
+ * 2^18, 8xMI355X with RCCL FRI fold"; reference workload src/fields/fq12/exp.rs:638-696).  One process per GPU; every
+ * rank calls the same functions with the same arguments and receives the same proof.  Work and the derived matrices
+ * (coefficients, LDE, Z, Merkle trees) are sharded: columns for iNTT / LDE / Z / openings / the FRI batch combination,
+ * LDE ROWS for leaf hashing, Merkle subtrees, constraint evaluation and query answers (rank s owns the rows whose Merkle
+ * leaf index has top log2(world) bits = s: complete cap subtrees).  The trace VALUES are resident on every rank
+ * (generated there by sbn_split_prover_generate_trace, or loaded).  Exchange steps: one all-to-all per commitment
+ * (columns -> rows), and small all-gathers (caps, quotient values, openings, FRI partial sums, query rows).
+ * The library does no communication itself: the caller supplies the collectives (torch.distributed / RCCL in
+ * starky_bn254_amd/split.py; a host-staged backend for tests) and the device staging memory they work on.
+ * world must be 1, 2, 4, 8 or 16 (<= 2^cap_height). */
+typedef struct sbn_comm {
+  void* ctx;                 /* passed back to the callbacks */
+  uint32_t rank, world;
+  void* send_buf;            /* device memory, >= send_bytes of sbn_split_exchange_bytes */
+  void* recv_buf;            /* device memory, >= recv_bytes; holds this rank's row-sharded LDE matrices during a proof */
+  uint64_t send_bytes, recv_bytes;
+  /* Block d = send_buf[send_off[d] .. +send_len[d]) goes to rank d; the block from rank s lands at
+   * recv_buf[recv_off[s] .. +recv_len[s]).  Arrays of `world` entries, bytes.  Blocks sent to different ranks may be the
+   * same region (an all-gather).  Returns 0 when the received data is complete and visible to the device. */
+  int (*all_to_all)(void* ctx, const uint64_t* send_off, const uint64_t* send_len, const uint64_t* recv_off, const uint64_t* recv_len);
+  /* Host memory: every rank contributes `bytes` at send; recv = [world][bytes] in rank order. */
+  int (*all_gather_host)(void* ctx, const void* send, void* recv, uint64_t bytes);
+} sbn_comm;
+typedef struct sbn_split_prover sbn_split_prover;
+/* Staging sizes a rank needs for (air, degree_bits) in a world of `world` ranks. */
+int sbn_split_exchange_bytes(const sbn_air_desc* air, const sbn_config* cfg, uint32_t degree_bits, uint32_t world, uint64_t* send_bytes, uint64_t* recv_bytes);
+int sbn_split_prover_create(const sbn_air_desc* air, const sbn_config* cfg, uint32_t degree_bits, const sbn_comm* comm, sbn_split_prover** out);
+void sbn_split_prover_destroy(sbn_split_prover* p);
+/* As sbn_prover_generate_trace / sbn_prover_load_trace: the full trace values on this rank. */
+int sbn_split_prover_generate_trace(sbn_split_prover* p, const uint32_t* ios, size_t num_io, uint64_t* pi_out);
+int sbn_split_prover_load_trace(sbn_split_prover* p, const uint64_t* trace_col_major, const uint64_t* public_inputs, size_t n_pi);
+/* The proof of the whole trace, on every rank, word for word the proof sbn_prover_prove gives on one GPU. */
+int sbn_split_prover_prove(sbn_split_prover* p, sbn_proof** out);
+int sbn_split_prover_stage_times(const sbn_split_prover* p, float* ms_out, int cap);
 
 /* Proof object ---------------------------------------------------------------------------------- */
 size_t sbn_proof_num_words(const sbn_proof* proof);

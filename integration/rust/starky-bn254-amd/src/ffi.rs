@@ -20,6 +20,8 @@ pub struct sbn_config {
     pub fri_arity_bits: u32,
     pub fri_final_poly_bits: u32,
     pub num_query_rounds: u32,
+    /// 1 = plonky2 0.1.x FRI (final polynomial multiplied by X, PR #436), 0 = later upstream; see include/sbn.h
+    pub fri_final_poly_times_x: u32,
 }
 
 #[repr(C)]

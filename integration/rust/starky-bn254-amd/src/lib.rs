@@ -47,6 +47,9 @@ fn check(rc: i32, what: &str) -> Result<()> {
     }
 }
 
+/// Which FRI the linked plonky2 speaks (include/sbn.h `sbn_config.fri_final_poly_times_x`).
+pub const FRI_FINAL_POLY_TIMES_X: u32 = 1;
+
 /// `StarkConfig` -> `sbn_config`.  Only `FriReductionStrategy::ConstantArityBits` is supported, which is what
 /// `standard_fast_config` uses (exp.rs:250-253).
 pub fn to_sbn_config(c: &StarkConfig) -> Result<ffi::sbn_config> {
@@ -64,6 +67,9 @@ pub fn to_sbn_config(c: &StarkConfig) -> Result<ffi::sbn_config> {
         fri_arity_bits: arity_bits,
         fri_final_poly_bits: final_poly_bits,
         num_query_rounds: c.fri_config.num_query_rounds as u32,
+        // plonky2 0.1.3 @ 541e127 (the fork this crate links) still multiplies the final polynomial by X in
+        // fri/oracle.rs::prove_openings; set to 0 when building against a plonky2 that dropped the step.
+        fri_final_poly_times_x: FRI_FINAL_POLY_TIMES_X,
     })
 }
 

@@ -218,6 +218,11 @@ int orc_g1op_generate_trace(const uint32_t* pts, size_t rows, uint64_t* trace_ou
   return 0;
 }
 
+// Switch of this restatement (oracle/fri.hpp FriConfig::final_poly_times_x): 1 = plonky2 0.1.x "multiply the final
+// polynomial by X" step (default), 0 = the later upstream form without it.
+static int g_final_poly_times_x = 1;
+void orc_set_final_poly_times_x(int on) { g_final_poly_times_x = on ? 1 : 0; }
+
 // prove(): trace col-major [ncols][1<<degree_bits]; returns malloc'd canonical proof words.
 int orc_prove(int kind, size_t num_io, const uint64_t* trace, unsigned degree_bits, const uint64_t* pi, size_t npi,
               uint64_t** proof_out, size_t* nwords_out, double* seconds_out) {
@@ -229,6 +234,7 @@ int orc_prove(int kind, size_t num_io, const uint64_t* trace, unsigned degree_bi
   for (size_t c = 0; c < ncols; c++) for (size_t i = 0; i < n; i++) { if (trace[c * n + i] >= GL_P) return -3; cols[c][i] = GF(trace[c * n + i]); }
   std::vector<GF> pis(npi); for (size_t i = 0; i < npi; i++) pis[i] = GF(pi[i]);
   StarkConfig cfg;
+  cfg.fri.final_poly_times_x = g_final_poly_times_x != 0;
   auto t0 = std::chrono::steady_clock::now();
   StarkProofWithPublicInputs p = prove(*air, cfg, cols, pis);
   auto t1 = std::chrono::steady_clock::now();
@@ -249,6 +255,7 @@ int orc_verify(int kind, size_t num_io, const uint64_t* proof, size_t nwords, co
   StarkProofWithPublicInputs p;
   if (!deserialize_proof(proof, nwords, p)) { if (why) *why = "malformed proof bytes"; return -2; }
   StarkConfig cfg;
+  cfg.fri.final_poly_times_x = g_final_poly_times_x != 0;
   const char* reason = "";
   if (!verify(*air, cfg, p, &reason)) { if (why) *why = reason; return -3; }
   return 0;

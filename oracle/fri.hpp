@@ -13,6 +13,12 @@ struct FriConfig {
   unsigned rate_bits = 1, cap_height = 4, proof_of_work_bits = 16;
   unsigned arity_bits = 4, final_poly_bits = 5;  // FriReductionStrategy::ConstantArityBits(4, 5)
   unsigned num_query_rounds = 84;
+  // fri/oracle.rs `prove_openings`: "Multiply the final polynomial by `X`, so that `final_poly` has the maximum degree for
+  // which the LDT will pass" (mir-protocol/plonky2 PR #436): the quotients keep their n-1 coefficients and a zero is
+  // inserted in FRONT; the verifier's fri_combine_initial returns `sum * subgroup_x`.  Present in the 0.1.x line the
+  // reference pins (recalled, [DEP-RECALL]); later upstream versions dropped the step and pad a zero at the END instead
+  // (final_poly_times_x = false).  Not a StarkConfig field upstream: a switch of this restatement only.
+  bool final_poly_times_x = true;
 };
 // starky config.rs `StarkConfig::standard_fast_config`.
 struct StarkConfig {
@@ -104,9 +110,11 @@ static inline FriProof prove_openings(const FriInstanceInfo& instance,
     if (final_poly.empty()) final_poly.assign(n, Ext::zero());
     for (size_t i = 0; i < n; i++) final_poly[i] = final_poly[i] * shift + quot[i];
   }
-  // lde + coset FFT over the extension
+  // lde + coset FFT over the extension (with the multiply-by-X step: final_poly.coeffs.insert(0, ZERO); the last padded
+  // coefficient of every quotient is zero, so the shift loses nothing and the length stays n)
   std::vector<Ext> coeffs(n << params.config.rate_bits, Ext::zero());
-  for (size_t i = 0; i < n; i++) coeffs[i] = final_poly[i];
+  if (params.config.final_poly_times_x) { for (size_t i = 0; i + 1 < n; i++) coeffs[i + 1] = final_poly[i]; }
+  else for (size_t i = 0; i < n; i++) coeffs[i] = final_poly[i];
   std::vector<Ext> values = ext_coset_fft(coeffs, GF(GL_GENERATOR));
 
   FriProof proof;
@@ -284,7 +292,7 @@ static inline bool verify_fri_proof(const FriInstanceInfo& instance, const FriOp
         sum = sum * ext_pow(chal.fri_alpha, batch.polys.size());
         sum += numerator * ext_inv(denominator);
       }
-      old_eval = sum;
+      old_eval = params.config.final_poly_times_x ? sum * Ext(subgroup_x) : sum;
     }
     if (rp.steps.size() != params.reduction_arity_bits.size()) { *why = "fri: steps count"; return false; }
     for (size_t i = 0; i < params.reduction_arity_bits.size(); i++) {

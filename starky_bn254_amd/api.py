@@ -32,6 +32,8 @@ EXPORTS = [
     "sbn_batch_prover_create", "sbn_batch_prover_prove_ios", "sbn_batch_prover_destroy",
     "sbn_prove", "sbn_proof_num_words", "sbn_proof_words", "sbn_proof_serialize", "sbn_proof_degree_bits",
     "sbn_proof_free", "sbn_verify", "sbn_commit_values", "sbn_poseidon_permute_batch", "sbn_poseidon_permute_host",
+    "sbn_split_exchange_bytes", "sbn_split_prover_create", "sbn_split_prover_destroy", "sbn_split_prover_generate_trace",
+    "sbn_split_prover_load_trace", "sbn_split_prover_prove", "sbn_split_prover_stage_times",
 ]
 
 
@@ -47,7 +49,8 @@ class _AirDesc(C.Structure):
 
 class _Config(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("security_bits", "num_challenges", "rate_bits", "cap_height",
-                                            "proof_of_work_bits", "fri_arity_bits", "fri_final_poly_bits", "num_query_rounds")]
+                                            "proof_of_work_bits", "fri_arity_bits", "fri_final_poly_bits", "num_query_rounds",
+                                            "fri_final_poly_times_x")]
 
 
 def lib_path():
@@ -134,6 +137,12 @@ class StarkConfig:
 
     def __getattr__(self, name):
         return getattr(object.__getattribute__(self, "_c"), name)
+
+    def __setattr__(self, name, value):
+        if name != "_c" and any(name == f[0] for f in _Config._fields_):
+            setattr(self._c, name, value)
+        else:
+            object.__setattr__(self, name, value)
 
 
 class _Stark:

@@ -19,6 +19,7 @@ void sbn_standard_fast_config(sbn_config* c) {
   if (!c) return;
   c->security_bits = 100; c->num_challenges = 2; c->rate_bits = 1; c->cap_height = 4; c->proof_of_work_bits = 16;
   c->fri_arity_bits = 4; c->fri_final_poly_bits = 5; c->num_query_rounds = 84;
+  c->fri_final_poly_times_x = 1;
 }
 
 size_t sbn_air_num_columns(const sbn_air_desc* air) { AirShape s; return air_shape(air, nullptr, s) ? s.ncols : 0; }
@@ -54,12 +55,14 @@ int sbn_prove(const sbn_air_desc* air, const sbn_config* cfg, const uint64_t* tr
 // `inflight` prover contexts on the current GPU, one host thread each; every unit = one instance list of the table,
 // witness generated on the device, then proved.  While one proof sits in a latency-bound tail or waits for the host
 // transcript, the kernels of the others fill the GPU (30.7 instead of 26.5 proofs/s for G1ExpStark(128)).
-struct sbn_batch_prover { std::vector<sbn_prover*> provers; };
+struct sbn_batch_prover { std::vector<sbn_prover*> provers; int kind = 0; };
 
 int sbn_batch_prover_create(const sbn_air_desc* air, const sbn_config* cfg, uint32_t degree_bits, uint32_t inflight, sbn_batch_prover** out) {
   if (!out || inflight == 0 || inflight > 16) return fail(SBN_ERR_BAD_ARG, "bad arguments (1 <= inflight <= 16)");
   *out = nullptr;
+  if (!air) return fail(SBN_ERR_BAD_ARG, "null argument");
   sbn_batch_prover* B = new sbn_batch_prover();
+  B->kind = air->kind;
   for (uint32_t i = 0; i < inflight; i++) {
     sbn_prover* P = nullptr;
     int rc = sbn_prover_create(air, cfg, degree_bits, &P);
@@ -77,6 +80,8 @@ void sbn_batch_prover_destroy(sbn_batch_prover* B) {
 int sbn_batch_prover_prove_ios(sbn_batch_prover* B, const uint32_t* ios, size_t ios_words_per_unit, size_t num_io, size_t count, sbn_proof** proofs_out) {
   if (!B || !ios || !proofs_out) return fail(SBN_ERR_BAD_ARG, "null argument");
   for (size_t i = 0; i < count; i++) proofs_out[i] = nullptr;
+  if (exp_io_words(B->kind) == 0 || ios_words_per_unit != exp_io_words(B->kind) * num_io)
+    return fail(SBN_ERR_BAD_ARG, "ios_words_per_unit must be %zu u32 words per instance times num_io", exp_io_words(B->kind));
   std::atomic<size_t> next(0);
   std::atomic<int> first_rc(0);
   std::mutex m; std::string msg;

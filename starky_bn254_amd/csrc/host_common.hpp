@@ -78,11 +78,18 @@ static inline bool air_shape(const sbn_air_desc* air, const sbn_config* cfg, Air
 }
 static inline bool is_exp_air(int kind) { return kind == SBN_AIR_G1_EXP || kind == SBN_AIR_G2_EXP || kind == SBN_AIR_FQ12_EXP || kind == SBN_AIR_FQ_EXP || kind == SBN_AIR_FQ12_EXP_U64; }
 static inline size_t exp_rows_per_instance(int kind) { return kind == SBN_AIR_FQ12_EXP_U64 ? 128 : 512; }
+// u32 words of one instance in the `ios` arrays of include/sbn.h (x, offset, exp_val)
+static inline size_t exp_io_words(int kind) {
+  switch (kind) {
+    case SBN_AIR_G1_EXP: return 40; case SBN_AIR_G2_EXP: return 72; case SBN_AIR_FQ12_EXP: return 200; case SBN_AIR_FQ_EXP: return 24;
+    case SBN_AIR_FQ12_EXP_U64: return 194; default: return 0;
+  }
+}
 static inline ExpShape exp_shape(const AirShape& a) { return ExpShape(exp_e(a.kind), (int)a.num_io); }
 static inline bool config_supported(const sbn_config* c) {
   return c && c->num_challenges == SBN_NCH && c->rate_bits == 1 && c->cap_height >= 1 && c->cap_height <= 8 &&
          c->fri_arity_bits >= 1 && c->fri_arity_bits <= 4 && c->num_query_rounds >= 1 && c->num_query_rounds <= 512 &&
-         c->proof_of_work_bits <= 32;
+         c->proof_of_work_bits <= 32 && c->fri_final_poly_times_x <= 1;
 }
 
 // tracegen.hip: Jacobian curve chains of every G1ExpStark instance on host threads (layout: bn254w.cuh g1_chains)

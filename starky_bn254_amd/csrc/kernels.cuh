@@ -576,18 +576,24 @@ __global__ __launch_bounds__(256) void permutation_z_kernel(const u64* __restric
 // "next" access re-hits the same lines.  Output: quotient values acc_j / Z_H(x_i) for j < 2.
 // Algorithmic bytes: 8*M*(C + Zc) read once, 16*M written.
 // =================================================================================================
+// `base` holds the local rows, `nbase` the next rows (the same matrix on one GPU; in the oversized-trace split a rank
+// holds the LDE rows i = j * R + rho of its Merkle subtrees and, from R = 4 ranks up, a second plane with the rows i + 2).
 struct DevRow {
-  const u64* base; size_t m; size_t i, inext;
+  const u64* base; const u64* nbase; size_t m; size_t i, inext;
   __device__ __forceinline__ F l(int c) const { return F(base[(size_t)c * m + i]); }
-  __device__ __forceinline__ F n(int c) const { return F(base[(size_t)c * m + inext]); }
+  __device__ __forceinline__ F n(int c) const { return F(nbase[(size_t)c * m + inext]); }
 };
 struct DevZRow {
-  const u64* base; size_t m; size_t i, inext;
+  const u64* base; const u64* nbase; size_t m; size_t i, inext;
   __device__ __forceinline__ F zl(int z) const { return F(base[(size_t)z * m + i]); }
-  __device__ __forceinline__ F zn(int z) const { return F(base[(size_t)z * m + inext]); }
+  __device__ __forceinline__ F zn(int z) const { return F(nbase[(size_t)z * m + inext]); }
 };
 struct QuotientParams {
   const u64* lde; const u64* zlde; size_t m; u32 next_step;
+  // Row sharding (all zero / equal to lde, zlde on one GPU): m = LOCAL point count, local point j is LDE point
+  // (j << row_shift) | row_rho (tables xs / lag_* / zh_inv are indexed by the LDE point), its next row is local row
+  // (j + next_step) mod m of lde_next / zlde_next.
+  const u64* lde_next; const u64* zlde_next; u32 row_shift, row_rho;
   const u64* xs; const u64* lag_first; const u64* lag_last;  // per LDE point
   u64 zh_inv[2];   // 1/Z_H on the two residues of i mod 2
   u64 last;        // g^-1
@@ -615,14 +621,15 @@ __global__ __launch_bounds__(256) void quotient_kernel(QuotientParams p) {
   if (i >= p.m) return;
   const u32 seg = blockIdx.y;
   size_t inext = (i + p.next_step) & (p.m - 1);
+  const size_t ig = (i << p.row_shift) | p.row_rho;   // LDE point of local row i
   Cons<F> cs;
 #pragma unroll
   for (int j = 0; j < SBN_NCH; j++) { cs.alpha[j] = F(p.alpha[j]); cs.acc[j] = F(0); cs.apow[j] = (const F*)p.apow[j]; }
-  cs.z_last = F(p.xs[i]) - F(p.last);
-  cs.l_first = F(p.lag_first[i]);
-  cs.l_last = F(p.lag_last[i]);
-  DevRow row{p.lde, p.m, i, inext};
-  DevZRow zrow{p.zlde, p.m, i, inext};
+  cs.z_last = F(p.xs[ig]) - F(p.last);
+  cs.l_first = F(p.lag_first[ig]);
+  cs.l_last = F(p.lag_last[ig]);
+  DevRow row{p.lde, p.lde_next, p.m, i, inext};
+  DevZRow zrow{p.zlde, p.zlde_next, p.m, i, inext};
   if (KIND == 1) {
     if (seg == 0) g1op_eval(cs, row);
     else if (seg == 2) permutation_checks(cs, row, zrow, G1OpShape(), p.num_zs, F(p.gamma0), F(p.gamma1), true, 0, p.zsplit);
@@ -640,7 +647,7 @@ __global__ __launch_bounds__(256) void quotient_kernel(QuotientParams p) {
 __global__ __launch_bounds__(256) void quotient_combine_kernel(QuotientParams p) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= p.m) return;
-  F dinv(p.zh_inv[i & 1]);
+  F dinv(p.zh_inv[((i << p.row_shift) | p.row_rho) & 1]);
 #pragma unroll
   for (int j = 0; j < SBN_NCH; j++) {
     F acc(p.part[((size_t)(QSEG - 1) * SBN_NCH + j) * p.m + i]);   // nothing follows the last segment
@@ -857,18 +864,23 @@ __global__ __launch_bounds__(256) void divide_by_linear_pass2(u64* __restrict__ 
 }
 __global__ __launch_bounds__(256) void divide_by_linear_pass3(const u64* __restrict__ ca, const u64* __restrict__ cb, size_t nchunks, u64 z0, u64 z1,
                                                               const u64* __restrict__ ha, const u64* __restrict__ hb, u64 mul0, u64 mul1,
-                                                              u64* __restrict__ oa, u64* __restrict__ ob, int accumulate) {
+                                                              u64* __restrict__ oa, u64* __restrict__ ob, int accumulate, u32 times_x) {
+  // times_x = 1: quotient coefficient q_i lands at index i + 1 (plonky2 0.1.x multiplies the final polynomial by X:
+  // `final_poly.coeffs.insert(0, ZERO)` on the n-1 coefficient quotients); q_{n-1} = 0 is the padding and is dropped,
+  // index 0 keeps the zero of the caller's memset.
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= nchunks) return;
   const E2 z{F(z0), F(z1)}, mul{F(mul0), F(mul1)};
-  const size_t s = t * DBL_CHUNK;
+  const size_t s = t * DBL_CHUNK, n = nchunks * DBL_CHUNK;
   E2 b{F(ha[t]), F(hb[t])};
   for (u32 k = DBL_CHUNK; k-- > 0;) {
     const size_t i = s + k;
     const E2 q = b;  // q_i = B_{i+1}: the value of b BEFORE absorbing c_i
     b = b * z + E2(F(ca[i]), F(cb[i]));
-    const E2 o = accumulate ? E2(F(oa[i]), F(ob[i])) * mul + q : q;
-    oa[i] = o.a.v; ob[i] = o.b.v;
+    const size_t j = i + times_x;
+    if (j >= n) continue;
+    const E2 o = accumulate ? E2(F(oa[j]), F(ob[j])) * mul + q : q;
+    oa[j] = o.a.v; ob[j] = o.b.v;
   }
 }
 
@@ -899,6 +911,44 @@ __global__ __launch_bounds__(256) void pow_kernel(PowParams p) {
 
 // K10 query gathers, written straight in the proof's word layout.
 // rows: out[q*qstride + off + c] = mat[c*m + bitrev(idx[q])]
+// ---- oversized-trace split (BASELINE config[4]: one trace over R GPUs) ---------------------------------------------
+// Rank s owns the LDE rows whose Merkle leaf index bitrev(i) has top log R bits = s, i.e. i = j * R + rho(s) with
+// rho = bit reversal on log R bits: complete cap subtrees, so hashing needs no exchange.  split_pack_kernel scatters a
+// column chunk of a rank's LDE block [nc][m] into the all-to-all send buffer: plane L [dest][ncols_own][m/R] (row i
+// goes to its owner at local row i >> log R) and, from 4 ranks up, plane N (row i is the NEXT row of point i - 2, whose
+// owner gets it at the local row of that point); with 2 ranks the next row of local row j is local row j + 1.
+__global__ __launch_bounds__(256) void split_pack_kernel(const u64* __restrict__ lde, size_t m, u32 nc, u32 c0, u32 ncols_own, u32 log_r,
+                                                         u64* __restrict__ send_l, u64* __restrict__ send_n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const u32 c = blockIdx.y;
+  if (i >= m || c >= nc) return;
+  const u64 v = lde[(size_t)c * m + i];
+  const size_t ml = m >> log_r, rmask = ((size_t)1 << log_r) - 1;
+  const u32 s = bitrev32((u32)(i & rmask), log_r);
+  send_l[((size_t)s * ncols_own + c0 + c) * ml + (i >> log_r)] = v;
+  if (send_n) {
+    const size_t p = (i + m - 2) & (m - 1);   // the point whose next row this is
+    const u32 s2 = bitrev32((u32)(p & rmask), log_r);
+    send_n[((size_t)s2 * ncols_own + c0 + c) * ml + (p >> log_r)] = v;
+  }
+}
+// gathered [rank][nplanes][m/R] -> natural order [nplanes][m]
+__global__ void split_unpack_rows_kernel(const u64* __restrict__ in, size_t m, u32 nplanes, u32 log_r, u64* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const size_t ml = m >> log_r;
+  const u32 s = bitrev32((u32)(i & (((size_t)1 << log_r) - 1)), log_r);
+  for (u32 p = 0; p < nplanes; p++) out[(size_t)p * m + i] = in[((size_t)s * nplanes + p) * ml + (i >> log_r)];
+}
+// out[k] = sum over ranks of in[rank][k] (mod p): the FRI batch-combine partial sums (RCCL has no mod-p reduction)
+__global__ void split_modadd_kernel(const u64* __restrict__ in, size_t len, u32 nranks, u64* __restrict__ out) {
+  const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= len) return;
+  F acc(in[k]);
+  for (u32 r = 1; r < nranks; r++) acc += F(in[(size_t)r * len + k]);
+  out[k] = acc.v;
+}
+
 __global__ void gather_rows_kernel(const u64* mat, size_t m, u32 lde_log, u32 ncols, const u32* idx, u64* out, size_t qstride, size_t off) {
   u32 c = blockIdx.x * blockDim.x + threadIdx.x;
   u32 q = blockIdx.y;

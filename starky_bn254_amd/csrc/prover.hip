@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <thread>
 #include <atomic>
+#include <chrono>
 
 using namespace sbn;
 
@@ -30,11 +31,12 @@ enum Stage {
   ST_TRACE_COMMIT, ST_PERM_Z, ST_Z_COMMIT, ST_QUOTIENT_EVAL, ST_QUOTIENT_COMMIT,
   ST_OPENINGS, ST_FRI_COMBINE, ST_FRI_LAYERS, ST_POW, ST_QUERIES, ST_COUNT
 };
-enum Extra { EX_TRACE_ABSORB_MS, EX_TRACE_ABSORB_LAUNCHES, EX_Z_ABSORB_MS, EX_Z_ABSORB_LAUNCHES, EX_TRACEGEN_MS, EX_COUNT };
+enum Extra { EX_TRACE_ABSORB_MS, EX_TRACE_ABSORB_LAUNCHES, EX_Z_ABSORB_MS, EX_Z_ABSORB_LAUNCHES, EX_TRACEGEN_MS, EX_COMM_MS, EX_COUNT };
 static const char* STAGE_NAMES[ST_COUNT + EX_COUNT] = {
   "trace_commit", "perm_z", "z_commit", "quotient_eval", "quotient_commit",
   "openings", "fri_combine", "fri_layers", "pow", "queries",
-  "trace_absorb_kernels_ms", "trace_absorb_launches", "z_absorb_kernels_ms", "z_absorb_launches", "device_tracegen_ms"};
+  "trace_absorb_kernels_ms", "trace_absorb_launches", "z_absorb_kernels_ms", "z_absorb_launches", "device_tracegen_ms",
+  "split_exchange_ms"};
 static constexpr int MAX_CHUNKS = 256;
 
 struct DevTree {  // Merkle digests, levels concatenated (leaf level first)
@@ -42,8 +44,30 @@ struct DevTree {  // Merkle digests, levels concatenated (leaf level first)
   u64* level(u32 l) const { return d + (2 * nleaf - ((2 * nleaf) >> l)) * 4; }
 };
 
+// Oversized-trace split (include/sbn.h, sbn_split_prover_*): this rank's share of one proof.
+struct SplitCtx {
+  sbn_comm comm;
+  u32 log_r = 0, rho = 0;                 // world = 2^log_r; this rank owns the LDE rows i = j * world + rho
+  size_t ml = 0;                          // local LDE rows = m >> log_r
+  std::vector<size_t> ccnt, coff, zcnt, zoff;   // trace / Z columns per rank (contiguous ranges)
+  size_t c0 = 0, cr = 0, z0 = 0, zr = 0, cmax = 0, zmax = 0;   // this rank's ranges, largest shares
+  u32 planes = 1;                         // 2 from four ranks up: the rows i + 2 of the local rows arrive as a second plane
+  u64 *lde_l = nullptr, *lde_n = nullptr, *zlde_l = nullptr, *zlde_n = nullptr, *scratch = nullptr;   // views of comm.recv_buf
+  size_t scratch_words = 0;
+  u64* d_ldechunk = nullptr;              // [ntt_chunk][m]: one column chunk of this rank's LDE before it is packed
+  u32* d_idx_local = nullptr;             // query leaf indices inside this rank's subtrees
+  double comm_s = 0;
+};
+static void split_partition(size_t total, u32 world, std::vector<size_t>& cnt, std::vector<size_t>& off) {
+  cnt.resize(world); off.resize(world);
+  size_t o = 0;
+  for (u32 r = 0; r < world; r++) { cnt[r] = total / world + (r < total % world ? 1 : 0); off[r] = o; o += cnt[r]; }
+}
+
 struct sbn_prover {
   AirShape air; sbn_config cfg; FriShape fri;
+  SplitCtx* sp = nullptr;                 // null: the whole proof on this GPU
+  size_t lde_scratch_words = 0;           // capacity of d_lde as witness-generation scratch
   u32 degree_bits, lde_log; size_t n, m;
   int device; hipStream_t stream;
   // matrices
@@ -143,9 +167,12 @@ static int ntt_columns(sbn_prover* P, const u64* in, size_t in_cs, u64* out, siz
 
 static u64 host_inv_pow2(u32 k) { return f_inv(F((u64)1 << k)).v; }
 // the R = 512 fast pass needs 69,632 bytes of dynamic LDS (> the 64 KiB default)
+// Function attributes are per DEVICE: one flag per device of the process (sbn_set_device may select another GPU later).
+static constexpr int SBN_MAX_DEVICES = 64;
 static int ntt_fast_setup() {  // idempotent, so a race between prover threads is harmless; the flag only saves the call
-  static std::atomic<bool> done(false);
-  if (!done.load()) { HIPC(hipFuncSetAttribute((const void*)ntt_fast_pass_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 32 * 272 * 8)); done.store(true); }
+  static std::atomic<bool> done[SBN_MAX_DEVICES];
+  const int d = g_device >= 0 && g_device < SBN_MAX_DEVICES ? g_device : 0;
+  if (!done[d].load()) { HIPC(hipFuncSetAttribute((const void*)ntt_fast_pass_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 32 * 272 * 8)); done[d].store(true); }
   return 0;
 }
 
@@ -253,6 +280,87 @@ static int commit_pipeline(sbn_prover* P, const u64* vals, u64* coef, u64* lde, 
 // Host waits inside prove().  Polling hipStreamQuery / hipEventQuery instead was measured: no gain over the runtime's waits.
 static inline hipError_t stream_wait(hipStream_t st) { return hipStreamSynchronize(st); }
 static inline hipError_t event_wait(hipEvent_t ev) { return hipEventSynchronize(ev); }
+// ---- oversized-trace split: exchange helpers ------------------------------------------------------------------------
+static int split_all_to_all(sbn_prover* P, const std::vector<uint64_t>& so, const std::vector<uint64_t>& sl, const std::vector<uint64_t>& ro,
+                            const std::vector<uint64_t>& rl) {
+  SplitCtx* S = P->sp;
+  HIPC(hipStreamSynchronize(P->stream));   // the collective runs on the caller's stream: everything packed so far must be done
+  auto t0 = std::chrono::steady_clock::now();
+  const int rc = S->comm.all_to_all(S->comm.ctx, so.data(), sl.data(), ro.data(), rl.data());
+  S->comm_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  if (rc) return fail(SBN_ERR_HIP, "sbn_comm.all_to_all failed (%d)", rc);
+  return 0;
+}
+static int split_all_gather_host(sbn_prover* P, const void* send, void* recv, size_t bytes) {
+  SplitCtx* S = P->sp;
+  auto t0 = std::chrono::steady_clock::now();
+  const int rc = S->comm.all_gather_host(S->comm.ctx, send, recv, bytes);
+  S->comm_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  if (rc) return fail(SBN_ERR_HIP, "sbn_comm.all_gather_host failed (%d)", rc);
+  return 0;
+}
+// every rank contributes `words` u64 at the start of the send buffer; the result [world][words] lands in the receive scratch
+static int split_all_gather_device(sbn_prover* P, size_t words) {
+  SplitCtx* S = P->sp;
+  const u32 R = S->comm.world;
+  if (words * R > S->scratch_words || words * sizeof(u64) > S->comm.send_bytes) return fail(SBN_ERR_HIP, "internal: split scratch too small");
+  const uint64_t base = (uint64_t)((const char*)S->scratch - (const char*)S->comm.recv_buf);
+  std::vector<uint64_t> so(R, 0), sl(R, words * sizeof(u64)), ro(R), rl(R, words * sizeof(u64));
+  for (u32 r = 0; r < R; r++) ro[r] = base + (uint64_t)r * words * sizeof(u64);
+  return split_all_to_all(P, so, sl, ro, rl);
+}
+// PolynomialBatch::from_values for this rank's share: iNTT + coset LDE of its own columns (coefficients stay here),
+// one all-to-all columns -> rows per plane, then sponge + Merkle subtrees over its LDE rows.
+static int commit_split(sbn_prover* P, const u64* vals_own, u64* coef_own, size_t ncols_own, size_t ncols_max, const std::vector<size_t>& cnt,
+                        const std::vector<size_t>& off, size_t total, u64* plane_l, u64* plane_n, DevTree& t) {
+  SplitCtx* S = P->sp;
+  const u32 R = S->comm.world;
+  const size_t m = P->m, ml = S->ml, ch = P->ntt_chunk;
+  u64* send_l = (u64*)S->comm.send_buf;
+  u64* send_n = S->planes == 2 ? send_l + ncols_own * m : nullptr;   // per plane: [dest][ncols_own][ml] = ncols_own * m words
+  (void)ncols_max;
+  for (size_t c0 = 0; c0 < ncols_own; c0 += ch) {
+    const size_t nc = std::min(ch, ncols_own - c0);
+    int rc = ntt_columns(P, vals_own + c0 * P->n, P->n, coef_own + c0 * P->n, P->n, P->d_tmp, m, nc, P->degree_bits, true, P->n, nullptr, nullptr,
+                         host_inv_pow2(P->degree_bits));
+    if (rc) return rc;
+    rc = ntt_columns(P, coef_own + c0 * P->n, P->n, S->d_ldechunk, m, P->d_tmp, m, nc, P->lde_log, false, P->n, P->d_shift, nullptr, 1);
+    if (rc) return rc;
+    hipLaunchKernelGGL(split_pack_kernel, dim3((unsigned)((m + 255) / 256), (unsigned)nc), dim3(256), 0, P->stream, S->d_ldechunk, m, (u32)nc, (u32)c0,
+                       (u32)ncols_own, S->log_r, send_l, send_n);
+  }
+  HIPC(hipGetLastError());
+  for (u32 pl = 0; pl < S->planes; pl++) {
+    const u64* dst = pl ? plane_n : plane_l;
+    std::vector<uint64_t> so(R), sl(R), ro(R), rl(R);
+    for (u32 r = 0; r < R; r++) {
+      so[r] = (uint64_t)(((size_t)pl * ncols_own * m + (size_t)r * ncols_own * ml) * sizeof(u64));
+      sl[r] = (uint64_t)(ncols_own * ml * sizeof(u64));
+      ro[r] = (uint64_t)((const char*)(dst + off[r] * ml) - (const char*)S->comm.recv_buf);
+      rl[r] = (uint64_t)(cnt[r] * ml * sizeof(u64));
+    }
+    int rc = split_all_to_all(P, so, sl, ro, rl);
+    if (rc) return rc;
+  }
+  const size_t nchunks = (total + ch - 1) / ch;
+  for (size_t k = 0; k < nchunks; k++) {
+    const size_t c0 = k * ch, nc = std::min(ch, total - c0);
+    hipLaunchKernelGGL(leaf_absorb_kernel, dim3((unsigned)((ml + 255) / 256)), dim3(256), 0, P->stream, plane_l + c0 * ml, ml, P->lde_log - S->log_r, (u32)nc,
+                       P->d_sponge, k == 0 ? 1 : 0, k + 1 == nchunks ? 1 : 0, t.d);
+  }
+  HIPC(hipGetLastError());
+  return tree_build_inner(P, t, P->stream);
+}
+// the Merkle cap: this rank's 2^(cap_height - log R) subtree roots, all-gathered in rank order = cap order
+static int split_cap_to_host(sbn_prover* P, const DevTree& t, std::vector<u64>& cap) {
+  SplitCtx* S = P->sp;
+  const size_t capn = (size_t)1 << P->cfg.cap_height, own = capn >> S->log_r;
+  std::vector<u64> mine(own * 4);
+  HIPC(hipMemcpyAsync(mine.data(), t.level(t.nlevels), own * 4 * sizeof(u64), hipMemcpyDeviceToHost, P->stream));
+  HIPC(hipStreamSynchronize(P->stream));
+  cap.resize(capn * 4);
+  return split_all_gather_host(P, mine.data(), cap.data(), own * 4 * sizeof(u64));
+}
 static int absorb_times(sbn_prover* P, size_t ncols, int ex_ms) {
   size_t nchunks = (ncols + P->ntt_chunk - 1) / P->ntt_chunk;
   float tot = 0;
@@ -269,7 +377,22 @@ static int tree_cap_to_host(sbn_prover* P, const DevTree& t, std::vector<u64>& c
 }
 
 // ---- create / destroy -----------------------------------------------------------------------------
+static int split_sizes(const AirShape& as, u32 degree_bits, u32 rate_bits, u32 world, size_t chunk, uint64_t* send_bytes, uint64_t* recv_bytes, size_t* scratch_words) {
+  const size_t n = (size_t)1 << degree_bits, m = n << rate_bits;
+  const u32 planes = world >= 4 ? 2 : 1;
+  const size_t cmax = (as.ncols + world - 1) / world, zmax = (as.nzs + world - 1) / world;
+  const size_t sw = std::max<size_t>(2 * m, 2 * n * world);   // gathered quotient values / FRI partial sums
+  (void)chunk;
+  *send_bytes = (uint64_t)(std::max(std::max(cmax, zmax) * m * planes, 2 * n) * sizeof(u64));
+  *recv_bytes = (uint64_t)(((as.ncols + as.nzs) * (m / world) * planes + sw) * sizeof(u64));
+  *scratch_words = sw;
+  return 0;
+}
+static int create_ctx(const sbn_air_desc* air, const sbn_config* cfg, uint32_t degree_bits, const sbn_comm* comm, sbn_prover** out);
 extern "C" int sbn_prover_create(const sbn_air_desc* air, const sbn_config* cfg, uint32_t degree_bits, sbn_prover** out) {
+  return create_ctx(air, cfg, degree_bits, nullptr, out);
+}
+static int create_ctx(const sbn_air_desc* air, const sbn_config* cfg, uint32_t degree_bits, const sbn_comm* comm, sbn_prover** out) {
   if (!air || !cfg || !out) return fail(SBN_ERR_BAD_ARG, "null argument");
   *out = nullptr;
   if (!config_supported(cfg)) return fail(SBN_ERR_UNSUPPORTED, "unsupported StarkConfig (need num_challenges=2, rate_bits=1)");
@@ -289,46 +412,89 @@ extern "C" int sbn_prover_create(const sbn_air_desc* air, const sbn_config* cfg,
   P->n = (size_t)1 << degree_bits; P->m = (size_t)1 << P->lde_log;
   P->fri = fri_shape(*cfg, degree_bits);
   P->device = g_device;
-  if (P->fri.total_arity() > degree_bits + cfg->rate_bits - cfg->cap_height) { delete P; return fail(SBN_ERR_UNSUPPORTED, "FRI total reduction arity is too large"); }
-  const char* ce = getenv("SBN_NTT_CHUNK");
-  P->ntt_chunk = ce ? (size_t)atol(ce) : 64;
-  if (P->ntt_chunk == 0) P->ntt_chunk = 64;
-  { const char* fe = getenv("SBN_FAST_NTT"); P->fast_ntt = !(fe && fe[0] == '0'); }
-  { int rc0 = ntt_fast_setup(); if (rc0) { delete P; return rc0; } }
-  HIPC(hipStreamCreate(&P->stream));
-  HIPC(hipStreamCreate(&P->hstream));
-  for (auto& e : P->ev) HIPC(hipEventCreate(&e));
-  for (auto& e : P->abs_ev) HIPC(hipEventCreate(&e));
-  for (auto& e : P->chunk_ready) HIPC(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  HIPC(hipEventCreateWithFlags(&P->hash_done, hipEventDisableTiming));
-  for (auto& v : P->stage_ms) v = 0;
-  const size_t n = P->n, m = P->m, C = as.ncols, Z = as.nzs;
+  // every failure below releases what was created so far (sbn_prover_destroy accepts a partly built context) and
+  // returns the FIRST error code
   int rc = 0;
-  rc |= dmalloc(&P->d_trace, C * n); rc |= dmalloc(&P->d_coef, C * n); rc |= dmalloc(&P->d_lde, C * m);
-  rc |= dmalloc(&P->d_tmp, std::max(P->ntt_chunk, (size_t)4) * m);
-  rc |= dmalloc(&P->d_zval, Z * n); rc |= dmalloc(&P->d_zcoef, Z * n); rc |= dmalloc(&P->d_zlde, Z * m);
-  rc |= dmalloc(&P->d_q, 2 * m); rc |= dmalloc(&P->d_qlde, 4 * m);
-  rc |= tree_alloc(P->tree_t, m, cfg->cap_height); rc |= tree_alloc(P->tree_z, m, cfg->cap_height); rc |= tree_alloc(P->tree_q, m, cfg->cap_height);
-  rc |= dmalloc(&P->d_tw_f, m / 2); rc |= dmalloc(&P->d_tw_i, m / 2); rc |= dmalloc(&P->d_shift, m); rc |= dmalloc(&P->d_shift_inv, m);
-  rc |= dmalloc(&P->d_xs, m); rc |= dmalloc(&P->d_lag_first, m); rc |= dmalloc(&P->d_lag_last, m);
+  auto acc = [&](int r) { if (!rc) rc = r; };
+  auto hipc = [&](hipError_t e, const char* what) { if (e != hipSuccess && !rc) rc = fail(SBN_ERR_HIP, "%s failed: %s", what, hipGetErrorString(e)); };
+  if (P->fri.total_arity() > degree_bits + cfg->rate_bits - cfg->cap_height) { sbn_prover_destroy(P); return fail(SBN_ERR_UNSUPPORTED, "FRI total reduction arity is too large"); }
+  // Column chunk of the commit pipeline: a multiple of 8 (the sponge permutes after every 8 absorbed columns, so any other
+  // chunk boundary would change the leaf digests), between 8 and 256.
+  P->ntt_chunk = 64;
+  if (const char* ce = getenv("SBN_NTT_CHUNK")) {
+    const long v = atol(ce);
+    if (v < 8 || v > 256 || (v % 8) != 0) { sbn_prover_destroy(P); return fail(SBN_ERR_BAD_ARG, "SBN_NTT_CHUNK must be a multiple of 8 between 8 and 256"); }
+    P->ntt_chunk = (size_t)v;
+  }
+  { const char* fe = getenv("SBN_FAST_NTT"); P->fast_ntt = !(fe && fe[0] == '0'); }
+  acc(ntt_fast_setup());
+  hipc(hipStreamCreate(&P->stream), "hipStreamCreate");
+  hipc(hipStreamCreate(&P->hstream), "hipStreamCreate");
+  for (auto& e : P->ev) hipc(hipEventCreate(&e), "hipEventCreate");
+  for (auto& e : P->abs_ev) hipc(hipEventCreate(&e), "hipEventCreate");
+  for (auto& e : P->chunk_ready) hipc(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
+  hipc(hipEventCreateWithFlags(&P->hash_done, hipEventDisableTiming), "hipEventCreate");
+  for (auto& v : P->stage_ms) v = 0;
+  if (rc) { sbn_prover_destroy(P); return rc; }
+  const size_t n = P->n, m = P->m, C = as.ncols, Z = as.nzs;
+  if (comm) {
+    // one trace over comm->world GPUs: this rank keeps the coefficients of its own columns and the LDE ROWS of its Merkle
+    // subtrees (views of the caller's receive buffer); the trace values stay whole
+    const u32 R = comm->world;
+    u32 lr = 0; while ((1u << lr) < R) lr++;
+    uint64_t sb = 0, rb = 0; size_t sw = 0;
+    split_sizes(as, degree_bits, cfg->rate_bits, R, P->ntt_chunk, &sb, &rb, &sw);
+    if ((1u << lr) != R || lr > cfg->cap_height || comm->rank >= R || !comm->all_to_all || !comm->all_gather_host || !comm->send_buf || !comm->recv_buf ||
+        comm->send_bytes < sb || comm->recv_bytes < rb) {
+      sbn_prover_destroy(P);
+      return fail(SBN_ERR_BAD_ARG, "bad sbn_comm (world must be a power of two <= 2^cap_height; staging buffers of sbn_split_exchange_bytes)");
+    }
+    SplitCtx* S = P->sp = new SplitCtx();
+    S->comm = *comm; S->log_r = lr; S->rho = bitrev32(comm->rank, lr); S->ml = m >> lr; S->planes = R >= 4 ? 2 : 1;
+    split_partition(C, R, S->ccnt, S->coff); split_partition(Z, R, S->zcnt, S->zoff);
+    S->c0 = S->coff[comm->rank]; S->cr = S->ccnt[comm->rank]; S->z0 = S->zoff[comm->rank]; S->zr = S->zcnt[comm->rank];
+    S->cmax = S->ccnt[0]; S->zmax = S->zcnt[0];
+    u64* rbuf = (u64*)comm->recv_buf;
+    S->lde_l = rbuf; rbuf += C * S->ml;
+    if (S->planes == 2) { S->lde_n = rbuf; rbuf += C * S->ml; }
+    S->zlde_l = rbuf; rbuf += Z * S->ml;
+    if (S->planes == 2) { S->zlde_n = rbuf; rbuf += Z * S->ml; }
+    S->scratch = rbuf; S->scratch_words = sw;
+    P->lde_scratch_words = (size_t)(rb / sizeof(u64));   // witness generation runs before the first exchange
+    acc(dmalloc(&P->d_trace, C * n)); acc(dmalloc(&P->d_coef, std::max<size_t>(S->cr, 1) * n));
+    acc(dmalloc(&P->d_zval, std::max<size_t>(S->zr, 1) * n)); acc(dmalloc(&P->d_zcoef, std::max<size_t>(S->zr, 1) * n));
+    acc(dmalloc(&S->d_ldechunk, P->ntt_chunk * m));
+    hipc(hipMalloc((void**)&S->d_idx_local, cfg->num_query_rounds * sizeof(u32)), "hipMalloc");
+    acc(tree_alloc(P->tree_t, S->ml, cfg->cap_height - lr)); acc(tree_alloc(P->tree_z, S->ml, cfg->cap_height - lr));
+  } else {
+    P->lde_scratch_words = C * m;
+    acc(dmalloc(&P->d_trace, C * n)); acc(dmalloc(&P->d_coef, C * n)); acc(dmalloc(&P->d_lde, C * m));
+    acc(dmalloc(&P->d_zval, Z * n)); acc(dmalloc(&P->d_zcoef, Z * n)); acc(dmalloc(&P->d_zlde, Z * m));
+    acc(tree_alloc(P->tree_t, m, cfg->cap_height)); acc(tree_alloc(P->tree_z, m, cfg->cap_height));
+  }
+  acc(dmalloc(&P->d_tmp, std::max(P->ntt_chunk, (size_t)4) * m));
+  acc(dmalloc(&P->d_q, 2 * m)); acc(dmalloc(&P->d_qlde, 4 * m));
+  acc(tree_alloc(P->tree_q, m, cfg->cap_height));
+  acc(dmalloc(&P->d_tw_f, m / 2)); acc(dmalloc(&P->d_tw_i, m / 2)); acc(dmalloc(&P->d_shift, m)); acc(dmalloc(&P->d_shift_inv, m));
+  acc(dmalloc(&P->d_xs, m)); acc(dmalloc(&P->d_lag_first, m)); acc(dmalloc(&P->d_lag_last, m));
   P->apow_n = apow_len(as.npi, as.nzs);
-  rc |= dmalloc(&P->d_apow, (size_t)SBN_NCH * P->apow_n);
-  rc |= dmalloc(&P->d_zpow, 4 * n); rc |= dmalloc(&P->d_open, (C + Z + 4) * 4);
-  if (hipHostMalloc((void**)&P->h_open, (C + Z + 4) * 4 * sizeof(u64), hipHostMallocDefault) != hipSuccess) rc |= 1;
-  if (hipHostMalloc((void**)&P->h_open2, C * 4 * sizeof(u64), hipHostMallocDefault) != hipSuccess) rc |= 1;
-  rc |= dmalloc(&P->d_part, 2 * 32 * n); rc |= dmalloc(&P->d_w, 4096); rc |= dmalloc(&P->d_sponge, 12 * m);
-  rc |= dmalloc(&P->d_fa, 4 * n); rc |= dmalloc(&P->d_fcoef, 2 * m); rc |= dmalloc(&P->d_fcoef2, 2 * m);
-  rc |= dmalloc(&P->d_pow, 1);
+  acc(dmalloc(&P->d_apow, (size_t)SBN_NCH * P->apow_n));
+  acc(dmalloc(&P->d_zpow, 4 * n)); acc(dmalloc(&P->d_open, (C + Z + 4) * 4));
+  hipc(hipHostMalloc((void**)&P->h_open, (C + Z + 4) * 4 * sizeof(u64), hipHostMallocDefault), "hipHostMalloc");
+  hipc(hipHostMalloc((void**)&P->h_open2, C * 4 * sizeof(u64), hipHostMallocDefault), "hipHostMalloc");
+  acc(dmalloc(&P->d_part, 2 * 32 * n)); acc(dmalloc(&P->d_w, 4096)); acc(dmalloc(&P->d_sponge, 12 * m));
+  acc(dmalloc(&P->d_fa, 4 * n)); acc(dmalloc(&P->d_fcoef, 2 * m)); acc(dmalloc(&P->d_fcoef2, 2 * m));
+  acc(dmalloc(&P->d_pow, 1));
   if (rc) { sbn_prover_destroy(P); return rc; }
   P->d_fb = P->d_fa + 2 * n;
-  HIPC(hipMalloc((void**)&P->d_pic, sizeof(ExpPiConsts<F>)));
-  HIPC(hipMalloc((void**)&P->d_idx, cfg->num_query_rounds * sizeof(u32)));
+  hipc(hipMalloc((void**)&P->d_pic, sizeof(ExpPiConsts<F>)), "hipMalloc");
+  hipc(hipMalloc((void**)&P->d_idx, cfg->num_query_rounds * sizeof(u32)), "hipMalloc");
   // FRI layer buffers
   {
     u32 bits = P->lde_log;
     for (u32 ab : P->fri.arity_bits) {
-      u64* v = nullptr; rc |= dmalloc(&v, 2 * ((size_t)1 << bits)); P->fri_vals.push_back(v);
-      DevTree t; rc |= tree_alloc(t, (size_t)1 << (bits - ab), cfg->cap_height); P->fri_trees.push_back(t);
+      u64* v = nullptr; acc(dmalloc(&v, 2 * ((size_t)1 << bits))); P->fri_vals.push_back(v);
+      DevTree t; acc(tree_alloc(t, (size_t)1 << (bits - ab), cfg->cap_height)); P->fri_trees.push_back(t);
       bits -= ab;
     }
     if (rc) { sbn_prover_destroy(P); return rc; }
@@ -340,7 +506,7 @@ extern "C" int sbn_prover_create(const sbn_air_desc* air, const sbn_config* cfg,
     u32 bits = P->lde_log;
     for (u32 ab : P->fri.arity_bits) { bits -= ab; s += 2 * ((size_t)1 << ab) + (size_t)(bits - cfg->cap_height) * 4; }
     P->qstride = s;
-    rc |= dmalloc(&P->d_qbuf, s * cfg->num_query_rounds);
+    acc(dmalloc(&P->d_qbuf, s * cfg->num_query_rounds));
     if (rc) { sbn_prover_destroy(P); return rc; }
   }
   // tables
@@ -359,11 +525,12 @@ extern "C" int sbn_prover_create(const sbn_air_desc* air, const sbn_config* cfg,
       if (as.kind == SBN_AIR_G1_OP) G1OpShape::pair((int)z, l, r); else exp_shape(as).pair((int)z, l, r);
       pairs[z].lhs = l; pairs[z].rhs = r;
     }
-    HIPC(hipMalloc((void**)&P->d_pairs, Z * sizeof(PairCols)));
-    HIPC(hipMemcpy(P->d_pairs, pairs.data(), Z * sizeof(PairCols), hipMemcpyHostToDevice));
+    hipc(hipMalloc((void**)&P->d_pairs, Z * sizeof(PairCols)), "hipMalloc");
+    if (!rc) hipc(hipMemcpy(P->d_pairs, pairs.data(), Z * sizeof(PairCols), hipMemcpyHostToDevice), "hipMemcpy");
   }
-  HIPC(hipStreamSynchronize(P->stream));
-  HIPC(hipGetLastError());
+  hipc(hipStreamSynchronize(P->stream), "hipStreamSynchronize");
+  hipc(hipGetLastError(), "table kernels");
+  if (rc) { sbn_prover_destroy(P); return rc; }
   *out = P;
   return SBN_OK;
 }
@@ -377,19 +544,24 @@ extern "C" void sbn_prover_destroy(sbn_prover* P) {
   for (u64* b : bufs) if (b) (void)hipFree(b);
   for (u64* b : P->fri_vals) if (b) (void)hipFree(b);
   for (auto& t : P->fri_trees) if (t.d) (void)hipFree(t.d);
+  if (P->sp) {
+    if (P->sp->d_ldechunk) (void)hipFree(P->sp->d_ldechunk);
+    if (P->sp->d_idx_local) (void)hipFree(P->sp->d_idx_local);
+    delete P->sp;
+  }
   if (P->d_pic) (void)hipFree(P->d_pic);
   if (P->d_idx) (void)hipFree(P->d_idx);
   if (P->d_pairs) (void)hipFree(P->d_pairs);
-  for (auto& e : P->ev) (void)hipEventDestroy(e);
-  for (auto& e : P->abs_ev) (void)hipEventDestroy(e);
-  for (auto& e : P->chunk_ready) (void)hipEventDestroy(e);
-  (void)hipEventDestroy(P->hash_done);
+  for (auto& e : P->ev) if (e) (void)hipEventDestroy(e);   // a partly built context (failed create) holds null handles
+  for (auto& e : P->abs_ev) if (e) (void)hipEventDestroy(e);
+  for (auto& e : P->chunk_ready) if (e) (void)hipEventDestroy(e);
+  if (P->hash_done) (void)hipEventDestroy(P->hash_done);
   if (P->d_sponge) (void)hipFree(P->d_sponge);
   if (P->h_chain) (void)hipHostFree(P->h_chain);
   if (P->h_open) (void)hipHostFree(P->h_open);
   if (P->h_open2) (void)hipHostFree(P->h_open2);
-  (void)hipStreamDestroy(P->hstream);
-  (void)hipStreamDestroy(P->stream);
+  if (P->hstream) (void)hipStreamDestroy(P->hstream);
+  if (P->stream) (void)hipStreamDestroy(P->stream);
   delete P;
 }
 
@@ -434,9 +606,10 @@ extern "C" int sbn_prover_load_trace_device(sbn_prover* P, const uint64_t* d_tra
 // Scratch lives in the (not yet used) LDE buffer; the only host traffic is the instance list in (20 KB) and the
 // instance outputs + error word back (8 KB).
 // the u16 range-check kernel keeps 156 KB in LDS (> the 64 KiB default); idempotent, see ntt_fast_setup
-static int range_check_setup() {
-  static std::atomic<bool> done(false);
-  if (!done.load()) { HIPC(hipFuncSetAttribute((const void*)tg::range_check_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tg::RC_LDS_BYTES)); done.store(true); }
+static int range_check_setup(int device) {
+  static std::atomic<bool> done[SBN_MAX_DEVICES];
+  const int d = device >= 0 && device < SBN_MAX_DEVICES ? device : 0;
+  if (!done[d].load()) { HIPC(hipFuncSetAttribute((const void*)tg::range_check_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tg::RC_LDS_BYTES)); done[d].store(true); }
   return 0;
 }
 template <int E>
@@ -453,7 +626,8 @@ static int generate_trace_device(sbn_prover* P, const uint32_t* ios, size_t K, u
   const ExpShape sh = exp_shape(P->air);
   P->loaded = false;
   // carve the scratch
-  u64* w = P->d_lde;
+  u64* const wbase = P->sp ? (u64*)P->sp->comm.recv_buf : P->d_lde;   // scratch: the LDE buffer, not yet in use
+  u64* w = wbase;
   auto take = [&](size_t words) { u64* r = w; w += (words + 7) & ~(size_t)7; return r; };
   const size_t cw = 257 * 12 * E * K;  // one Jacobian chain of every instance
   u64* ja = take(cw); u64* jb = take(cw);
@@ -463,8 +637,8 @@ static int generate_trace_device(sbn_prover* P, const uint32_t* ios, size_t K, u
   unsigned char* row_op = (unsigned char*)take(n / 8 + 1);
   uint32_t* d_ios = (uint32_t*)take(IOW * K / 2 + 1);
   int* d_err = (int*)take(1);
-  if ((size_t)(w - P->d_lde) > P->air.ncols * P->m) return fail(SBN_ERR_UNSUPPORTED, "scratch does not fit");
-  if (int rc = range_check_setup()) return rc;
+  if ((size_t)(w - wbase) > P->lde_scratch_words) return fail(SBN_ERR_UNSUPPORTED, "scratch does not fit");
+  if (int rc = range_check_setup(P->device)) return rc;
 
   const bool timing = getenv("SBN_TRACE_TIMING") != nullptr;
   hipEvent_t e0 = P->abs_ev[0], e1 = P->abs_ev[1];
@@ -546,7 +720,8 @@ static int generate_trace_device_fq12(sbn_prover* P, const uint32_t* ios, size_t
   hipStream_t st = P->stream;
   const ExpShape sh = exp_shape(P->air);
   P->loaded = false;
-  u64* w = P->d_lde;
+  u64* const wbase = P->sp ? (u64*)P->sp->comm.recv_buf : P->d_lde;   // scratch: the LDE buffer, not yet in use
+  u64* w = wbase;
   auto take = [&](size_t words) { u64* r = w; w += (words + 7) & ~(size_t)7; return r; };
   if (u64e)
     for (size_t k = 0; k < K; k++)
@@ -556,7 +731,7 @@ static int generate_trace_device_fq12(sbn_prover* P, const uint32_t* ios, size_t
   u64* inv = take(n);
   uint32_t* d_ios = (uint32_t*)take(IOW * K / 2 + 1);
   int* d_err = (int*)take(1);
-  if ((size_t)(w - P->d_lde) > P->air.ncols * P->m) return fail(SBN_ERR_UNSUPPORTED, "scratch does not fit");
+  if ((size_t)(w - wbase) > P->lde_scratch_words) return fail(SBN_ERR_UNSUPPORTED, "scratch does not fit");
 
   const bool timing = getenv("SBN_TRACE_TIMING") != nullptr;
   hipEvent_t e0 = P->abs_ev[0], e1 = P->abs_ev[1];
@@ -630,14 +805,15 @@ static int generate_trace_device_fq(sbn_prover* P, const uint32_t* ios, size_t K
   hipStream_t st = P->stream;
   const ExpShape sh = exp_shape(P->air);
   P->loaded = false;
-  u64* w = P->d_lde;
+  u64* const wbase = P->sp ? (u64*)P->sp->comm.recv_buf : P->d_lde;   // scratch: the LDE buffer, not yet in use
+  u64* w = wbase;
   auto take = [&](size_t words) { u64* r = w; w += (words + 7) & ~(size_t)7; return r; };
   const size_t cw = 257 * 4 * K;
   u64* ca = take(cw); u64* cb = take(cw);
   u64* inv = take(n);
   uint32_t* d_ios = (uint32_t*)take(IOW * K / 2 + 1);
   int* d_err = (int*)take(1);
-  if (int rc = range_check_setup()) return rc;
+  if (int rc = range_check_setup(P->device)) return rc;
   hipEvent_t e0 = P->abs_ev[0], e1 = P->abs_ev[1];
   HIPC(hipEventRecord(e0, st));
   HIPC(hipMemcpyAsync(d_ios, ios, IOW * K * sizeof(uint32_t), hipMemcpyHostToDevice, st));
@@ -724,9 +900,13 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
 
   // P1 trace commitment ---------------------------------------------------------------------------
   HIPC(hipEventRecord(P->ev[ST_TRACE_COMMIT], st));
-  if ((rc = commit_pipeline(P, P->d_trace, P->d_coef, P->d_lde, C, P->tree_t, EX_TRACE_ABSORB_MS, EX_TRACE_ABSORB_LAUNCHES))) return rc;
+  SplitCtx* const S = P->sp;   // non-null: this rank's share of one trace split over S->comm.world GPUs
+  if (S) {
+    S->comm_s = 0;
+    if ((rc = commit_split(P, P->d_trace + S->c0 * n, P->d_coef, S->cr, S->cmax, S->ccnt, S->coff, C, S->lde_l, S->lde_n, P->tree_t))) return rc;
+  } else if ((rc = commit_pipeline(P, P->d_trace, P->d_coef, P->d_lde, C, P->tree_t, EX_TRACE_ABSORB_MS, EX_TRACE_ABSORB_LAUNCHES))) return rc;
   HIPC(hipEventRecord(P->ev[ST_PERM_Z], st));
-  if ((rc = tree_cap_to_host(P, P->tree_t, trace_cap))) return rc;
+  if ((rc = S ? split_cap_to_host(P, P->tree_t, trace_cap) : tree_cap_to_host(P, P->tree_t, trace_cap))) return rc;
   ch.observe_words(trace_cap.data(), capw);
 
   // P2 permutation argument -------------------------------------------------------------------------
@@ -734,15 +914,24 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
   F gam[2][2];
   for (int s = 0; s < 2; s++) for (int c = 0; c < (int)cfg.num_challenges; c++) { (void)ch.challenge(); gam[s][c] = ch.challenge(); }
   const F gamma0 = gam[0][0], gamma1 = gam[1][1];  // instance i of a batch uses sets[i].challenges[chal]
-  if (n % 2048 == 0) hipLaunchKernelGGL(permutation_z_kernel<8>, dim3((unsigned)Z), dim3(256), 0, st, P->d_trace, n, P->d_pairs, gamma0.v, gamma1.v, P->d_zval);
-  else if (n % 1024 == 0) hipLaunchKernelGGL(permutation_z_kernel<4>, dim3((unsigned)Z), dim3(256), 0, st, P->d_trace, n, P->d_pairs, gamma0.v, gamma1.v, P->d_zval);
-  else hipLaunchKernelGGL(permutation_z_kernel<2>, dim3((unsigned)Z), dim3(256), 0, st, P->d_trace, n, P->d_pairs, gamma0.v, gamma1.v, P->d_zval);   // n = 512
+  {
+    const size_t zn = S ? S->zr : Z;                       // Z columns computed here (the split: this rank's range)
+    const PairCols* pairs = P->d_pairs + (S ? S->z0 : 0);
+    if (zn == 0) {}
+    else if (n % 2048 == 0) hipLaunchKernelGGL(permutation_z_kernel<8>, dim3((unsigned)zn), dim3(256), 0, st, P->d_trace, n, pairs, gamma0.v, gamma1.v, P->d_zval);
+    else if (n % 1024 == 0) hipLaunchKernelGGL(permutation_z_kernel<4>, dim3((unsigned)zn), dim3(256), 0, st, P->d_trace, n, pairs, gamma0.v, gamma1.v, P->d_zval);
+    else hipLaunchKernelGGL(permutation_z_kernel<2>, dim3((unsigned)zn), dim3(256), 0, st, P->d_trace, n, pairs, gamma0.v, gamma1.v, P->d_zval);   // n = 512
+  }
   HIPC(hipGetLastError());
   HIPC(hipEventRecord(P->ev[ST_Z_COMMIT], st));
-  if ((rc = absorb_times(P, C, EX_TRACE_ABSORB_MS))) return rc;   // (27 event queries: behind the Z kernel, not in front of it)
-  if ((rc = commit_pipeline(P, P->d_zval, P->d_zcoef, P->d_zlde, Z, P->tree_z, EX_Z_ABSORB_MS, EX_Z_ABSORB_LAUNCHES))) return rc;
+  if (S) {
+    if ((rc = commit_split(P, P->d_zval, P->d_zcoef, S->zr, S->zmax, S->zcnt, S->zoff, Z, S->zlde_l, S->zlde_n, P->tree_z))) return rc;
+  } else {
+    if ((rc = absorb_times(P, C, EX_TRACE_ABSORB_MS))) return rc;   // (27 event queries: behind the Z kernel, not in front of it)
+    if ((rc = commit_pipeline(P, P->d_zval, P->d_zcoef, P->d_zlde, Z, P->tree_z, EX_Z_ABSORB_MS, EX_Z_ABSORB_LAUNCHES))) return rc;
+  }
   HIPC(hipEventRecord(P->ev[ST_QUOTIENT_EVAL], st));
-  if ((rc = tree_cap_to_host(P, P->tree_z, z_cap))) return rc;
+  if ((rc = S ? split_cap_to_host(P, P->tree_z, z_cap) : tree_cap_to_host(P, P->tree_z, z_cap))) return rc;
   ch.observe_words(z_cap.data(), capw);
 
   // P3 quotient -------------------------------------------------------------------------------------
@@ -771,12 +960,21 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
   {
     QuotientParams qp{};
     qp.lde = P->d_lde; qp.zlde = P->d_zlde; qp.m = m; qp.next_step = 2;  // 2^quotient_degree_bits
+    qp.lde_next = qp.lde; qp.zlde_next = qp.zlde; qp.row_shift = 0; qp.row_rho = 0;
+    if (S) {
+      // this rank's LDE points j * R + rho; the row two LDE points on is local row j + 1 (two ranks) or sits at local row j
+      // of the second plane (four ranks and more)
+      qp.lde = S->lde_l; qp.zlde = S->zlde_l; qp.m = S->ml; qp.row_shift = S->log_r; qp.row_rho = S->rho;
+      qp.lde_next = S->planes == 2 ? S->lde_n : S->lde_l; qp.zlde_next = S->planes == 2 ? S->zlde_n : S->zlde_l;
+      qp.next_step = S->comm.world == 1 ? 2 : (S->comm.world == 2 ? 1 : 0);
+    }
     qp.xs = P->d_xs; qp.lag_first = P->d_lag_first; qp.lag_last = P->d_lag_last;
     F gn = f_exp_pow2(F(GL_GEN), P->degree_bits);
     qp.zh_inv[0] = f_inv(gn - F(1)).v; qp.zh_inv[1] = f_inv(-gn - F(1)).v;  // Z_H(7 w^i) = 7^N (-1)^i - 1
     qp.last = f_inv(f_root_of_unity(P->degree_bits)).v;
     for (int j = 0; j < SBN_NCH; j++) { qp.alpha[j] = alphas[j].v; qp.apow[j] = P->d_apow + (size_t)j * P->apow_n; }
     qp.gamma0 = gamma0.v; qp.gamma1 = gamma1.v; qp.num_zs = (int)Z; qp.num_io = (int)P->air.num_io; qp.pic = P->d_pic; qp.qout = P->d_q;
+    if (S) qp.qout = (u64*)S->comm.send_buf;   // [2][ml]: all-gathered below
     qp.part = P->d_part;   // QSEG x SBN_NCH planes of m words (the FRI combine's scratch, idle here)
     {
       // constraints that follow each segment: [AIR head][AIR tail][first-row + transitions < zsplit][transitions >= zsplit]
@@ -785,16 +983,22 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
       const u64 after[4] = {n_tail + 2 * (u64)Z, 2 * (u64)Z, (u64)Z - (u64)qp.zsplit, 0};
       for (int sgm = 0; sgm < 4; sgm++) for (int j = 0; j < SBN_NCH; j++) qp.seg_shift[sgm][j] = f_pow(alphas[j], after[sgm]).v;
     }
-    const dim3 qgrid((unsigned)((m + 255) / 256), QSEG);
+    const dim3 qgrid((unsigned)((qp.m + 255) / 256), QSEG);
     if (P->air.kind == SBN_AIR_G1_OP) hipLaunchKernelGGL(quotient_kernel<1>, qgrid, dim3(256), 0, st, qp);
     else if (P->air.kind == SBN_AIR_G1_EXP) hipLaunchKernelGGL(quotient_kernel<2>, qgrid, dim3(256), 0, st, qp);
     else if (P->air.kind == SBN_AIR_G2_EXP) hipLaunchKernelGGL(quotient_kernel<3>, qgrid, dim3(256), 0, st, qp);
     else if (P->air.kind == SBN_AIR_FQ_EXP) hipLaunchKernelGGL(quotient_kernel<5>, qgrid, dim3(256), 0, st, qp);
     else if (P->air.kind == SBN_AIR_FQ12_EXP_U64) hipLaunchKernelGGL(quotient_kernel<6>, qgrid, dim3(256), 0, st, qp);
     else hipLaunchKernelGGL(quotient_kernel<4>, qgrid, dim3(256), 0, st, qp);
-    hipLaunchKernelGGL(quotient_combine_kernel, blocks(m), dim3(256), 0, st, qp);
+    hipLaunchKernelGGL(quotient_combine_kernel, blocks(qp.m), dim3(256), 0, st, qp);
     HIPC(hipGetLastError());
-    if ((rc = absorb_times(P, Z, EX_Z_ABSORB_MS))) return rc;   // behind the quotient kernel
+    if (S) {
+      // quotient values of every rank's points -> all ranks, natural order; the 4 quotient columns are then committed on
+      // every rank alike (no exchange: 4 columns)
+      if ((rc = split_all_gather_device(P, 2 * S->ml))) return rc;
+      hipLaunchKernelGGL(split_unpack_rows_kernel, blocks(m), dim3(256), 0, st, S->scratch, m, 2u, S->log_r, P->d_q);
+      HIPC(hipGetLastError());
+    } else if ((rc = absorb_times(P, Z, EX_Z_ABSORB_MS))) return rc;   // behind the quotient kernel
   }
   HIPC(hipEventRecord(P->ev[ST_QUOTIENT_COMMIT], st));
   // coset_ifft(7) of the 2 quotient value vectors (size m), in place via tmp; the result viewed as
@@ -819,36 +1023,64 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
   // pass), then Z and quotient at both points, then trace at g*zeta -- the coefficients are read twice, in time the
   // device would otherwise spend waiting for the host.
   const u64* open = P->h_open;
-  const bool u4 = n % 1024 == 0;
-  auto open_k = u4 ? openings_kernel<4> : openings_kernel<1>;
-  auto open1_k = u4 ? openings1_kernel<4> : openings1_kernel<1>;
-  const u64 *zp0 = P->d_zpow, *zp1 = P->d_zpow + n, *zp2 = P->d_zpow + 2 * n, *zp3 = P->d_zpow + 3 * n;
-  const size_t Ch = C / 2;   // two slices of the trace columns: the host starts after a quarter of an opening pass
-  hipLaunchKernelGGL(open1_k, dim3((unsigned)Ch), dim3(256), 0, st, P->d_coef, n, zp0, zp1, P->d_open, 0u);
-  HIPC(hipMemcpyAsync(P->h_open, P->d_open, Ch * 4 * sizeof(u64), hipMemcpyDeviceToHost, st));
-  HIPC(hipEventRecord(P->chunk_ready[2], st));  // (the commit pipeline's chunk events are idle here)
-  hipLaunchKernelGGL(open1_k, dim3((unsigned)(C - Ch)), dim3(256), 0, st, P->d_coef + Ch * n, n, zp0, zp1, P->d_open + Ch * 4, 0u);
-  HIPC(hipMemcpyAsync(P->h_open + Ch * 4, P->d_open + Ch * 4, (C - Ch) * 4 * sizeof(u64), hipMemcpyDeviceToHost, st));
-  HIPC(hipEventRecord(P->chunk_ready[0], st));
-  hipLaunchKernelGGL(open_k, dim3((unsigned)Z), dim3(256), 0, st, P->d_zcoef, n, zp0, zp1, zp2, zp3, P->d_open + C * 4);
-  hipLaunchKernelGGL(open_k, dim3(4), dim3(256), 0, st, P->d_q, n, zp0, zp1, zp2, zp3, P->d_open + (C + Z) * 4);
-  HIPC(hipMemcpyAsync(P->h_open + C * 4, P->d_open + C * 4, (Z + 4) * 4 * sizeof(u64), hipMemcpyDeviceToHost, st));
-  HIPC(hipEventRecord(P->chunk_ready[1], st));
-  hipLaunchKernelGGL(open1_k, dim3((unsigned)C), dim3(256), 0, st, P->d_coef, n, zp2, zp3, P->d_open, 2u);
-  HIPC(hipGetLastError());
-  HIPC(hipMemcpyAsync(P->h_open2, P->d_open, C * 4 * sizeof(u64), hipMemcpyDeviceToHost, st));   // a second buffer: the host is reading the first
-  HIPC(hipEventRecord(P->ev[ST_FRI_COMBINE], st));
-  // observe_openings: batch zeta = local ++ perm_zs ++ quotient ; batch g*zeta = next ++ perm_zs_next
-  HIPC(event_wait(P->chunk_ready[2]));
-  for (size_t p = 0; p < Ch; p++) { ch.observe(F(open[4 * p])); ch.observe(F(open[4 * p + 1])); }
-  HIPC(event_wait(P->chunk_ready[0]));
-  for (size_t p = Ch; p < C; p++) { ch.observe(F(open[4 * p])); ch.observe(F(open[4 * p + 1])); }
-  HIPC(event_wait(P->chunk_ready[1]));
-  for (size_t p = C; p < C + Z + 4; p++) { ch.observe(F(open[4 * p])); ch.observe(F(open[4 * p + 1])); }
-  HIPC(stream_wait(st));
   const u64* open2 = P->h_open2;
-  for (size_t p = 0; p < C; p++) { ch.observe(F(open2[4 * p + 2])); ch.observe(F(open2[4 * p + 3])); }
-  for (size_t p = C; p < C + Z; p++) { ch.observe(F(open[4 * p + 2])); ch.observe(F(open[4 * p + 3])); }
+  if (S) {
+    // this rank evaluates its own trace / Z columns at both points (the quotient columns everywhere), the values are
+    // all-gathered on the host and observed in transcript order
+    const u64 *zp0 = P->d_zpow, *zp1 = P->d_zpow + n, *zp2 = P->d_zpow + 2 * n, *zp3 = P->d_zpow + 3 * n;
+    auto open_k = n % 1024 == 0 ? openings_kernel<4> : openings_kernel<1>;
+    if (S->cr) hipLaunchKernelGGL(open_k, dim3((unsigned)S->cr), dim3(256), 0, st, P->d_coef, n, zp0, zp1, zp2, zp3, P->d_open + S->c0 * 4);
+    if (S->zr) hipLaunchKernelGGL(open_k, dim3((unsigned)S->zr), dim3(256), 0, st, P->d_zcoef, n, zp0, zp1, zp2, zp3, P->d_open + (C + S->z0) * 4);
+    hipLaunchKernelGGL(open_k, dim3(4), dim3(256), 0, st, P->d_q, n, zp0, zp1, zp2, zp3, P->d_open + (C + Z) * 4);
+    HIPC(hipGetLastError());
+    HIPC(hipMemcpyAsync(P->h_open, P->d_open, (C + Z + 4) * 4 * sizeof(u64), hipMemcpyDeviceToHost, st));
+    HIPC(hipEventRecord(P->ev[ST_FRI_COMBINE], st));
+    HIPC(stream_wait(st));
+    const u32 R = S->comm.world;
+    const size_t per = (S->cmax + S->zmax) * 4;
+    std::vector<u64> mine(per, 0), all((size_t)R * per);
+    memcpy(mine.data(), P->h_open + S->c0 * 4, S->cr * 4 * sizeof(u64));
+    memcpy(mine.data() + S->cmax * 4, P->h_open + (C + S->z0) * 4, S->zr * 4 * sizeof(u64));
+    if ((rc = split_all_gather_host(P, mine.data(), all.data(), per * sizeof(u64)))) return rc;
+    for (u32 r = 0; r < R; r++) {
+      memcpy(P->h_open + S->coff[r] * 4, all.data() + (size_t)r * per, S->ccnt[r] * 4 * sizeof(u64));
+      memcpy(P->h_open + (C + S->zoff[r]) * 4, all.data() + (size_t)r * per + S->cmax * 4, S->zcnt[r] * 4 * sizeof(u64));
+    }
+    open2 = open;
+    for (size_t p = 0; p < C + Z + 4; p++) { ch.observe(F(open[4 * p])); ch.observe(F(open[4 * p + 1])); }
+    for (size_t p = 0; p < C + Z; p++) { ch.observe(F(open[4 * p + 2])); ch.observe(F(open[4 * p + 3])); }
+  } else {
+    const bool u4 = n % 1024 == 0;
+    auto open_k = u4 ? openings_kernel<4> : openings_kernel<1>;
+    auto open1_k = u4 ? openings1_kernel<4> : openings1_kernel<1>;
+    const u64 *zp0 = P->d_zpow, *zp1 = P->d_zpow + n, *zp2 = P->d_zpow + 2 * n, *zp3 = P->d_zpow + 3 * n;
+    const size_t Ch = C / 2;   // two slices of the trace columns: the host starts after a quarter of an opening pass
+    hipLaunchKernelGGL(open1_k, dim3((unsigned)Ch), dim3(256), 0, st, P->d_coef, n, zp0, zp1, P->d_open, 0u);
+    HIPC(hipMemcpyAsync(P->h_open, P->d_open, Ch * 4 * sizeof(u64), hipMemcpyDeviceToHost, st));
+    HIPC(hipEventRecord(P->chunk_ready[2], st));  // (the commit pipeline's chunk events are idle here)
+    hipLaunchKernelGGL(open1_k, dim3((unsigned)(C - Ch)), dim3(256), 0, st, P->d_coef + Ch * n, n, zp0, zp1, P->d_open + Ch * 4, 0u);
+    HIPC(hipMemcpyAsync(P->h_open + Ch * 4, P->d_open + Ch * 4, (C - Ch) * 4 * sizeof(u64), hipMemcpyDeviceToHost, st));
+    HIPC(hipEventRecord(P->chunk_ready[0], st));
+    hipLaunchKernelGGL(open_k, dim3((unsigned)Z), dim3(256), 0, st, P->d_zcoef, n, zp0, zp1, zp2, zp3, P->d_open + C * 4);
+    hipLaunchKernelGGL(open_k, dim3(4), dim3(256), 0, st, P->d_q, n, zp0, zp1, zp2, zp3, P->d_open + (C + Z) * 4);
+    HIPC(hipMemcpyAsync(P->h_open + C * 4, P->d_open + C * 4, (Z + 4) * 4 * sizeof(u64), hipMemcpyDeviceToHost, st));
+    HIPC(hipEventRecord(P->chunk_ready[1], st));
+    hipLaunchKernelGGL(open1_k, dim3((unsigned)C), dim3(256), 0, st, P->d_coef, n, zp2, zp3, P->d_open, 2u);
+    HIPC(hipGetLastError());
+    HIPC(hipMemcpyAsync(P->h_open2, P->d_open, C * 4 * sizeof(u64), hipMemcpyDeviceToHost, st));   // a second buffer: the host is reading the first
+    HIPC(hipEventRecord(P->ev[ST_FRI_COMBINE], st));
+    // observe_openings: batch zeta = local ++ perm_zs ++ quotient ; batch g*zeta = next ++ perm_zs_next
+    HIPC(event_wait(P->chunk_ready[2]));
+    for (size_t p = 0; p < Ch; p++) { ch.observe(F(open[4 * p])); ch.observe(F(open[4 * p + 1])); }
+    HIPC(event_wait(P->chunk_ready[0]));
+    for (size_t p = Ch; p < C; p++) { ch.observe(F(open[4 * p])); ch.observe(F(open[4 * p + 1])); }
+    HIPC(event_wait(P->chunk_ready[1]));
+    for (size_t p = C; p < C + Z + 4; p++) { ch.observe(F(open[4 * p])); ch.observe(F(open[4 * p + 1])); }
+    HIPC(stream_wait(st));
+    for (size_t p = 0; p < C; p++) { ch.observe(F(open2[4 * p + 2])); ch.observe(F(open2[4 * p + 3])); }
+    for (size_t p = C; p < C + Z; p++) { ch.observe(F(open[4 * p + 2])); ch.observe(F(open[4 * p + 3])); }
+
+  }
 
   // P5 FRI ------------------------------------------------------------------------------------------
   E2 fri_alpha = ch.ext_challenge();
@@ -860,7 +1092,11 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
     auto plan = [&](u32 npoly, E2 weight0) { size_t off = wall.size(); u32 ng = (npoly + GS - 1) / GS; E2 ag = e2_pow(fri_alpha, GS), cur = weight0;
                                              for (u32 k = 0; k < ng; k++) { wall.push_back(cur.a.v); wall.push_back(cur.b.v); cur = cur * ag; } return off; };
     E2 one{F(1), F(0)};
-    size_t w_t = plan((u32)C, one), w_z = Z ? plan((u32)Z, e2_pow(fri_alpha, C)) : 0, w_q = plan(4, e2_pow(fri_alpha, C + Z));
+    // the split: this rank's columns only, with the weights of their global positions
+    const size_t tc0 = S ? S->c0 : 0, tcn = S ? S->cr : C, tz0 = S ? S->z0 : 0, tzn = S ? S->zr : Z;
+    size_t w_t = tcn ? plan((u32)tcn, e2_pow(fri_alpha, tc0)) : 0, w_z = tzn ? plan((u32)tzn, e2_pow(fri_alpha, C + tz0)) : 0,
+           w_q = plan(4, e2_pow(fri_alpha, C + Z));
+    (void)one;
     if (wall.size() > 4096) return fail(SBN_ERR_UNSUPPORTED, "too many FRI combine groups");
     HIPC(hipMemcpyAsync(P->d_w, wall.data(), wall.size() * sizeof(u64), hipMemcpyHostToDevice, st));
     // alpha^k, k < GS, as two planes in the quotient's alpha-power buffer (idle now; it holds at least 1,025 words per plane)
@@ -878,12 +1114,22 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
       return 0;
     };
     u64 *f1a = P->d_fb, *f1b = P->d_fb + n, *f0a = P->d_fa, *f0b = P->d_fa + n;
-    if ((rc = combine(P->d_coef, (u32)C, w_t, f1a, f1b, 0))) return rc;
-    if (Z) if ((rc = combine(P->d_zcoef, (u32)Z, w_z, f1a, f1b, 1))) return rc;
+    if (!tcn) HIPC(hipMemsetAsync(f1a, 0, 2 * n * sizeof(u64), st));
+    if (tcn) if ((rc = combine(P->d_coef, (u32)tcn, w_t, f1a, f1b, 0))) return rc;
+    if (tzn) if ((rc = combine(P->d_zcoef, (u32)tzn, w_z, f1a, f1b, 1))) return rc;
+    if (S) {
+      // F1 = sum over ranks of the partial sums: all-gather + a mod-p add kernel (RCCL has no mod-p reduction); 16 N bytes per rank
+      HIPC(hipMemcpyAsync(S->comm.send_buf, f1a, 2 * n * sizeof(u64), hipMemcpyDeviceToDevice, st));
+      HIPC(stream_wait(st));  // `wall` (pageable host memory) must outlive its upload; the copy must precede the collective
+      if ((rc = split_all_gather_device(P, 2 * n))) return rc;
+      hipLaunchKernelGGL(split_modadd_kernel, blocks(2 * n), dim3(256), 0, st, S->scratch, 2 * n, S->comm.world, f1a);
+      HIPC(hipGetLastError());
+    }
     HIPC(hipMemcpyAsync(f0a, f1a, 2 * n * sizeof(u64), hipMemcpyDeviceToDevice, st));
     if ((rc = combine(P->d_q, 4, w_q, f0a, f0b, 1))) return rc;
     HIPC(stream_wait(st));  // `wall` (pageable host memory) must outlive its upload
-    // final_poly = alpha^(C+Z) * (F0 / (X - zeta)) + F1 / (X - g zeta), padded back to n, then lde -> m
+    // final_poly = alpha^(C+Z) * (F0 / (X - zeta)) + F1 / (X - g zeta), n-1 coefficients each; times X (a zero in front, plonky2
+    // 0.1.x, sbn_config.fri_final_poly_times_x) or zero-padded at the end; then lde -> m
     HIPC(hipMemsetAsync(P->d_fcoef, 0, 2 * m * sizeof(u64), st));
     E2 shift2 = e2_pow(fri_alpha, C + Z);
     auto divide = [&](const u64* ca, const u64* cb, E2 z, E2 mul, int accumulate) {
@@ -891,7 +1137,7 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
       u64 *ha = P->d_part, *hb = P->d_part + nch;
       hipLaunchKernelGGL(divide_by_linear_pass1, blocks(nch), dim3(256), 0, st, ca, cb, nch, z.a.v, z.b.v, ha, hb);
       hipLaunchKernelGGL(divide_by_linear_pass2, dim3(1), dim3(256), 0, st, ha, hb, nch, z.a.v, z.b.v);
-      hipLaunchKernelGGL(divide_by_linear_pass3, blocks(nch), dim3(256), 0, st, ca, cb, nch, z.a.v, z.b.v, ha, hb, mul.a.v, mul.b.v, P->d_fcoef, P->d_fcoef + m, accumulate);
+      hipLaunchKernelGGL(divide_by_linear_pass3, blocks(nch), dim3(256), 0, st, ca, cb, nch, z.a.v, z.b.v, ha, hb, mul.a.v, mul.b.v, P->d_fcoef, P->d_fcoef + m, accumulate, cfg.fri_final_poly_times_x);
     };
     divide(f0a, f0b, zeta, E2{F(0), F(0)}, 0);
     divide(f1a, f1b, zeta_next, shift2, 1);
@@ -969,21 +1215,32 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
   // fri_prover_query_rounds
   const u32 nq = cfg.num_query_rounds;
   std::vector<u64> qwords(P->qstride * nq);
+  std::vector<u32> idx(nq), idx_local(nq);  // pageable sources of async uploads: they live until the stream_wait below
+  size_t split_section = 0;                 // the split: words per query that come from the row-sharded trees
   {
-    std::vector<u32> idx(nq);
     for (u32 q = 0; q < nq; q++) idx[q] = (u32)(ch.challenge().v % m);
     HIPC(hipMemcpyAsync(P->d_idx, idx.data(), nq * sizeof(u32), hipMemcpyHostToDevice, st));
     size_t off = 0;
     const u32 nsib = P->lde_log - cfg.cap_height;
-    auto initial = [&](const u64* mat, size_t ncols, const DevTree& t) {
-      hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((ncols + 255) / 256), nq), dim3(256), 0, st, mat, m, P->lde_log, (u32)ncols, P->d_idx, P->d_qbuf, P->qstride, off);
+    // a row-sharded matrix (the split): `rows` local rows, leaf index inside this rank's subtrees; the rank that owns a
+    // query's leaf holds its whole row and its Merkle path up to the cap (other ranks gather a row that is dropped below)
+    auto initial = [&](const u64* mat, size_t ncols, const DevTree& t, size_t rows, u32 log_rows, const u32* d_index) {
+      hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((ncols + 255) / 256), nq), dim3(256), 0, st, mat, rows, log_rows, (u32)ncols, d_index, P->d_qbuf, P->qstride, off);
       off += ncols;
-      hipLaunchKernelGGL(gather_siblings_kernel, dim3(nq), dim3(128), 0, st, t.d, t.nleaf, nsib, P->d_idx, 0u, P->d_qbuf, P->qstride, off);
+      hipLaunchKernelGGL(gather_siblings_kernel, dim3(nq), dim3(128), 0, st, t.d, t.nleaf, nsib, d_index, 0u, P->d_qbuf, P->qstride, off);
       off += (size_t)nsib * 4;
     };
-    initial(P->d_lde, C, P->tree_t);
-    if (Z) initial(P->d_zlde, Z, P->tree_z);
-    initial(P->d_qlde, 4, P->tree_q);
+    if (S) {
+      for (u32 q = 0; q < nq; q++) idx_local[q] = idx[q] & (u32)(S->ml - 1);
+      HIPC(hipMemcpyAsync(S->d_idx_local, idx_local.data(), nq * sizeof(u32), hipMemcpyHostToDevice, st));
+      initial(S->lde_l, C, P->tree_t, S->ml, P->lde_log - S->log_r, S->d_idx_local);
+      if (Z) initial(S->zlde_l, Z, P->tree_z, S->ml, P->lde_log - S->log_r, S->d_idx_local);
+      split_section = off;
+    } else {
+      initial(P->d_lde, C, P->tree_t, m, P->lde_log, P->d_idx);
+      if (Z) initial(P->d_zlde, Z, P->tree_z, m, P->lde_log, P->d_idx);
+    }
+    initial(P->d_qlde, 4, P->tree_q, m, P->lde_log, P->d_idx);
     u32 bits = P->lde_log, shift = 0;
     for (size_t li = 0; li < P->fri.arity_bits.size(); li++) {
       u32 ab = P->fri.arity_bits[li];
@@ -1003,6 +1260,18 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
   HIPC(hipEventRecord(P->ev[ST_COUNT], st));
   HIPC(stream_wait(st));
   for (int i = 0; i < ST_COUNT; i++) HIPC(hipEventElapsedTime(&P->stage_ms[i], P->ev[i], P->ev[i + 1]));
+  if (S) {
+    // the trace / Z sections of every query come from the rank that owns the leaf: all-gather on the host and pick
+    const u32 R = S->comm.world;
+    std::vector<u64> mine((size_t)nq * split_section), all((size_t)R * nq * split_section);
+    for (u32 q = 0; q < nq; q++) memcpy(mine.data() + (size_t)q * split_section, qwords.data() + (size_t)q * P->qstride, split_section * sizeof(u64));
+    if ((rc = split_all_gather_host(P, mine.data(), all.data(), mine.size() * sizeof(u64)))) return rc;
+    for (u32 q = 0; q < nq; q++) {
+      const u32 owner = idx[q] >> (P->lde_log - S->log_r);
+      memcpy(qwords.data() + (size_t)q * P->qstride, all.data() + ((size_t)owner * nq + q) * split_section, split_section * sizeof(u64));
+    }
+    P->stage_ms[ST_COUNT + EX_COMM_MS] = (float)(S->comm_s * 1e3);
+  }
 
   // assemble canonical proof words (layout: include/sbn.h) -----------------------------------------
   sbn_proof* pr = new sbn_proof();
@@ -1115,3 +1384,44 @@ extern "C" int sbn_set_device(int device) {
   return SBN_OK;
 }
 extern "C" int sbn_device_count(void) { int n = 0; return hipGetDeviceCount(&n) == hipSuccess ? n : 0; }
+
+// ---- oversized-trace split: C ABI (include/sbn.h) -----------------------------------------------------------------------
+struct sbn_split_prover { sbn_prover* P; };
+extern "C" int sbn_split_exchange_bytes(const sbn_air_desc* air, const sbn_config* cfg, uint32_t degree_bits, uint32_t world, uint64_t* send_bytes,
+                                        uint64_t* recv_bytes) {
+  if (!air || !cfg || !send_bytes || !recv_bytes || world == 0) return fail(SBN_ERR_BAD_ARG, "null argument");
+  AirShape as;
+  if (!air_shape(air, cfg, as)) return fail(SBN_ERR_BAD_ARG, "unknown air kind / num_io");
+  size_t sw;
+  return split_sizes(as, degree_bits, cfg->rate_bits, world, 64, send_bytes, recv_bytes, &sw);
+}
+extern "C" int sbn_split_prover_create(const sbn_air_desc* air, const sbn_config* cfg, uint32_t degree_bits, const sbn_comm* comm, sbn_split_prover** out) {
+  if (!out || !comm) return fail(SBN_ERR_BAD_ARG, "null argument");
+  *out = nullptr;
+  sbn_prover* P = nullptr;
+  int rc = create_ctx(air, cfg, degree_bits, comm, &P);
+  if (rc) return rc;
+  *out = new sbn_split_prover{P};
+  return SBN_OK;
+}
+extern "C" void sbn_split_prover_destroy(sbn_split_prover* sp) {
+  if (!sp) return;
+  sbn_prover_destroy(sp->P);
+  delete sp;
+}
+extern "C" int sbn_split_prover_generate_trace(sbn_split_prover* sp, const uint32_t* ios, size_t num_io, uint64_t* pi_out) {
+  if (!sp) return fail(SBN_ERR_BAD_ARG, "null argument");
+  return sbn_prover_generate_trace(sp->P, ios, num_io, pi_out);
+}
+extern "C" int sbn_split_prover_load_trace(sbn_split_prover* sp, const uint64_t* trace, const uint64_t* pi, size_t n_pi) {
+  if (!sp) return fail(SBN_ERR_BAD_ARG, "null argument");
+  return sbn_prover_load_trace(sp->P, trace, pi, n_pi);
+}
+extern "C" int sbn_split_prover_prove(sbn_split_prover* sp, sbn_proof** out) {
+  if (!sp) return fail(SBN_ERR_BAD_ARG, "null argument");
+  return sbn_prover_prove(sp->P, out);
+}
+extern "C" int sbn_split_prover_stage_times(const sbn_split_prover* sp, float* ms_out, int cap) {
+  if (!sp) return 0;
+  return sbn_prover_stage_times(sp->P, ms_out, cap);
+}

@@ -207,6 +207,11 @@ def prove(kind, num_io, trace, pi):
     return words, secs.value
 
 
+def set_final_poly_times_x(on):
+    """Which plonky2 FRI the oracle speaks: True (default) = the 0.1.x 'multiply the final polynomial by X' step."""
+    lib().orc_set_final_poly_times_x(1 if on else 0)
+
+
 def verify(kind, num_io, words):
     words = np.ascontiguousarray(words, dtype=np.uint64)
     why = C.c_char_p()

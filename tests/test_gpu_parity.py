@@ -80,6 +80,26 @@ def test_g1stark_proof_bit_exact(gpu, O, golden, rows, seed):
     assert proof.recover_degree_bits(cfg) == rows.bit_length() - 1
 
 
+def test_g1stark_proof_without_the_times_x_step(gpu, O):
+    """sbn_config.fri_final_poly_times_x = 0 (later upstream plonky2: no multiply-by-X of the FRI final polynomial):
+    GPU proof bytes == the oracle's in the same mode, and differ from the default mode's."""
+    pts, _ = O.g1op_inputs(1024, 3)
+    stark = gpu.G1Stark()
+    trace = stark.generate_trace(pts)
+    cfg = stark.config()
+    cfg.fri_final_poly_times_x = 0
+    proof = gpu.prove(stark, cfg, trace, np.zeros(0, dtype=np.uint64))
+    try:
+        O.set_final_poly_times_x(False)
+        ref, _ = O.prove(O.AIR_G1_OP, 0, trace, np.zeros(0, dtype=np.uint64))
+    finally:
+        O.set_final_poly_times_x(True)
+    assert np.array_equal(proof.words, ref)
+    gpu.verify_stark_proof(stark, proof, cfg)
+    with pytest.raises(gpu.SbnError):
+        gpu.verify_stark_proof(stark, proof, stark.config())
+
+
 @pytest.fixture(scope="module")
 def g1exp_gpu_proof(gpu, g1exp_case):
     stark = gpu.G1ExpStark(128)
@@ -124,6 +144,25 @@ def test_g1exp_full_oracle_proof_equality(gpu, O, g1exp_case, g1exp_gpu_proof):
     _, _, p1, _, _ = g1exp_gpu_proof
     ref, _ = O.prove(O.AIR_G1_EXP, 128, g1exp_case["trace"], g1exp_case["pi"])
     assert np.array_equal(p1.words, ref)
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_g1exp_more_seeds_full_oracle_proof_equality(gpu, O, seed):
+    """More seeds of BASELINE config[1] (with seed 1 above: three in all), the witness generated on the device: trace,
+    public inputs and every proof word equal the CPU oracle's (its prove() runs on the box, about a minute per seed)."""
+    ios, _ = O.g1exp_inputs(128, seed)
+    trace, pi = O.g1exp_trace(ios)
+    stark = gpu.G1ExpStark(128)
+    cfg = stark.config()
+    prover = gpu.Prover(stark, cfg, 16)
+    try:
+        assert np.array_equal(prover.generate_trace(ios), pi)
+        got = prover.prove()
+    finally:
+        prover.close()
+    want, _ = O.prove(O.AIR_G1_EXP, 128, trace, pi)
+    assert np.array_equal(got.words, want)
+    gpu.verify_stark_proof(stark, got, cfg)
 
 
 def test_g1exp_device_witness_generation_matches_oracle(gpu, O, g1exp_case, g1exp_gpu_proof, golden):
@@ -288,6 +327,43 @@ def test_fq12exp_2pow16_independent_verifier(gpu, O):
     t = proof.words.copy()
     t[12 + 3 * 64 + 5] = (int(t[12 + 3 * 64 + 5]) + 1) % P
     assert O.verify(O.AIR_FQ12_EXP, num_io, t)[0] != 0
+
+
+def test_fq12exp_2pow18_config4(gpu, O):
+    """BASELINE config[4] on one GPU: Fq12ExpStark(512), 2^18 rows x 11786 columns (24.7 GB trace, never on the host:
+    the witness is generated on the device), reference workload src/fields/fq12/exp.rs:638-696.  The oracle's prover
+    would need an hour here, so the size-independent checks of the 2^16 case: outputs equal offset * x^e by python tower
+    arithmetic, the oracle's VERIFIER (independent code) and the product's accept the proof, a flipped opening / cap /
+    public input is rejected, and a second prove() is word-identical."""
+    num_io = 512
+    ios, native = O.fq12exp_inputs(num_io, 3)
+    stark = gpu.Fq12ExpStark(num_io)
+    cfg = stark.config()
+    assert (stark.num_columns, stark.num_public_inputs, stark.num_permutation_zs(cfg)) == (11786, 299008, 5328)
+    prover = gpu.Prover(stark, cfg, 18)
+    try:
+        pi = prover.generate_trace(ios)
+        for k in (0, 257, 511):
+            x, off, e = native[k]
+            got = [sum(int(pi[584 * k + 392 + 16 * c + i]) << (16 * i) for i in range(16)) for c in range(12)]
+            assert got == O.fq12_mul(off, O.fq12_pow(x, e))
+        p1 = prover.prove()
+        p2 = prover.prove()
+        times = prover.stage_times()
+    finally:
+        prover.close()
+    assert np.array_equal(p1.words, p2.words)
+    assert p1.recover_degree_bits(cfg) == 18
+    assert np.array_equal(p1.words[-299008:], pi)
+    assert O.verify(O.AIR_FQ12_EXP, num_io, p1.words) == (0, "")
+    gpu.verify_stark_proof(stark, p1, cfg)
+    for idx in (13, 12 + 3 * 64 + 5, len(p1.words) - 299008 + 700):      # trace cap, an opening, a public input
+        t = p1.words.copy()
+        t[idx] = (int(t[idx]) + 1) % P
+        assert O.verify(O.AIR_FQ12_EXP, num_io, t)[0] != 0
+        with pytest.raises(gpu.SbnError):
+            gpu.verify_stark_proof(stark, gpu.Proof(t, 18), cfg)
+    print("Fq12ExpStark(512) stage times (ms):", {k: round(v, 1) for k, v in times.items()})
 
 
 def test_fq12exp_device_witness_generation_matches_oracle(gpu, O, fq12exp_case, golden):

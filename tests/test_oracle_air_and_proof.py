@@ -108,6 +108,32 @@ def test_g1op_prove_verify_and_digest(O, g1op_case, golden):
     assert [int(x) for x in w[1:12]] == [9, 2283, 1264, 4, 0, 4, 1, 1, 4, 32, 84]
 
 
+def test_fri_final_poly_times_x_switch(O, S, g1op_case):
+    """plonky2 0.1.x multiplies the FRI final polynomial by X (prove_openings: insert(0, ZERO); fri_combine_initial:
+    sum * subgroup_x); later upstream versions do not.  The dependency is un-vendored ([DEP-RECALL]), so both forms are
+    kept behind a switch: each verifier (oracle and product host verifier) accepts its own form and rejects the other."""
+    stark = S.G1Stark()
+    cfg1, cfg0 = stark.config(), stark.config()
+    assert cfg1.fri_final_poly_times_x == 1
+    cfg0.fri_final_poly_times_x = 0
+    w1 = g1op_case["proof"]
+    try:
+        O.set_final_poly_times_x(False)
+        w0, _ = O.prove(O.AIR_G1_OP, 0, g1op_case["trace"], g1op_case["pi"])
+        assert O.verify(O.AIR_G1_OP, 0, w0) == (0, "")
+        assert O.verify(O.AIR_G1_OP, 0, w1)[0] != 0
+    finally:
+        O.set_final_poly_times_x(True)
+    assert not np.array_equal(w0, w1)
+    assert O.verify(O.AIR_G1_OP, 0, w1) == (0, "")
+    assert O.verify(O.AIR_G1_OP, 0, w0)[0] != 0
+    S.verify_stark_proof(stark, S.Proof(w1, 9), cfg1)
+    S.verify_stark_proof(stark, S.Proof(w0, 9), cfg0)
+    for w, cfg in ((w1, cfg0), (w0, cfg1)):
+        with pytest.raises(S.SbnError):
+            S.verify_stark_proof(stark, S.Proof(w, 9), cfg)
+
+
 @pytest.mark.parametrize("where", ["trace_cap", "opening", "fri_cap", "query_leaf", "final_poly", "pow", "truncate", "noncanonical"])
 def test_oracle_rejects_tampering(O, g1op_case, where):
     w = g1op_case["proof"].copy()
