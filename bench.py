@@ -38,19 +38,29 @@ def main():
     ap.add_argument("--no-batch-mode", action="store_true", help="skip the extra 3-proofs-in-flight throughput measurement")
     ap.add_argument("--concurrency", type=int, default=1,
                     help="independent proofs in flight per GPU (batch mode, BASELINE config[2]); 1 = single-proof latency (default)")
-    ap.add_argument("--table", choices=["g1", "g2"], default="g1",
-                    help="g1 = G1ExpStark(128), the BASELINE metric (default); g2 = G2ExpStark(128), BASELINE config[3]")
+    ap.add_argument("--table", choices=["g1", "g2", "fq12"], default="g1",
+                    help="g1 = G1ExpStark(128), the BASELINE metric (default); g2 = G2ExpStark(128), BASELINE config[3]; fq12 (with --split) = Fq12ExpStark")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="BASELINE config[2] literally: this many independent G1 proofs (seeds seed+unit), units dealt round-robin to the ranks, "
+                         "witness generated on the device inside the timed region, per-unit digests gathered on rank 0 (strong scaling; --steps is ignored)")
+    ap.add_argument("--split", action="store_true",
+                    help="BASELINE config[4]: ONE proof split over all ranks (sbn_split_prover_*, RCCL all-to-all + all-gathers); --table fq12 --num-io 512 is the config as written")
+    ap.add_argument("--num-io", type=int, default=None, help="instances of the table (default 128; --split --table fq12: 512)")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="PMC-measured HBM bytes per dominant-kernel launch; default: profiles/*_pmc_summary.json (separate rocprofv3 --pmc passes)")
     args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    # host worker pool of the library (Jacobian chains of the device witness generation, canonical checks): the ranks of a
+    # node share its cores
+    os.environ.setdefault("SBN_HOST_THREADS", str(max(1, min(64, (os.cpu_count() or 8) // max(world, 1)))))
 
     import numpy as np
     import torch
     import starky_bn254_amd as S
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
@@ -61,9 +71,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.split:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # "nccl" is RCCL on ROCm
         else:
@@ -72,9 +83,26 @@ def main():
     rc = S.lib().sbn_set_device(local_rank)
     if rc != 0:
         raise SystemExit("sbn_set_device failed")
+    from starky_bn254_amd import sharding
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        return sharding.max_over_ranks(x, dist, device=dev if args.backend == "nccl" else None)
+
+    if args.split:
+        return bench_split(args, S, np, torch, dist, rank, world, barrier, max_over_ranks)
+    if args.batch:
+        return bench_batch(args, S, np, torch, dist, rank, world, barrier, max_over_ranks)
+    if args.table == "fq12":
+        raise SystemExit("--table fq12 is the oversized-trace workload: use it with --split")
 
     # synthetic inputs: random G1 points and 256-bit scalars (src/curves/g1/exp.rs:794-809), one instance set per rank
-    from starky_bn254_amd import sharding
     stark = S.G1ExpStark(NUM_IO) if args.table == "g1" else S.G2ExpStark(NUM_IO)
     cfg = stark.config()
     ios = synthetic_ios(NUM_IO, sharding.unit_seed(args.seed, rank), args.table)
@@ -90,11 +118,6 @@ def main():
         p2 = S.Prover(stark, cfg, DEGREE_BITS)
         p2.load_trace(trace, pi)
         extra.append(p2)
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
 
     proof = None
     for _ in range(args.warmup):
@@ -121,8 +144,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     barrier()
-    if dist is not None:
-        elapsed = sharding.max_over_ranks(elapsed, dist, device=dev if args.backend == "nccl" else None)
+    elapsed = max_over_ranks(elapsed)
 
     # every rank checks its own proof outside the timed region
     S.verify_stark_proof(stark, proof, cfg)
@@ -185,20 +207,7 @@ def main():
 
     if rank == 0:
         steps = max(args.steps, 1)
-        if args.traffic_bytes is None:
-            args.traffic_bytes = committed_traffic("leaf_absorb_kernel")
-        n, m, C = 1 << DEGREE_BITS, 1 << (DEGREE_BITS + 1), stark.num_columns
-        Zc = stark.num_permutation_zs(cfg)
         stage_ms = {k: v / steps for k, v in stage_acc.items()}
-        # dominant kernel: leaf_absorb_kernel over the trace LDE (Poseidon sponge, one launch per 64-column
-        # chunk on the hash stream; timed launch by launch with HIP events on that stream)
-        launches = max(stage_ms.get("trace_absorb_launches", 1.0), 1.0)
-        tot_bytes = 8.0 * m * C + 32.0 * m + 2 * 96.0 * m * (launches - 1)   # LDE once, digests, carried sponge state
-        alg_bytes = tot_bytes / launches
-        dom_ms = stage_ms.get("trace_absorb_kernels_ms", float("nan")) / launches
-        achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms and dom_ms > 0 else None
-        p_cols = 1 + 3 * (Zc // 2)                         # distinct trace columns read by the permutation argument
-        proof_alg_bytes = 8.0 * n * (6 * C + 7 * Zc + p_cols)   # 8.67 GB
         ms_per_step = elapsed / (steps * max(args.concurrency, 1)) * 1e3
         line = {
             "metric": "G1 scalar-mult proofs/sec at trace height 2^16" if args.table == "g1" else "G2 scalar-mult proofs/sec at trace height 2^16",
@@ -208,23 +217,15 @@ def main():
             "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
-            "config": {"workload": f"{type(stark).__name__}(num_io=128): prove() of a 2^16-row x {C}-column trace (128 scalar mults), trace resident in HBM",
-                       "degree_bits": DEGREE_BITS, "num_columns": C, "num_public_inputs": stark.num_public_inputs,
-                       "permutation_zs": Zc, "fri": "rate_bits=1 cap=4 arity=16 queries=84 pow_bits=16",
+            "config": {"workload": f"{type(stark).__name__}(num_io=128): prove() of a 2^16-row x {stark.num_columns}-column trace (128 scalar mults), trace resident in HBM",
+                       "degree_bits": DEGREE_BITS, "num_columns": stark.num_columns, "num_public_inputs": stark.num_public_inputs,
+                       "permutation_zs": stark.num_permutation_zs(cfg), "fri": "rate_bits=1 cap=4 arity=16 queries=84 pow_bits=16",
                        "proofs_per_rank": args.steps * max(args.concurrency, 1), "proofs_in_flight_per_gpu": max(args.concurrency, 1),
-                       "parallelism": f"independent proofs x{world}, no collective"},
-            "roofline": {"bound": "hbm", "kernel": "leaf_absorb_kernel (trace LDE, Poseidon sponge per row, 64-column chunks)", "launches_per_proof": launches,
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-                         "traffic": args.traffic_bytes, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": dom_ms,
-                         "note": "ALU-bound kernel (210 Poseidon permutations per row); see DESIGN.md",
-                         "valu_issue": valu_issue(dom_ms)},
-            "proof_roofline": {"algorithmic_bytes_per_proof": proof_alg_bytes,
-                               "achieved_GBps": proof_alg_bytes / (ms_per_step * 1e-3) / 1e9,
-                               "frac_of_hbm_peak": proof_alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                       "parallelism": f"independent proofs x{world}, no collective", "host_threads_per_rank": int(os.environ["SBN_HOST_THREADS"])},
             "stage_ms": stage_ms,
             "host": {"tracegen_s": t_tracegen, "h2d_s": t_h2d, "trace_bytes": int(trace.nbytes)},
         }
+        line.update(rooflines(args, stark, cfg, stage_ms, ms_per_step))
         if batch:
             line["batch_mode"] = batch
         if e2e:
@@ -239,6 +240,163 @@ def main():
         dist.destroy_process_group()
 
 
+def rooflines(args, stark, cfg, stage_ms, ms_per_proof, degree_bits=DEGREE_BITS):
+    """`roofline` (dominant kernel) and `proof_roofline` (whole proof) objects of the bench line."""
+    traffic, source = args.traffic_bytes, "--traffic-bytes argument"
+    if traffic is None:
+        traffic, source = committed_pmc("leaf_absorb_kernel"), committed_pmc_file() or "no committed PMC summary"
+        source = f"committed rocprofv3 --pmc passes ({source}), not measured in this run"
+    n, m, C = 1 << degree_bits, 1 << (degree_bits + 1), stark.num_columns
+    Zc = stark.num_permutation_zs(cfg)
+    # dominant kernel: leaf_absorb_kernel over the trace LDE (Poseidon sponge, one launch per 64-column
+    # chunk on the hash stream; timed launch by launch with HIP events on that stream)
+    launches = max(stage_ms.get("trace_absorb_launches", 1.0), 1.0)
+    tot_bytes = 8.0 * m * C + 32.0 * m + 2 * 96.0 * m * (launches - 1)   # LDE once, digests, carried sponge state
+    alg_bytes = tot_bytes / launches
+    dom_ms = stage_ms.get("trace_absorb_kernels_ms", float("nan")) / launches
+    achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms and dom_ms > 0 else None
+    p_cols = 1 + 3 * (Zc // 2)                         # distinct trace columns read by the permutation argument
+    proof_alg_bytes = 8.0 * n * (6 * C + 7 * Zc + p_cols)   # SURVEY section 8d: 8.67 GB for G1
+    return {
+        "roofline": {"bound": "hbm", "kernel": "leaf_absorb_kernel (trace LDE, Poseidon sponge per row, 64-column chunks)", "launches_per_proof": launches,
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
+                     "traffic": traffic, "traffic_source": source, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": dom_ms,
+                     "note": "ALU-bound kernel (210 Poseidon permutations per row); see DESIGN.md",
+                     "valu_issue": valu_issue(dom_ms)},
+        "proof_roofline": {"algorithmic_bytes_per_proof": proof_alg_bytes,
+                           "achieved_GBps": proof_alg_bytes / (ms_per_proof * 1e-3) / 1e9,
+                           "frac_of_hbm_peak": proof_alg_bytes / (ms_per_proof * 1e-3) / 1e9 / HBM_PEAK_GBS},
+    }
+
+
+def bench_batch(args, S, np, torch, dist, rank, world, barrier, max_over_ranks):
+    """BASELINE config[2] as written: a batch of `--batch` independent G1 scalar-mult proofs (seeds seed + unit), dealt
+    round-robin to the ranks (sharding.shard_units), every rank proving its units with 3 proofs in flight from instance
+    lists (witness generated on the device INSIDE the timed region).  No data-path collective; digests gathered for rank 0."""
+    from starky_bn254_amd import sharding
+    if args.table != "g1":
+        raise SystemExit("--batch is the G1 batch of BASELINE config[2]")
+    stark = S.G1ExpStark(NUM_IO)
+    cfg = stark.config()
+    units = sharding.shard_units(args.batch, rank, world)
+    t0 = time.time()
+    ios_units = np.stack([synthetic_ios(NUM_IO, sharding.unit_seed(args.seed, u), "g1") for u in units]) if units else np.zeros((0, NUM_IO, 40), np.uint32)
+    t_inputs = time.time() - t0
+    inflight = 3
+    bp = S.BatchProver(stark, cfg, DEGREE_BITS, inflight)
+    if len(units):
+        bp.prove_ios(ios_units[:min(inflight, len(units))])            # warm-up (untimed)
+    barrier()
+    t0 = time.perf_counter()
+    proofs = bp.prove_ios(ios_units) if len(units) else []
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    barrier()
+    elapsed = max_over_ranks(elapsed)
+    local = {int(u): sharding.digest(p.words) for u, p in zip(units, proofs)}
+    for p in proofs[:2]:
+        S.verify_stark_proof(stark, p, cfg)                              # a sample per rank, outside the timed region
+    merged = sharding.gather_digests(local, dist) if dist is not None else local
+    if rank == 0:
+        ok = sorted(merged) == list(range(args.batch)) and len(set(merged.values())) == args.batch
+        line = {"metric": "G1 scalar-mult proofs/sec at trace height 2^16", "value": args.batch / elapsed, "unit": "proofs/s", "n_gpus": world,
+                "steps": len(units), "warmup": min(inflight, len(units)), "ms_per_step": elapsed / max(len(units), 1) * 1e3, "higher_is_better": True,
+                "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+                "config": {"workload": f"batch of {args.batch} independent G1ExpStark(128) proofs (2^16 rows x 1676 columns each), instance list -> device witness -> proof, "
+                                       f"{inflight} proofs in flight per GPU (BASELINE config[2])",
+                           "units_per_rank": len(units), "seeds": f"{args.seed}..{args.seed + args.batch - 1}", "parallelism": f"units round-robin over {world} ranks, no collective",
+                           "host_threads_per_rank": int(os.environ["SBN_HOST_THREADS"])},
+                "batch_check": {"digests_gathered": len(merged), "all_units_present_and_distinct": bool(ok)},
+                "host": {"synthetic_inputs_s": t_inputs}}
+        print(json.dumps(line), flush=True)
+    bp.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def bench_split(args, S, np, torch, dist, rank, world, barrier, max_over_ranks):
+    """BASELINE config[4]: ONE proof split over the ranks (sbn_split_prover_*): columns for NTT / LDE / Z / openings / FRI
+    combine, Merkle-subtree rows for hashing / constraints / queries, RCCL all-to-all in between.  A step = one whole proof."""
+    from starky_bn254_amd.split import SplitProver
+    num_io = args.num_io or (512 if args.table == "fq12" else NUM_IO)
+    stark = {"g1": S.G1ExpStark, "g2": S.G2ExpStark, "fq12": S.Fq12ExpStark}[args.table](num_io)
+    cfg = stark.config()
+    bits = (512 * num_io).bit_length() - 1
+    ios = synthetic_ios_fq12(num_io, args.seed) if args.table == "fq12" else synthetic_ios(num_io, args.seed, args.table)
+    sp = SplitProver(stark, cfg, bits, staged=(args.backend != "nccl"))
+    sp.generate_trace(ios)
+    proof = None
+    for _ in range(args.warmup):
+        proof = sp.prove()
+    acc = {}
+    sp.comm.bytes_sent = 0
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        proof = sp.prove()
+        for k, v in sp.stage_times().items():
+            acc[k] = acc.get(k, 0.0) + v
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    barrier()
+    elapsed = max_over_ranks(elapsed)
+    S.verify_stark_proof(stark, proof, cfg)
+    digests = sharding_gather({rank: digest_of(proof)}, dist)
+    if rank == 0:
+        steps = max(args.steps, 1)
+        n, C, Zc = 1 << bits, stark.num_columns, stark.num_permutation_zs(cfg)
+        p_cols = {"g1": 1 + 3 * (Zc // 2), "g2": 1 + 3 * (Zc // 2), "fq12": 1 + 6 * (Zc // 4)}[args.table]
+        alg = 8.0 * n * (6 * C + 7 * Zc + p_cols)
+        ms = elapsed / steps * 1e3
+        line = {"metric": f"{type(stark).__name__} proofs/sec at trace height 2^{bits}, one proof split over {world} GPU(s)", "value": steps / elapsed, "unit": "proofs/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "strong",
+                "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+                "config": {"workload": f"{type(stark).__name__}(num_io={num_io}): ONE prove() of a 2^{bits}-row x {C}-column trace split over {world} rank(s) "
+                                       f"(BASELINE config[4]{' as written' if args.table == 'fq12' and num_io == 512 else ''}), witness resident on every rank",
+                           "degree_bits": bits, "num_columns": C, "permutation_zs": Zc, "backend": "RCCL (torch.distributed nccl)" if args.backend == "nccl" else "host-staged gloo",
+                           "parallelism": f"column shard -> all-to-all -> row shard (Merkle cap subtrees), {world} ranks"},
+                "proof_roofline": {"algorithmic_bytes_per_proof": alg, "achieved_GBps": alg / (ms * 1e-3) / 1e9,
+                                   "frac_of_aggregate_hbm_peak": alg / (ms * 1e-3) / 1e9 / (HBM_PEAK_GBS * world)},
+                "stage_ms_rank0": {k: v / steps for k, v in acc.items()},
+                "exchange": {"bytes_sent_per_proof_rank0": sp.comm.bytes_sent // steps, "exchange_ms_rank0": acc.get("split_exchange_ms", 0.0) / steps},
+                "all_ranks_same_proof": len(set(digests.values())) == 1}
+        print(json.dumps(line), flush=True)
+    sp.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def digest_of(proof):
+    import hashlib
+    return hashlib.sha256(proof.to_bytes()).hexdigest()
+
+
+def sharding_gather(local, dist):
+    if dist is None or dist.get_world_size() == 1:
+        return local
+    from starky_bn254_amd import sharding
+    return sharding.gather_digests(local, dist)
+
+
+def synthetic_ios_fq12(num_io, seed):
+    """num_io x (x, offset: 12 flat-basis Fq coefficients each; exponent: uniform mod r), u32 LE limbs (src/fields/fq12/exp.rs:647-660)."""
+    import numpy as np
+    P = 21888242871839275222246405745257275088696311157297823662689037894645226208583
+    R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+    rng = np.random.default_rng(seed)
+    ios = np.zeros((num_io, 200), dtype=np.uint32)
+    for k in range(num_io):
+        for c in range(24):
+            v = int.from_bytes(rng.bytes(32), "little") % P
+            ios[k, 8 * c:8 * c + 8] = [(v >> (32 * i)) & 0xFFFFFFFF for i in range(8)]
+        e = int.from_bytes(rng.bytes(32), "little") % R
+        ios[k, 192:200] = [(e >> (32 * i)) & 0xFFFFFFFF for i in range(8)]
+    return ios
+
+
 def committed_pmc(kernel, key="hbm_bytes_per_launch_corrected"):
     """A per-launch figure of `kernel` from the newest committed PMC summary (tools/summarize_pmc.py)."""
     import glob
@@ -251,19 +409,37 @@ def committed_pmc(kernel, key="hbm_bytes_per_launch_corrected"):
     return d.get(kernel, {}).get(key)
 
 
-def committed_traffic(kernel):
-    return committed_pmc(kernel)
+def committed_pmc_file():
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")),
+                   key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))])
+    return os.path.relpath(files[-1], ROOT) if files else None
 
 
 def valu_issue(dom_ms):
-    """The bound this kernel actually runs against: VALU issue.  Wave-instructions per launch from the committed
-    SQ_INSTS_VALU pass; a wave64 VALU instruction occupies its SIMD for 4 cycles, 1,024 SIMDs at the 2.4 GHz peak clock."""
+    """The bound this kernel actually runs against: VALU issue.  The instruction mix of one permutation (tools/poseidon_mix.py,
+    from the hand-scheduled streams) is priced with the MEASURED issue cost of every instruction class at the kernel's 2
+    waves per SIMD (tools/microbench/valu_rates.hip -> profiles/r2_valu_rates.txt: v_mad_u64_u32, carry adds and VOP3 ops
+    hold a SIMD ~2 ns whatever the occupancy; only plain VOP2 adds / moves reach ~1 ns with a partner wave) -- the time the
+    1,024 SIMDs need just to ISSUE a launch's instructions, against the measured launch time."""
+    import glob
+    import re
     n = committed_pmc("leaf_absorb_kernel", "valu_wave_instructions_per_launch")
-    if not n or not dom_ms or dom_ms <= 0:
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sponge_issue_model.json")), key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))])
+    if not dom_ms or dom_ms <= 0:
         return None
-    peak = 1024 * 2.4e9 / 4
-    ach = n / (dom_ms * 1e-3)
-    return {"wave_instructions_per_launch": n, "achieved_per_s": ach, "peak_per_s": peak, "frac": ach / peak}
+    out = {"wave_instructions_per_launch": n, "achieved_per_s": (n / (dom_ms * 1e-3)) if n else None}
+    if files:
+        m = json.load(open(files[-1]))
+        wave_perms_per_simd = (1 << 20) / 64 / 1024          # 2^17 rows x 8 permutations per 64-column launch, 1,024 SIMDs
+        issue_ms = m["issue_us_per_wave_permutation_per_simd"] * wave_perms_per_simd * 1e-3
+        out.update({"issue_floor_ms_per_launch": issue_ms, "frac": issue_ms / dom_ms, "peak_per_s": 1024 / (m["weighted_ns_per_wave_instruction"] * 1e-9),
+                    "model": os.path.relpath(files[-1], ROOT), "rates": m["source"]})
+    else:
+        peak = 1024 * 2.4e9 / 4
+        out.update({"peak_per_s": peak, "frac": out["achieved_per_s"] / peak if out["achieved_per_s"] else None, "model": "4 cycles at 2.4 GHz (no committed model)"})
+    return out
 
 
 def synthetic_ios(num_io, seed, table="g1"):
@@ -348,8 +524,9 @@ def cpu_baseline(trace, pi, table="g1"):
     import oracle_lib as O
     words, secs = O.prove(O.AIR_G1_EXP if table == "g1" else O.AIR_G2_EXP, NUM_IO, trace, pi)
     return {"value": 1.0 / secs, "unit": "proofs/s", "cores": os.cpu_count(), "kind": "port",
+            "kind_note": "restated C++ port (oracle/), NOT the Rust reference: the reference cannot be built in this image",
             "sample": "1 full 2^16-row prove() on the same trace (oracle/, OpenMP on all host cores): the smallest unit of this workload",
-            "seconds": secs}
+            "seconds": secs, "stage_seconds": O.last_stage_seconds()}
 
 
 if __name__ == "__main__":

@@ -26,6 +26,11 @@ static U256 u256_from_u32(const uint32_t* w) {
 extern "C" {
 
 void orc_poseidon_round_constants(uint64_t* out) { memcpy(out, poseidon_consts().rc, 360 * 8); }
+void orc_poseidon_permute_fast(uint64_t* st) {  // sparse partial rounds (what the Merkle hashing uses); must equal the definition
+  PState s; for (int i = 0; i < 12; i++) s[i] = GF(st[i]);
+  poseidon_permute_fast(s);
+  for (int i = 0; i < 12; i++) st[i] = s[i].v;
+}
 void orc_poseidon_permute(uint64_t* st) {
   PState s; for (int i = 0; i < 12; i++) s[i] = GF(st[i]);
   poseidon_permute(s);
@@ -246,6 +251,12 @@ int orc_prove(int kind, size_t num_io, const uint64_t* trace, unsigned degree_bi
   return 0;
 }
 void orc_free(void* p) { free(p); }
+// Stage k of the last orc_prove: name (static storage until the next prove) and wall seconds; returns the stage count.
+int orc_last_stage_seconds(int k, const char** name, double* seconds) {
+  auto& v = stage_log();
+  if (k >= 0 && (size_t)k < v.size()) { if (name) *name = v[k].first.c_str(); if (seconds) *seconds = v[k].second; }
+  return (int)v.size();
+}
 
 // 0 = accepted; negative = rejected (message in *why).
 int orc_verify(int kind, size_t num_io, const uint64_t* proof, size_t nwords, const char** why) {

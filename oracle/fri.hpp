@@ -163,7 +163,7 @@ static inline FriProof prove_openings(const FriInstanceInfo& instance,
       for (long c = 0; c < (1 << 16); c++) {
         PState st = inter;
         st[wpos] = GF(base + (u64)c);
-        poseidon_permute(st);
+        poseidon_permute_fast(st);
         u64 resp = st[SPONGE_RATE - 1].v;
         unsigned lz = resp ? (unsigned)__builtin_clzll(resp) : 64;
         if (lz >= min_lz) {

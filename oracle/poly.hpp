@@ -168,13 +168,19 @@ struct PolynomialBatch {
 #pragma omp parallel for schedule(dynamic, 4)
     for (size_t c = 0; c < ncols; c++) lde[c] = coset_lde(polys[c], rate_bits, GF(GL_GENERATOR));
     // transpose + reverse_index_bits_in_place
+    // (blocks of 64 natural-order points: every column is read in contiguous runs and the 64 destination rows stay in cache)
     b.tree.leaves.assign(m, std::vector<GF>());
 #pragma omp parallel for schedule(static)
-    for (size_t i = 0; i < m; i++) {
-      size_t src = reverse_bits(i, lgm);
-      std::vector<GF> row(ncols);
-      for (size_t c = 0; c < ncols; c++) row[c] = lde[c][src];
-      b.tree.leaves[i].swap(row);
+    for (size_t i = 0; i < m; i++) b.tree.leaves[i].resize(ncols);
+    const size_t TB = m < 64 ? m : 64;
+#pragma omp parallel for schedule(static)
+    for (size_t s0 = 0; s0 < m; s0 += TB) {
+      GF* dst[64];
+      for (size_t k = 0; k < TB; k++) dst[k] = b.tree.leaves[reverse_bits(s0 + k, lgm)].data();
+      for (size_t c = 0; c < ncols; c++) {
+        const GF* col = lde[c].data() + s0;
+        for (size_t k = 0; k < TB; k++) dst[k][c] = col[k];
+      }
     }
     b.tree.build(cap_height);
     b.polynomials = std::move(polys);

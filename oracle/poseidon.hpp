@@ -106,8 +106,10 @@ static inline void mds_layer(PState& s) {
   // (as plonky2's `mds_layer` does) and recombined with one 128-bit reduction per output.
   u64 lo[24], hi[24];
   for (int i = 0; i < 12; i++) { lo[i] = lo[i + 12] = s[i].v & 0xffffffffULL; hi[i] = hi[i + 12] = s[i].v >> 32; }
+#pragma GCC unroll 12
   for (int r = 0; r < 12; r++) {
     u64 sl = 0, sh = 0;
+#pragma GCC unroll 12
     for (int i = 0; i < 12; i++) { sl += lo[i + r] * MDS_CIRC[i]; sh += hi[i + r] * MDS_CIRC[i]; }
     sl += lo[r] * MDS_DIAG[r]; sh += hi[r] * MDS_DIAG[r];
     s[r].v = gl_reduce128((u128)sl + ((u128)sh << 32));
@@ -128,6 +130,47 @@ static inline void poseidon_permute(PState& s) {
   }
 }
 
+// The same permutation with the 22 partial rounds in their sparse form (Poseidon paper appendix B; plonky2's "fast partial
+// rounds" are the same rewrite): one dense 11x11 product up front, then per round  s0' = m00 s0 + <vhat_r, s[1..]>,
+// s[i] += what_r[i] s0.  Tables generated by tools/gen_poseidon_fast_partial.py (SBN_GEN_OUT=oracle), which checks the
+// rewrite against the plain form; tests/test_oracle_core.py compares the two here as well.  poseidon_permute above stays
+// the definition; the hashing below uses this one (4x fewer multiplications: the CPU baseline should not be a strawman).
+namespace pfast {
+static const u64 EFF_RC[360] = {
+#include "poseidon_eff_consts.inc"
+};
+#include "poseidon_fast_consts.inc"
+struct Acc { u128 lo = 0, hi = 0; };  // sum of 64x64 products, low and high words summed apart
+static inline void mac(Acc& a, u64 x, u64 y) { u128 p = (u128)x * y; a.lo += (u64)p; a.hi += (u64)(p >> 64); }
+static inline u64 fold(const Acc& a) { u128 t = a.lo + a.hi * (u128)GL_EPS; return gl_reduce128(t); }  // 2^64 = 2^32 - 1
+}  // namespace pfast
+static inline void poseidon_permute_fast(PState& s) {
+  const u64* rc = pfast::EFF_RC;
+  int r = 0;
+  for (int k = 0; k < 4; k++, r++) {
+    for (int i = 0; i < 12; i++) s[i] = sbox7(s[i] + GF(rc[12 * r + i]));
+    mds_layer(s);
+  }
+  for (int i = 0; i < 12; i++) s[i] = s[i] + GF(rc[12 * r + i]);
+  {
+    u64 t[11];
+    for (int i = 0; i < 11; i++) { pfast::Acc a; for (int j = 0; j < 11; j++) pfast::mac(a, pfast::PFAST_INIT[11 * i + j], s[1 + j].v); t[i] = pfast::fold(a); }
+    for (int i = 0; i < 11; i++) s[1 + i].v = t[i];
+  }
+  for (int k = 0; k < 22; k++, r++) {
+    const GF s0 = sbox7(k ? s[0] + GF(rc[12 * r]) : s[0]);
+    pfast::Acc a; pfast::mac(a, pfast::PFAST_M00, s0.v);
+    const u64* vh = pfast::PFAST_VHAT + 11 * k; const u64* wh = pfast::PFAST_WHAT + 11 * k;
+    for (int i = 0; i < 11; i++) pfast::mac(a, vh[i], s[1 + i].v);
+    for (int i = 0; i < 11; i++) { pfast::Acc b; b.lo = s[1 + i].v; pfast::mac(b, wh[i], s0.v); s[1 + i].v = pfast::fold(b); }
+    s[0].v = pfast::fold(a);
+  }
+  for (int k = 0; k < 4; k++, r++) {
+    for (int i = 0; i < 12; i++) s[i] = sbox7(s[i] + GF(rc[12 * r + i]));
+    mds_layer(s);
+  }
+}
+
 struct Digest {
   GF e[4];
   bool operator==(const Digest& o) const {
@@ -141,7 +184,7 @@ static inline Digest hash_no_pad(const GF* in, size_t n) {
   for (size_t off = 0; off < n; off += SPONGE_RATE) {
     size_t len = n - off < (size_t)SPONGE_RATE ? n - off : SPONGE_RATE;
     for (size_t i = 0; i < len; i++) st[i] = in[off + i];
-    poseidon_permute(st);
+    poseidon_permute_fast(st);
   }
   Digest d; for (int i = 0; i < 4; i++) d.e[i] = st[i];
   return d;
@@ -155,7 +198,7 @@ static inline Digest hash_or_noop(const GF* in, size_t n) {
 static inline Digest two_to_one(const Digest& l, const Digest& r) {
   PState st; for (auto& x : st) x = GF();
   for (int i = 0; i < 4; i++) { st[i] = l.e[i]; st[4 + i] = r.e[i]; }
-  poseidon_permute(st);
+  poseidon_permute_fast(st);
   Digest d; for (int i = 0; i < 4; i++) d.e[i] = st[i];
   return d;
 }

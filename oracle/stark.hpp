@@ -145,12 +145,16 @@ static inline FriOpenings to_fri_openings(const StarkOpeningSet& o) {
   return f;
 }
 
-struct StageTimer {  // ORC_TIMING=1 prints per-stage wall time to stderr
+// Per-stage wall times of the last prove() (read back through orc_last_stage_seconds; ORC_TIMING=1 also prints them).
+static inline std::vector<std::pair<std::string, double>>& stage_log() { static std::vector<std::pair<std::string, double>> v; return v; }
+struct StageTimer {
   bool on; std::chrono::steady_clock::time_point t;
-  StageTimer() : on(getenv("ORC_TIMING") != nullptr), t(std::chrono::steady_clock::now()) {}
+  StageTimer() : on(getenv("ORC_TIMING") != nullptr), t(std::chrono::steady_clock::now()) { stage_log().clear(); }
   void lap(const char* name) {
     auto n = std::chrono::steady_clock::now();
-    if (on) fprintf(stderr, "[oracle] %-22s %8.3f s\n", name, std::chrono::duration<double>(n - t).count());
+    const double s = std::chrono::duration<double>(n - t).count();
+    stage_log().emplace_back(name, s);
+    if (on) fprintf(stderr, "[oracle] %-22s %8.3f s\n", name, s);
     t = n;
   }
 };

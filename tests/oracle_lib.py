@@ -71,6 +71,13 @@ def poseidon_permute(state):
     return [int(x) for x in a]
 
 
+def poseidon_permute_fast(state):
+    """The oracle's sparse-partial-round form (used by its Merkle hashing); must equal poseidon_permute."""
+    a = np.array(state, dtype=np.uint64)
+    lib().orc_poseidon_permute_fast(ptr(a))
+    return [int(x) for x in a]
+
+
 def round_constants():
     a = np.zeros(360, dtype=np.uint64)
     lib().orc_poseidon_round_constants(ptr(a))
@@ -205,6 +212,19 @@ def prove(kind, num_io, trace, pi):
     words = np.ctypeslib.as_array(out, shape=(nw.value,)).copy()
     lib().orc_free(out)
     return words, secs.value
+
+
+def last_stage_seconds():
+    """{stage name: wall seconds} of the last prove() (bench.py cpu_baseline)."""
+    L = lib()
+    L.orc_last_stage_seconds.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double)]
+    out = {}
+    n = L.orc_last_stage_seconds(-1, None, None)
+    for k in range(n):
+        name, secs = C.c_char_p(), C.c_double()
+        L.orc_last_stage_seconds(k, C.byref(name), C.byref(secs))
+        out[name.value.decode()] = secs.value
+    return out
 
 
 def set_final_poly_times_x(on):

@@ -30,6 +30,19 @@ def test_poseidon_round_constants_and_kats(O, golden):
         assert out == [int(x, 16) for x in v["output"]]
 
 
+def test_poseidon_fast_form_equals_definition(O, golden):
+    """The oracle hashes Merkle leaves with the sparse-partial-round form of the permutation; it must be the same map as
+    the plain definition (which the KATs pin), on the KAT inputs, edge values and random states."""
+    import random
+    rnd = random.Random(7)
+    P = 0xFFFFFFFF00000001
+    states = [[int(x, 16) for x in v["input"]] for v in golden["poseidon_kat"]["vectors"]]
+    states += [[P - 1] * 12, [0] * 11 + [1], [0xFFFFFFFF] * 12, [0xFFFFFFFF00000000] * 12]
+    states += [[rnd.randrange(P) for _ in range(12)] for _ in range(200)]
+    for st in states:
+        assert O.poseidon_permute_fast(st) == O.poseidon_permute(st)
+
+
 def test_poseidon_constants_independent_derivation(O):
     """tools/_chacha8.py (python) and oracle/poseidon.hpp (C++) derive the same 360 constants."""
     import os, sys

@@ -243,6 +243,8 @@ def test_generated_tables_and_instruction_streams_are_current(tmp_path):
     assert sorted(f for f in os.listdir(csrc) if f.endswith(".inc")) == produced
     for f in produced:
         assert open(os.path.join(tmp_path, f)).read() == open(os.path.join(csrc, f)).read(), f
+    for f in ("poseidon_eff_consts.inc", "poseidon_fast_consts.inc"):       # the oracle's own copies of the sparse-round tables
+        assert open(os.path.join(tmp_path, f)).read() == open(os.path.join(ROOT, "oracle", f)).read(), f
 
 
 
