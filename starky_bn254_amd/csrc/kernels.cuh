@@ -594,6 +594,7 @@ struct QuotientParams {
   // (j << row_shift) | row_rho (tables xs / lag_* / zh_inv are indexed by the LDE point), its next row is local row
   // (j + next_step) mod m of lde_next / zlde_next.
   const u64* lde_next; const u64* zlde_next; u32 row_shift, row_rho;
+  u32 swizzle;      // 1: 1-D grid, the four segments of a 256-point block run back to back on one XCD (see quotient_kernel)
   const u64* xs; const u64* lag_first; const u64* lag_last;  // per LDE point
   u64 zh_inv[2];   // 1/Z_H on the two residues of i mod 2
   u64 last;        // g^-1
@@ -617,9 +618,16 @@ struct QuotientParams {
 static constexpr u32 QSEG = 4;
 template <int KIND>
 __global__ __launch_bounds__(256) void quotient_kernel(QuotientParams p) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // Workgroup ids go round-robin over the 8 XCDs (each with its own L2).  With a (blocks, segment) grid the four segments
+  // of one 256-point block are dispatched a whole grid row apart and every one of them fetches its share of the LDE
+  // from HBM again (columns shared between segments, the rows i + 2 of the neighbour lines).  Swizzled: id = (bhi * 4 +
+  // segment) * 8 + xcd, block = bhi * 8 + xcd: the four segments of a block are 8 ids apart on the same XCD, so the second
+  // to fourth find the block's lines in that XCD's L2.
+  u32 seg = blockIdx.y;
+  size_t blk = blockIdx.x;
+  if (p.swizzle) { const u32 id = blockIdx.x, t = id >> 3; seg = t & (QSEG - 1); blk = (size_t)(t >> 2) * 8 + (id & 7); }
+  size_t i = blk * blockDim.x + threadIdx.x;
   if (i >= p.m) return;
-  const u32 seg = blockIdx.y;
   size_t inext = (i + p.next_step) & (p.m - 1);
   const size_t ig = (i << p.row_shift) | p.row_rho;   // LDE point of local row i
   Cons<F> cs;

@@ -983,7 +983,9 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
       const u64 after[4] = {n_tail + 2 * (u64)Z, 2 * (u64)Z, (u64)Z - (u64)qp.zsplit, 0};
       for (int sgm = 0; sgm < 4; sgm++) for (int j = 0; j < SBN_NCH; j++) qp.seg_shift[sgm][j] = f_pow(alphas[j], after[sgm]).v;
     }
-    const dim3 qgrid((unsigned)((qp.m + 255) / 256), QSEG);
+    const size_t qblocks = (qp.m + 255) / 256;
+    { const char* e = getenv("SBN_QUOTIENT_SWIZZLE"); qp.swizzle = (qblocks % 8 == 0 && !(e && e[0] == '0')) ? 1 : 0; }
+    const dim3 qgrid = qp.swizzle ? dim3((unsigned)(qblocks * QSEG), 1) : dim3((unsigned)qblocks, QSEG);
     if (P->air.kind == SBN_AIR_G1_OP) hipLaunchKernelGGL(quotient_kernel<1>, qgrid, dim3(256), 0, st, qp);
     else if (P->air.kind == SBN_AIR_G1_EXP) hipLaunchKernelGGL(quotient_kernel<2>, qgrid, dim3(256), 0, st, qp);
     else if (P->air.kind == SBN_AIR_G2_EXP) hipLaunchKernelGGL(quotient_kernel<3>, qgrid, dim3(256), 0, st, qp);
