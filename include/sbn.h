@@ -223,6 +223,12 @@ int sbn_poseidon_permute_batch(uint64_t* states, size_t count);
 /* The host permutation behind the Fiat-Shamir transcript of prove()/verify() (plonky2 Challenger's
  * PoseidonPermutation): sparse partial rounds, or the plain definition when use_definition != 0.  Host only. */
 int sbn_poseidon_permute_host(uint64_t* states, size_t count, int use_definition);
+/* The table's AIR constraints (eval_packed_generic of the table, e.g. src/curves/g1/exp.rs:331-495; no permutation checks)
+ * folded into the num_challenges = 2 accumulators acc_j = sum_t c_t alpha_j^(n-1-t) on ONE row pair over the base field:
+ * the regrouped evaluator the quotient kernel runs, on the host.  local_row / next_row: [num_columns]; z_last = x - g^-1,
+ * l_first / l_last = the Lagrange selectors at the point (starky ConstraintConsumer).  Host only. */
+int sbn_eval_constraints_host(const sbn_air_desc* air, const uint64_t* local_row, const uint64_t* next_row, const uint64_t* public_inputs,
+                              size_t n_pi, const uint64_t* alphas, uint64_t z_last, uint64_t l_first, uint64_t l_last, uint64_t* acc_out);
 
 #ifdef __cplusplus
 }

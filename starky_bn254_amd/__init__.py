@@ -7,5 +7,5 @@ symbol table can be checked), but every prove()/commit call fails loudly without
 from .api import (  # noqa: F401
     AIR_G1_OP, AIR_G1_EXP, AIR_G2_EXP, AIR_FQ12_EXP, AIR_FQ_EXP, AIR_FQ12_EXP_U64, SbnError, StarkConfig, G1Stark, G1ExpStark, G2ExpStark, Fq12ExpStark,
     FqExpStark, Fq12ExpU64Stark, Prover, BatchProver, Proof,
-    prove, verify_stark_proof, commit_values, poseidon_permute_batch, poseidon_permute_host, lib, lib_path, EXPORTS,
+    prove, verify_stark_proof, commit_values, eval_constraints_host, poseidon_permute_batch, poseidon_permute_host, lib, lib_path, EXPORTS,
 )

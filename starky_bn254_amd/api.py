@@ -32,7 +32,7 @@ EXPORTS = [
     "sbn_batch_prover_create", "sbn_batch_prover_prove_ios", "sbn_batch_prover_destroy",
     "sbn_prove", "sbn_proof_num_words", "sbn_proof_words", "sbn_proof_serialize", "sbn_proof_degree_bits",
     "sbn_proof_free", "sbn_verify", "sbn_commit_values", "sbn_poseidon_permute_batch", "sbn_poseidon_permute_host",
-    "sbn_split_exchange_bytes", "sbn_split_prover_create", "sbn_split_prover_destroy", "sbn_split_prover_generate_trace",
+    "sbn_eval_constraints_host", "sbn_split_exchange_bytes", "sbn_split_prover_create", "sbn_split_prover_destroy", "sbn_split_prover_generate_trace",
     "sbn_split_prover_load_trace", "sbn_split_prover_prove", "sbn_split_prover_stage_times",
 ]
 
@@ -476,6 +476,20 @@ def poseidon_permute_batch(states):
     s = np.ascontiguousarray(states, dtype=np.uint64).copy()
     _check(lib().sbn_poseidon_permute_batch(_ptr(s), s.shape[0]))
     return s
+
+
+def eval_constraints_host(stark, local_row, next_row, public_inputs, alphas, z_last, l_first, l_last):
+    """The table's AIR constraints folded into the two Horner accumulators on one row pair (host, base field)."""
+    lv = np.ascontiguousarray(local_row, dtype=np.uint64)
+    nv = np.ascontiguousarray(next_row, dtype=np.uint64)
+    pi = np.ascontiguousarray(public_inputs, dtype=np.uint64)
+    al = np.array(alphas, dtype=np.uint64)
+    acc = np.zeros(2, dtype=np.uint64)
+    L = lib()
+    L.sbn_eval_constraints_host.argtypes = [C.POINTER(_AirDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint64, C.c_uint64,
+                                            C.c_uint64, C.c_void_p]
+    _check(L.sbn_eval_constraints_host(C.byref(stark._d), _ptr(lv), _ptr(nv), _ptr(pi), len(pi), _ptr(al), z_last, l_first, l_last, _ptr(acc)))
+    return [int(x) for x in acc]
 
 
 def poseidon_permute_host(states, use_definition=False):

@@ -74,22 +74,66 @@ static constexpr int SGN_Z = GB + 317, SGN_X = GB + 318, SGN_Y = GB + 319;
 static constexpr int END = GB + 320;  // 384
 }  // namespace g1c
 
-// eval_packed_generic_addcy (src/modular/addcy.rs:16-58) for `modulus + out_aux_red = output + 2^256`,
-// followed by the quot_sign^2 = 1 constraint (modular.rs:123): 34 constraints, filter factored out.
+// ---- One challenge at a time: the modular gadgets in FACTORED form ----------------------------------------------------
+// A modular gadget (modular.rs:102-153, modular_zero.rs:82-120) ends with 32 coefficient constraints
+//     coef_k = sign * (quot * modulus)_k + ((x - beta) * aux)_k + [k < 16] lin_k - conv_k,        k = 0..31,
+// where conv = a limb convolution such as lambda * (x2 - x1) (pol_mul_wide, 16 x 16 limbs, 31 coefficients).  The
+// consumer folds them as sum_k alpha^(31-k) coef_k, and a Horner-weighted sum of CONVOLUTION coefficients factors:
+//     sum_{k<=30} alpha^(30-k) sum_{i+j=k} a_i b_j = (sum_i a_i alpha^(15-i)) * (sum_j b_j alpha^(15-j)) = rev(a) * rev(b),
+// rev(v) being the Horner fold of the limbs of v in column order.  Likewise the quotient part is rev17(quot) * rev16(m)
+// and the (x - beta) * aux part is (1 - 2^16 alpha) * rev31(aux).  So the 32 constraints cost a few dot products with
+// powers of alpha instead of 16 x 16 limb products per convolution -- the SAME field element (exact arithmetic, only
+// distributivity is used; no inverse of alpha, so alpha = 0 is fine too), 7 convolutions x 256 multiplies -> ~100 for the
+// G1 gadget, 2 x 144 x 256 -> ~600 for Fq12, and every limb column is read once per challenge instead of once per
+// coefficient it contributes to (the quotient kernel's first segment moved 3.0 GB for 0.45 GB of columns before).
+// tests/test_product_host.py::test_regrouped_constraints_equal_the_oracle_on_random_rows compares with the oracle's
+// constraint-by-constraint fold on random rows.
 template <class P, class Row>
-GL_HD void modop_prefix(const Cons<P>& cs, const Row& row, int oar_col, int out_col, int sign_col, Horner2<P>& h) {
+GL_HD P rev_limbs(const Cons<P>& cs, const Row& row, int j, int col, int n) {   // sum_i row[col + i] alpha_j^(n-1-i)
+  // as a dot product with the alpha-power table (uniform index: scalar loads), not as a Horner chain: the products are
+  // independent, so a lane has several multiplies in flight instead of one 16-deep dependent chain
+  const P* ap = cs.apow[j];
+  P h = row.l(col + n - 1);
+  for (int i = 0; i < n - 1; i++) h = h + row.l(col + i) * ap[n - 1 - i];
+  return h;
+}
+template <class P>
+GL_HD P rev_modulus(const Cons<P>& cs, int j) {   // sum_i m_i alpha_j^(15-i), m = the BN254 base-field modulus in 16-bit limbs
+  P h = lift<P>(bn254_modulus_limb(0));
+  for (int i = 1; i < 16; i++) h = h * cs.alpha[j] + lift<P>(bn254_modulus_limb(i));
+  return h;
+}
+// Local Horner sum (challenge j) of the 34 leading constraints of eval_modular_op: eval_packed_generic_addcy
+// (src/modular/addcy.rs:16-58) for `modulus + out_aux_red = output + 2^256`, then quot_sign^2 = 1 (modular.rs:123);
+// `h` is the sum so far.
+template <class P, class Row>
+GL_HD P modop_prefix(const Cons<P>& cs, const Row& row, int j, int oar_col, int out_col, P sign, P h) {
   const P overflow = lift<P>(65536), overflow_inv = lift<P>(18446462594437939201ULL), one = lift<P>(1);
+  const P al = cs.alpha[j];
   P cy = lift<P>(0);
   for (int i = 0; i < 16; i++) {
     P t = cy + lift<P>(bn254_modulus_limb(i)) + row.l(oar_col + i) - row.l(out_col + i);
-    h.push(cs, t * (overflow - t));
+    h = h * al + t * (overflow - t);
     cy = t * overflow_inv;
   }
-  h.push(cs, lift<P>(0));  // given_cy[0]*(given_cy[0]-1) with given_cy[0] = 1
-  h.push(cs, cy - one);    // cy == given_cy[0]
-  h.shift(cs, 15);         // given_cy[1..16] = 0
-  P s = row.l(sign_col);
-  h.push(cs, s * s - one);
+  h = h * al;                     // given_cy[0]*(given_cy[0]-1) with given_cy[0] = 1
+  h = h * al + (cy - one);        // cy == given_cy[0]
+  h = h * cs.apow[j][15];         // given_cy[1..16] = 0
+  return h * al + (sign * sign - one);
+}
+// Horner-weighted sum over the 32 coefficient constraints of  sign * (quot * modulus)_k + ((x - beta) * aux)_k :
+// quot_abs at qa_col (17 limbs), aux_lo / aux_hi (31 limbs each; aux = lo - 2^29 + 2^16 hi, modular.rs:118-121).
+template <class P, class Row>
+GL_HD P modop_tail(const Cons<P>& cs, const Row& row, int j, int qa_col, int lo_col, int hi_col, P sign, P mrev) {
+  const P base = lift<P>(65536), off = lift<P>(1ULL << 29), one = lift<P>(1);
+  const P al = cs.alpha[j];
+  P q = rev_limbs(cs, row, j, qa_col, 17);
+  // rev31(aux) = rev31(lo) + 2^16 rev31(hi) - 2^29 (1 + alpha + ... + alpha^30), again as dot products
+  const P* ap = cs.apow[j];
+  P ulo = row.l(lo_col + 30), uhi = row.l(hi_col + 30), geo = one;
+  for (int k = 0; k < 30; k++) { ulo = ulo + row.l(lo_col + k) * ap[30 - k]; uhi = uhi + row.l(hi_col + k) * ap[30 - k]; geo = geo + ap[30 - k]; }
+  const P u = ulo + base * uhi - off * geo;
+  return sign * q * mrev + (one - base * al) * u;
 }
 
 // Both eval_g1_add (muladd.rs:179-230) and eval_g1_double (:291-342) on the same row.
@@ -97,73 +141,25 @@ GL_HD void modop_prefix(const Cons<P>& cs, const Row& row, int oar_col, int out_
 template <class P, class Row>
 GL_HD void g1_gadget(const Cons<P>& cs, const Row& row, P* h_add, P* h_dbl) {
   using namespace g1c;
-  const P one = lift<P>(1), base = lift<P>(65536), off = lift<P>(1ULL << 29);
-  const P two = lift<P>(2), three = lift<P>(3);
-  // modular_zero prefix: quot_sign_zero^2 - 1   (modular_zero.rs:91)
-  Horner2<P> hza, hzd, hxa, hxd, hy;
-  P sz = row.l(SGN_Z), sx = row.l(SGN_X), sy = row.l(SGN_Y);
-#pragma unroll
-  for (int j = 0; j < SBN_NCH; j++) { hza.h[j] = sz * sz - one; hxa.h[j] = lift<P>(0); hy.h[j] = lift<P>(0); }
-  modop_prefix(cs, row, X_OAR, NX, SGN_X, hxa);
-  modop_prefix(cs, row, Y_OAR, NY, SGN_Y, hy);
-  hzd = hza; hxd = hxa;
-  P pz = lift<P>(0), px = lift<P>(0), py = lift<P>(0);  // previous aux coefficient of each gadget
-  for (int k = 0; k < 32; k++) {
-    // limb convolutions, coefficient k (pol_mul_wide, pol_utils.rs:221)
-    P c1 = lift<P>(0), c2 = c1, c3 = c1, c4 = c1, c5 = c1;
-    if (k < 31) {
-      int i0 = k > 15 ? k - 15 : 0, i1 = k < 15 ? k : 15;
-      for (int i = i0; i <= i1; i++) {
-        int j = k - i;
-        P li = row.l(LAM + i), axj = row.l(AX + j);
-        c1 += li * (row.l(BX + j) - axj);
-        c2 += li * row.l(AY + j);
-        c3 += row.l(AX + i) * axj;
-        c4 += li * row.l(LAM + j);
-        c5 += li * (axj - row.l(NX + j));
-      }
-    }
-    // quot(x) * modulus(x), coefficient k (pol_mul_wide2, pol_utils.rs:274); quot = sign*quot_abs
-    P qz = lift<P>(0), qx = qz, qy = qz;
-    {
-      int i0 = k > 15 ? k - 15 : 0, i1 = k < 16 ? k : 16;
-      for (int i = i0; i <= i1; i++) {
-        P m = lift<P>(bn254_modulus_limb(k - i));
-        qz += row.l(Z_QA + i) * m;
-        qx += row.l(X_QA + i) * m;
-        qy += row.l(Y_QA + i) * m;
-      }
-    }
-    // (x - beta) * aux(x), coefficient k (pol_adjoin_root, pol_utils.rs:348); aux_31 = 0
-    P az = lift<P>(0), ax_ = az, ay_ = az;
-    if (k < 31) {
-      az = row.l(Z_LO + k) - off + base * row.l(Z_HI + k);
-      ax_ = row.l(X_LO + k) - off + base * row.l(X_HI + k);
-      ay_ = row.l(Y_LO + k) - off + base * row.l(Y_HI + k);
-    }
-    P adjz = pz - base * az, adjx = px - base * ax_, adjy = py - base * ay_;
-    pz = az; px = ax_; py = ay_;
-    P zk = sz * qz + adjz;
-    P xk = sx * qx + adjx;
-    P yk = sy * qy + adjy - c5;
-    P za = zk - c1, zd = zk - (two * c2 - three * c3);
-    P xa = xk - c4, xd = xa;
-    if (k < 16) {
-      P axk = row.l(AX + k), ayk = row.l(AY + k), bxk = row.l(BX + k), nxk = row.l(NX + k);
-      za = za + (row.l(BY + k) - ayk);  // zero_pol = lambda*dx - dy
-      xa = xa + nxk + (axk + bxk);      // input = lambda^2 - (x1 + x2)
-      xd = xd + nxk + (axk + axk);
-      yk = yk + row.l(NY + k) + ayk;    // input = lambda*(x1 - new_x) - y1
-    }
-    hza.push(cs, za); hzd.push(cs, zd);
-    hxa.push(cs, xa); hxd.push(cs, xd);
-    hy.push(cs, yk);
-  }
-#pragma unroll
+  const P one = lift<P>(1), two = lift<P>(2), three = lift<P>(3);
+  const P sz = row.l(SGN_Z), sx = row.l(SGN_X), sy = row.l(SGN_Y);
   for (int j = 0; j < SBN_NCH; j++) {
-    P a132 = cs.apow[j][132], a66 = cs.apow[j][66];
-    h_add[j] = hza.h[j] * a132 + hxa.h[j] * a66 + hy.h[j];
-    h_dbl[j] = hzd.h[j] * a132 + hxd.h[j] * a66 + hy.h[j];
+    const P al = cs.alpha[j], a16 = cs.apow[j][16], a32 = cs.apow[j][32], mrev = rev_modulus(cs, j);
+    const P L = rev_limbs(cs, row, j, LAM, 16), ax = rev_limbs(cs, row, j, AX, 16), ay = rev_limbs(cs, row, j, AY, 16);
+    const P bx = rev_limbs(cs, row, j, BX, 16), by = rev_limbs(cs, row, j, BY, 16), nx = rev_limbs(cs, row, j, NX, 16), ny = rev_limbs(cs, row, j, NY, 16);
+    const P tz = modop_tail(cs, row, j, Z_QA, Z_LO, Z_HI, sz, mrev);
+    const P tx = modop_tail(cs, row, j, X_QA, X_LO, X_HI, sx, mrev);
+    const P ty = modop_tail(cs, row, j, Y_QA, Y_LO, Y_HI, sy, mrev);
+    // zero_pol = lambda*dx - dy (add) / 2*lambda*y - 3*x^2 (double); x: lambda^2 - (x1 + x2); y: lambda*(x1 - new_x) - y1
+    const P pz = (sz * sz - one) * a32;       // modular_zero prefix: quot_sign_zero^2 - 1 (modular_zero.rs:91), then 32 coefficients
+    const P za = pz + tz - al * (L * (bx - ax)) + a16 * (by - ay);
+    const P zd = pz + tz - al * (two * (L * ay) - three * (ax * ax));
+    const P px = modop_prefix(cs, row, j, X_OAR, NX, sx, lift<P>(0)) * a32 + tx - al * (L * L);
+    const P xa = px + a16 * (nx + ax + bx), xd = px + a16 * (nx + ax + ax);
+    const P y = modop_prefix(cs, row, j, Y_OAR, NY, sy, lift<P>(0)) * a32 + ty - al * (L * (ax - nx)) + a16 * (ny + ay);
+    const P a132 = cs.apow[j][132], a66 = cs.apow[j][66];
+    h_add[j] = za * a132 + xa * a66 + y;
+    h_dbl[j] = zd * a132 + xd * a66 + y;
   }
 }
 static constexpr int G1_GADGET_CONSTRAINTS = 165;
@@ -280,82 +276,42 @@ static constexpr int SGN_Z = GB + 634, SGN_X = GB + 636, SGN_Y = GB + 638;
 template <class P, class Row>
 GL_HD void g2_gadget(const Cons<P>& cs, const Row& row, P* h_add, P* h_dbl) {
   using namespace g2c;
-  const P one = lift<P>(1), base = lift<P>(65536), off = lift<P>(1ULL << 29), zero = lift<P>(0);
-  const P two = lift<P>(2), three = lift<P>(3);
-  Horner2<P> hza[2], hzd[2], hxa[2], hxd[2], hy[2];
+  const P one = lift<P>(1), zero = lift<P>(0), two = lift<P>(2), three = lift<P>(3);
   P sz[2], sx[2], sy[2];
-  for (int c = 0; c < 2; c++) {
-    sz[c] = row.l(SGN_Z + c); sx[c] = row.l(SGN_X + c); sy[c] = row.l(SGN_Y + c);
-#pragma unroll
-    for (int j = 0; j < SBN_NCH; j++) { hza[c].h[j] = sz[c] * sz[c] - one; hxa[c].h[j] = zero; hy[c].h[j] = zero; }
-    modop_prefix(cs, row, x_base(c), NX + 16 * c, SGN_X + c, hxa[c]);
-    modop_prefix(cs, row, y_base(c), NY + 16 * c, SGN_Y + c, hy[c]);
-    hzd[c] = hza[c]; hxd[c] = hxa[c];
-  }
-  P pz[2] = {zero, zero}, px[2] = {zero, zero}, py[2] = {zero, zero};
-  for (int k = 0; k < 32; k++) {
-    P c1[2] = {zero, zero}, c2[2] = {zero, zero}, c3[2] = {zero, zero}, c4[2] = {zero, zero}, c5[2] = {zero, zero};
-    if (k < 31) {
-      int i0 = k > 15 ? k - 15 : 0, i1 = k < 15 ? k : 15;
-      for (int i = i0; i <= i1; i++) {
-        int j = k - i;
-        P l0 = row.l(LAM + i), l1 = row.l(LAM + 16 + i);
-        P ax0 = row.l(AX + j), ax1 = row.l(AX + 16 + j);
-        P d0 = row.l(BX + j) - ax0, d1 = row.l(BX + 16 + j) - ax1;        // delta_x
-        P y0 = row.l(AY + j), y1 = row.l(AY + 16 + j);
-        P m0 = row.l(LAM + j), m1 = row.l(LAM + 16 + j);
-        P e0 = ax0 - row.l(NX + j), e1 = ax1 - row.l(NX + 16 + j);         // x1 - new_x
-        P xi0 = row.l(AX + i), xi1 = row.l(AX + 16 + i);
-        c1[0] += l0 * d0 - l1 * d1;  c1[1] += l0 * d1 + l1 * d0;
-        c2[0] += l0 * y0 - l1 * y1;  c2[1] += l0 * y1 + l1 * y0;
-        c3[0] += xi0 * ax0 - xi1 * ax1;  c3[1] += xi0 * ax1 + xi1 * ax0;
-        c4[0] += l0 * m0 - l1 * m1;  c4[1] += l0 * m1 + l1 * m0;
-        c5[0] += l0 * e0 - l1 * e1;  c5[1] += l0 * e1 + l1 * e0;
-      }
-    }
-    P qz[2] = {zero, zero}, qx[2] = {zero, zero}, qy[2] = {zero, zero};
-    {
-      int i0 = k > 15 ? k - 15 : 0, i1 = k < 16 ? k : 16;
-      for (int i = i0; i <= i1; i++) {
-        P m = lift<P>(bn254_modulus_limb(k - i));
-        for (int c = 0; c < 2; c++) {
-          qz[c] += row.l(z_qa(c) + i) * m;
-          qx[c] += row.l(x_base(c) + 16 + i) * m;
-          qy[c] += row.l(y_base(c) + 16 + i) * m;
-        }
-      }
-    }
-    for (int c = 0; c < 2; c++) {
-      P az = zero, ax_ = zero, ay_ = zero;
-      if (k < 31) {
-        az = row.l(z_qa(c) + 17 + k) - off + base * row.l(z_qa(c) + 48 + k);
-        ax_ = row.l(x_base(c) + 33 + k) - off + base * row.l(x_base(c) + 64 + k);
-        ay_ = row.l(y_base(c) + 33 + k) - off + base * row.l(y_base(c) + 64 + k);
-      }
-      P adjz = pz[c] - base * az, adjx = px[c] - base * ax_, adjy = py[c] - base * ay_;
-      pz[c] = az; px[c] = ax_; py[c] = ay_;
-      P zk = sz[c] * qz[c] + adjz;
-      P xk = sx[c] * qx[c] + adjx;
-      P yk = sy[c] * qy[c] + adjy - c5[c];
-      P za = zk - c1[c], zd = zk - (two * c2[c] - three * c3[c]);
-      P xa = xk - c4[c], xd = xa;
-      if (k < 16) {
-        P axk = row.l(AX + 16 * c + k), ayk = row.l(AY + 16 * c + k), bxk = row.l(BX + 16 * c + k), nxk = row.l(NX + 16 * c + k);
-        za = za + (row.l(BY + 16 * c + k) - ayk);
-        xa = xa + nxk + (axk + bxk);
-        xd = xd + nxk + (axk + axk);
-        yk = yk + row.l(NY + 16 * c + k) + ayk;
-      }
-      hza[c].push(cs, za); hzd[c].push(cs, zd);
-      hxa[c].push(cs, xa); hxd[c].push(cs, xd);
-      hy[c].push(cs, yk);
-    }
-  }
-#pragma unroll
+  for (int c = 0; c < 2; c++) { sz[c] = row.l(SGN_Z + c); sx[c] = row.l(SGN_X + c); sy[c] = row.l(SGN_Y + c); }
   for (int j = 0; j < SBN_NCH; j++) {
+    const P al = cs.alpha[j], a16 = cs.apow[j][16], a32 = cs.apow[j][32], mrev = rev_modulus(cs, j);
+    P L[2], ax[2], ay[2], bx[2], by[2], nx[2], ny[2];
+    for (int c = 0; c < 2; c++) {
+      L[c] = rev_limbs(cs, row, j, LAM + 16 * c, 16); ax[c] = rev_limbs(cs, row, j, AX + 16 * c, 16); ay[c] = rev_limbs(cs, row, j, AY + 16 * c, 16);
+      bx[c] = rev_limbs(cs, row, j, BX + 16 * c, 16); by[c] = rev_limbs(cs, row, j, BY + 16 * c, 16);
+      nx[c] = rev_limbs(cs, row, j, NX + 16 * c, 16); ny[c] = rev_limbs(cs, row, j, NY + 16 * c, 16);
+    }
+    // Fq2 limb products (fq2.rs:41-58) at the level of the reversed evaluations
+    const P d0 = bx[0] - ax[0], d1 = bx[1] - ax[1], e0 = ax[0] - nx[0], e1 = ax[1] - nx[1];
+    const P c1[2] = {L[0] * d0 - L[1] * d1, L[0] * d1 + L[1] * d0};              // lambda * delta_x
+    const P c2[2] = {L[0] * ay[0] - L[1] * ay[1], L[0] * ay[1] + L[1] * ay[0]};  // lambda * y1
+    const P x01 = ax[0] * ax[1];
+    const P c3[2] = {ax[0] * ax[0] - ax[1] * ax[1], x01 + x01};                   // x1^2
+    const P l01 = L[0] * L[1];
+    const P c4[2] = {L[0] * L[0] - L[1] * L[1], l01 + l01};                       // lambda^2
+    const P c5[2] = {L[0] * e0 - L[1] * e1, L[0] * e1 + L[1] * e0};              // lambda * (x1 - new_x)
+    P za[2], zd[2], xa[2], xd[2], y[2];
+    for (int c = 0; c < 2; c++) {
+      const P tz = modop_tail(cs, row, j, z_qa(c), z_qa(c) + 17, z_qa(c) + 48, sz[c], mrev);
+      const P tx = modop_tail(cs, row, j, x_base(c) + 16, x_base(c) + 33, x_base(c) + 64, sx[c], mrev);
+      const P ty = modop_tail(cs, row, j, y_base(c) + 16, y_base(c) + 33, y_base(c) + 64, sy[c], mrev);
+      const P pz = (sz[c] * sz[c] - one) * a32;
+      za[c] = pz + tz - al * c1[c] + a16 * (by[c] - ay[c]);
+      zd[c] = pz + tz - al * (two * c2[c] - three * c3[c]);
+      const P px = modop_prefix(cs, row, j, x_base(c), NX + 16 * c, sx[c], zero) * a32 + tx - al * c4[c];
+      xa[c] = px + a16 * (nx[c] + ax[c] + bx[c]);
+      xd[c] = px + a16 * (nx[c] + ax[c] + ax[c]);
+      y[c] = modop_prefix(cs, row, j, y_base(c), NY + 16 * c, sy[c], zero) * a32 + ty - al * c5[c] + a16 * (ny[c] + ay[c]);
+    }
     const P* ap = cs.apow[j];
-    h_add[j] = hza[0].h[j] * ap[297] + hza[1].h[j] * ap[264] + hxa[0].h[j] * ap[198] + hxa[1].h[j] * ap[132] + hy[0].h[j] * ap[66] + hy[1].h[j];
-    h_dbl[j] = hzd[0].h[j] * ap[297] + hzd[1].h[j] * ap[264] + hxd[0].h[j] * ap[198] + hxd[1].h[j] * ap[132] + hy[0].h[j] * ap[66] + hy[1].h[j];
+    h_add[j] = za[0] * ap[297] + za[1] * ap[264] + xa[0] * ap[198] + xa[1] * ap[132] + y[0] * ap[66] + y[1];
+    h_dbl[j] = zd[0] * ap[297] + zd[1] * ap[264] + xd[0] * ap[198] + xd[1] * ap[132] + y[0] * ap[66] + y[1];
   }
 }
 
@@ -373,63 +329,37 @@ static constexpr int A = 0, B = 192, OUT = 384, AUX = 576, SGN = 576 + 12 * 95;
 template <class P, class Row>
 GL_HD void fq12_gadget(const Cons<P>& cs, const Row& row, P* h_sq, P* h_mul) {
   using namespace f12c;
-  const P base = lift<P>(65536), off = lift<P>(1ULL << 29), zero = lift<P>(0), nine = lift<P>(9);
-#pragma unroll
-  for (int j = 0; j < SBN_NCH; j++) { h_sq[j] = zero; h_mul[j] = zero; }
-  for (int m = 0; m < 6; m++) {
-    Horner2<P> hs[2], hm[2];
-    P sgn[2], pa[2] = {zero, zero};
-    for (int q = 0; q < 2; q++) {
-      int c = m + 6 * q;
-#pragma unroll
-      for (int j = 0; j < SBN_NCH; j++) hs[q].h[j] = zero;
-      modop_prefix(cs, row, AUX + 95 * c, OUT + 16 * c, SGN + c, hs[q]);
-      hm[q] = hs[q];
-      sgn[q] = row.l(SGN + c);
-    }
-    for (int k = 0; k < 32; k++) {
+  const P zero = lift<P>(0), nine = lift<P>(9);
+  for (int j = 0; j < SBN_NCH; j++) {
+    const P al = cs.alpha[j], a16 = cs.apow[j][16], a32 = cs.apow[j][32], mrev = rev_modulus(cs, j);
+    P ar[12], br[12];   // reversed evaluations of the 12 + 12 coefficient limb vectors
+    for (int i = 0; i < 12; i++) { ar[i] = rev_limbs(cs, row, j, A + 16 * i, 16); br[i] = rev_limbs(cs, row, j, B + 16 * i, 16); }
+    P hs = zero, hm = zero;
+    for (int m = 0; m < 6; m++) {
+      // pol_mul_fq12 (mul.rs:24-87) on the evaluations: D[t] = sum_{i+j=t} (x_i y_j - x_{i+6} y_{j+6}), S[t] = sum (x_i y_{j+6} + x_{i+6} y_j)
       P ds = zero, ss = zero, ds6 = zero, ss6 = zero, dm = zero, sm = zero, dm6 = zero, sm6 = zero;
-      if (k < 31) {
-        int u0 = k > 15 ? k - 15 : 0, u1 = k < 15 ? k : 15;
-        for (int i = 0; i < 6; i++) {
-          int j = i <= m ? m - i : m + 6 - i;      // i + j = m  or  i + j = m + 6
-          bool wrap = i > m;
-          if (wrap && m == 5) continue;            // j would be 6: no such term
-          for (int u = u0; u <= u1; u++) {
-            int v = k - u;
-            P ai = row.l(A + 16 * i + u), ai6 = row.l(A + 16 * (i + 6) + u);
-            P aj = row.l(A + 16 * j + v), aj6 = row.l(A + 16 * (j + 6) + v);
-            P bj = row.l(B + 16 * j + v), bj6 = row.l(B + 16 * (j + 6) + v);
-            P d_s = ai * aj - ai6 * aj6, s_s = ai * aj6 + ai6 * aj;
-            P d_m = ai * bj - ai6 * bj6, s_m = ai * bj6 + ai6 * bj;
-            if (wrap) { ds6 += d_s; ss6 += s_s; dm6 += d_m; sm6 += s_m; }
-            else { ds += d_s; ss += s_s; dm += d_m; sm += s_m; }
-          }
-        }
+      for (int i = 0; i < 6; i++) {
+        const bool wrap = i > m;
+        if (wrap && m == 5) continue;            // i + j = 11 has no term with j < 6
+        const int t = wrap ? m + 6 - i : m - i;  // i + t = m  or  i + t = m + 6
+        const P d_s = ar[i] * ar[t] - ar[i + 6] * ar[t + 6], s_s = ar[i] * ar[t + 6] + ar[i + 6] * ar[t];
+        const P d_m = ar[i] * br[t] - ar[i + 6] * br[t + 6], s_m = ar[i] * br[t + 6] + ar[i + 6] * br[t];
+        if (wrap) { ds6 += d_s; ss6 += s_s; dm6 += d_m; sm6 += s_m; }
+        else { ds += d_s; ss += s_s; dm += d_m; sm += s_m; }
       }
-      P in_s[2] = {ds + nine * ds6 - ss6, ss + ds6 + nine * ss6};
-      P in_m[2] = {dm + nine * dm6 - sm6, sm + dm6 + nine * sm6};
+      const P in_s[2] = {ds + nine * ds6 - ss6, ss + ds6 + nine * ss6};
+      const P in_m[2] = {dm + nine * dm6 - sm6, sm + dm6 + nine * sm6};
       for (int q = 0; q < 2; q++) {
-        int c = m + 6 * q, ab = AUX + 95 * c;
-        P qv = zero;
-        int i0 = k > 15 ? k - 15 : 0, i1 = k < 16 ? k : 16;
-        for (int i = i0; i <= i1; i++) qv += row.l(ab + 16 + i) * lift<P>(bn254_modulus_limb(k - i));
-        P ax = zero;
-        if (k < 31) ax = row.l(ab + 33 + k) - off + base * row.l(ab + 64 + k);
-        P adj = pa[q] - base * ax;
-        pa[q] = ax;
-        P xk = sgn[q] * qv + adj;
-        if (k < 16) xk = xk + row.l(OUT + 16 * c + k);
-        hs[q].push(cs, xk - in_s[q]);
-        hm[q].push(cs, xk - in_m[q]);
+        const int c = m + 6 * q, ab = AUX + 95 * c;
+        const P sgn = row.l(SGN + c);
+        const P pre = modop_prefix(cs, row, j, ab, OUT + 16 * c, sgn, zero) * a32 + modop_tail(cs, row, j, ab + 16, ab + 33, ab + 64, sgn, mrev) +
+                      a16 * rev_limbs(cs, row, j, OUT + 16 * c, 16);
+        const P w = cs.apow[j][66 * (q ? 5 - m : 11 - m)];
+        hs = hs + (pre - al * in_s[q]) * w;
+        hm = hm + (pre - al * in_m[q]) * w;
       }
     }
-#pragma unroll
-    for (int j = 0; j < SBN_NCH; j++) {
-      P w0 = cs.apow[j][66 * (11 - m)], w1 = cs.apow[j][66 * (5 - m)];
-      h_sq[j] = h_sq[j] + hs[0].h[j] * w0 + hs[1].h[j] * w1;
-      h_mul[j] = h_mul[j] + hm[0].h[j] * w0 + hm[1].h[j] * w1;
-    }
+    h_sq[j] = hs; h_mul[j] = hm;
   }
 }
 
@@ -440,34 +370,15 @@ GL_HD void fq12_gadget(const Cons<P>& cs, const Row& row, P* h_sq, P* h_mul) {
 template <class P, class Row>
 GL_HD void fq_gadget(const Cons<P>& cs, const Row& row, P* h_sq, P* h_mul) {
   constexpr int A = 0, B = 16, OUT = 32, AUX = 48, SGN = 143;
-  const P base = lift<P>(65536), off = lift<P>(1ULL << 29), zero = lift<P>(0);
-  Horner2<P> hs, hm;
-#pragma unroll
-  for (int j = 0; j < SBN_NCH; j++) hs.h[j] = zero;
-  modop_prefix(cs, row, AUX, OUT, SGN, hs);
-  hm = hs;
   const P sgn = row.l(SGN);
-  P pa = zero;
-  for (int k = 0; k < 32; k++) {
-    P in_s = zero, in_m = zero;
-    if (k < 31) {
-      int u0 = k > 15 ? k - 15 : 0, u1 = k < 15 ? k : 15;
-      for (int u = u0; u <= u1; u++) { P au = row.l(A + u); in_s += au * row.l(A + k - u); in_m += au * row.l(B + k - u); }
-    }
-    P qv = zero;
-    int i0 = k > 15 ? k - 15 : 0, i1 = k < 16 ? k : 16;
-    for (int i = i0; i <= i1; i++) qv += row.l(AUX + 16 + i) * lift<P>(bn254_modulus_limb(k - i));
-    P ax = zero;
-    if (k < 31) ax = row.l(AUX + 33 + k) - off + base * row.l(AUX + 64 + k);
-    P adj = pa - base * ax;
-    pa = ax;
-    P xk = sgn * qv + adj;
-    if (k < 16) xk = xk + row.l(OUT + k);
-    hs.push(cs, xk - in_s);
-    hm.push(cs, xk - in_m);
+  for (int j = 0; j < SBN_NCH; j++) {
+    const P al = cs.alpha[j];
+    const P a = rev_limbs(cs, row, j, A, 16), b = rev_limbs(cs, row, j, B, 16);
+    const P pre = modop_prefix(cs, row, j, AUX, OUT, sgn, lift<P>(0)) * cs.apow[j][32] + modop_tail(cs, row, j, AUX + 16, AUX + 33, AUX + 64, sgn, rev_modulus(cs, j)) +
+                  cs.apow[j][16] * rev_limbs(cs, row, j, OUT, 16);
+    h_sq[j] = pre - al * (a * a);
+    h_mul[j] = pre - al * (a * b);
   }
-#pragma unroll
-  for (int j = 0; j < SBN_NCH; j++) { h_sq[j] = hs.h[j]; h_mul[j] = hm.h[j]; }
 }
 
 // ---- G1ExpStark / G2ExpStark (src/curves/g1/exp.rs, src/curves/g2/exp.rs) --------------------------------

@@ -594,7 +594,7 @@ struct QuotientParams {
   // (j << row_shift) | row_rho (tables xs / lag_* / zh_inv are indexed by the LDE point), its next row is local row
   // (j + next_step) mod m of lde_next / zlde_next.
   const u64* lde_next; const u64* zlde_next; u32 row_shift, row_rho;
-  u32 swizzle;      // 1: 1-D grid, the four segments of a 256-point block run back to back on one XCD (see quotient_kernel)
+  u32 seg_mask;     // segments whose kernels are launched (all four; a diagnostic switch for per-segment counter passes)
   const u64* xs; const u64* lag_first; const u64* lag_last;  // per LDE point
   u64 zh_inv[2];   // 1/Z_H on the two residues of i mod 2
   u64 last;        // g^-1
@@ -609,26 +609,26 @@ struct QuotientParams {
   int zsplit;       // permutation transition constraints [0, zsplit) go with segment 2, [zsplit, num_zs) with segment 3
 };
 
-// The constraint stream is one Horner sum in alpha, so it splits exactly.  grid.y = segment: 0 = AIR sections [1]-[8]
+// The constraint stream is one Horner sum in alpha, so it splits exactly into four segments: 0 = AIR sections [1]-[8]
 // (public inputs, transitions, flags, the add / double gadget), 1 = AIR sections [9]-[10] (io pulses, range check),
-// 2 = the permutation checks' first-row constraints and the first half of their transitions, 3 = the second half;
+// 2 = the permutation checks' first-row constraints and the first part of their transitions, 3 = the rest;
 // quotient_combine_kernel joins them as sum_s acc_s * alpha^(constraints after segment s).  With one lane per LDE point
-// there are only two waves per SIMD at 2^17 points; the split gives eight and quarters every lane's dependent chain
-// (2.65 -> 1.8 ms with two segments).
+// there are only two waves per SIMD at 2^17 points and one long dependent chain per lane (2.65 ms); four segments in
+// flight give eight waves and quarter the chain (1.56 ms).  Each PART is its own kernel (0: segment 0, 1: segment 1,
+// 2: segments 2 and 3 on grid.y) so that it gets its own register allocation -- as one kernel the gadget code of segment
+// 0 set the VGPR count, and with it the occupancy, of the permutation checks too -- and the prover launches PART 0 + 1
+// on its main stream and PART 2 on its second stream, so the parts still overlap.
+// Tried and measured (profiles/r2_quotient_ab.txt): an XCD-aware order that runs the four segments of a 256-point block
+// back to back on one XCD: traffic 7.50 -> 6.81 GB per launch but 1.56 -> 2.13 ms (tail imbalance); the re-reads were
+// not between segments but inside segment 0 (3.0 GB for 0.45 GB of columns: every limb re-read for each convolution
+// coefficient it feeds), which the factored gadgets of air.cuh removed (profiles/r2_quotient_segments.txt).
 static constexpr u32 QSEG = 4;
-template <int KIND>
+template <int KIND, int PART>
 __global__ __launch_bounds__(256) void quotient_kernel(QuotientParams p) {
-  // Workgroup ids go round-robin over the 8 XCDs (each with its own L2).  With a (blocks, segment) grid the four segments
-  // of one 256-point block are dispatched a whole grid row apart and every one of them fetches its share of the LDE
-  // from HBM again (columns shared between segments, the rows i + 2 of the neighbour lines).  Swizzled: id = (bhi * 4 +
-  // segment) * 8 + xcd, block = bhi * 8 + xcd: the four segments of a block are 8 ids apart on the same XCD, so the second
-  // to fourth find the block's lines in that XCD's L2.
-  u32 seg = blockIdx.y;
-  size_t blk = blockIdx.x;
-  if (p.swizzle) { const u32 id = blockIdx.x, t = id >> 3; seg = t & (QSEG - 1); blk = (size_t)(t >> 2) * 8 + (id & 7); }
-  size_t i = blk * blockDim.x + threadIdx.x;
-  if (i >= p.m) return;
-  size_t inext = (i + p.next_step) & (p.m - 1);
+  const u32 seg = PART == 2 ? 2 + blockIdx.y : (u32)PART;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p.m || !((p.seg_mask >> seg) & 1)) return;
+  const size_t inext = (i + p.next_step) & (p.m - 1);
   const size_t ig = (i << p.row_shift) | p.row_rho;   // LDE point of local row i
   Cons<F> cs;
 #pragma unroll
@@ -639,13 +639,15 @@ __global__ __launch_bounds__(256) void quotient_kernel(QuotientParams p) {
   DevRow row{p.lde, p.lde_next, p.m, i, inext};
   DevZRow zrow{p.zlde, p.zlde_next, p.m, i, inext};
   if (KIND == 1) {
-    if (seg == 0) g1op_eval(cs, row);
-    else if (seg == 2) permutation_checks(cs, row, zrow, G1OpShape(), p.num_zs, F(p.gamma0), F(p.gamma1), true, 0, p.zsplit);
-    else if (seg == 3) permutation_checks(cs, row, zrow, G1OpShape(), p.num_zs, F(p.gamma0), F(p.gamma1), false, p.zsplit, p.num_zs);
+    if (PART == 0) g1op_eval(cs, row);
+    else if (PART == 2) {
+      if (seg == 2) permutation_checks(cs, row, zrow, G1OpShape(), p.num_zs, F(p.gamma0), F(p.gamma1), true, 0, p.zsplit);
+      else permutation_checks(cs, row, zrow, G1OpShape(), p.num_zs, F(p.gamma0), F(p.gamma1), false, p.zsplit, p.num_zs);
+    }
   } else {
     constexpr int E = KIND == 4 ? 12 : (KIND == 6 ? 13 : (KIND == 3 ? 2 : (KIND == 5 ? 0 : 1)));
     ExpShape sh(E, p.num_io);
-    if (seg < 2) exp_eval<E>(cs, row, sh, (const ExpPiConsts<F>*)p.pic, 1 + (int)seg);
+    if (PART < 2) exp_eval<E>(cs, row, sh, (const ExpPiConsts<F>*)p.pic, 1 + PART);
     else if (seg == 2) permutation_checks(cs, row, zrow, sh, p.num_zs, F(p.gamma0), F(p.gamma1), true, 0, p.zsplit);
     else permutation_checks(cs, row, zrow, sh, p.num_zs, F(p.gamma0), F(p.gamma1), false, p.zsplit, p.num_zs);
   }

@@ -884,6 +884,27 @@ extern "C" int sbn_prover_stage_times(const sbn_prover* P, float* ms, int cap) {
 extern "C" const char* sbn_prover_stage_name(int i) { return (i >= 0 && i < ST_COUNT + EX_COUNT) ? STAGE_NAMES[i] : ""; }
 
 // ---- prove ----------------------------------------------------------------------------------------
+// quotient_kernel<KIND, PART>: PART 0 then 1 on the main stream, PART 2 (both permutation-check segments) on the second
+template <int KIND>
+static void launch_quotient_kind(sbn_prover* P, const QuotientParams& qp, size_t qblocks) {
+  const dim3 g1((unsigned)qblocks, 1), g2((unsigned)qblocks, 2);
+  if (qp.seg_mask & 12u) hipLaunchKernelGGL((quotient_kernel<KIND, 2>), g2, dim3(256), 0, P->hstream, qp);
+  if (qp.seg_mask & 1u) hipLaunchKernelGGL((quotient_kernel<KIND, 0>), g1, dim3(256), 0, P->stream, qp);
+  if (qp.seg_mask & 2u) hipLaunchKernelGGL((quotient_kernel<KIND, 1>), g1, dim3(256), 0, P->stream, qp);
+}
+static int launch_quotient_parts(sbn_prover* P, const QuotientParams& qp, size_t qblocks) {
+  switch (P->air.kind) {
+    case SBN_AIR_G1_OP: launch_quotient_kind<1>(P, qp, qblocks); break;
+    case SBN_AIR_G1_EXP: launch_quotient_kind<2>(P, qp, qblocks); break;
+    case SBN_AIR_G2_EXP: launch_quotient_kind<3>(P, qp, qblocks); break;
+    case SBN_AIR_FQ_EXP: launch_quotient_kind<5>(P, qp, qblocks); break;
+    case SBN_AIR_FQ12_EXP_U64: launch_quotient_kind<6>(P, qp, qblocks); break;
+    default: launch_quotient_kind<4>(P, qp, qblocks); break;
+  }
+  HIPC(hipGetLastError());
+  return 0;
+}
+
 extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
   if (!P || !out) return fail(SBN_ERR_BAD_ARG, "null argument");
   *out = nullptr;
@@ -984,14 +1005,14 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
       for (int sgm = 0; sgm < 4; sgm++) for (int j = 0; j < SBN_NCH; j++) qp.seg_shift[sgm][j] = f_pow(alphas[j], after[sgm]).v;
     }
     const size_t qblocks = (qp.m + 255) / 256;
-    { const char* e = getenv("SBN_QUOTIENT_SWIZZLE"); qp.swizzle = (qblocks % 8 == 0 && !(e && e[0] == '0')) ? 1 : 0; }
-    const dim3 qgrid = qp.swizzle ? dim3((unsigned)(qblocks * QSEG), 1) : dim3((unsigned)qblocks, QSEG);
-    if (P->air.kind == SBN_AIR_G1_OP) hipLaunchKernelGGL(quotient_kernel<1>, qgrid, dim3(256), 0, st, qp);
-    else if (P->air.kind == SBN_AIR_G1_EXP) hipLaunchKernelGGL(quotient_kernel<2>, qgrid, dim3(256), 0, st, qp);
-    else if (P->air.kind == SBN_AIR_G2_EXP) hipLaunchKernelGGL(quotient_kernel<3>, qgrid, dim3(256), 0, st, qp);
-    else if (P->air.kind == SBN_AIR_FQ_EXP) hipLaunchKernelGGL(quotient_kernel<5>, qgrid, dim3(256), 0, st, qp);
-    else if (P->air.kind == SBN_AIR_FQ12_EXP_U64) hipLaunchKernelGGL(quotient_kernel<6>, qgrid, dim3(256), 0, st, qp);
-    else hipLaunchKernelGGL(quotient_kernel<4>, qgrid, dim3(256), 0, st, qp);
+    { const char* e = getenv("SBN_DIAG_QUOTIENT_SEGMASK"); qp.seg_mask = e ? (u32)atoi(e) : 0xfu; }   // diagnostic only: the proof is invalid unless 15
+    if (qp.seg_mask != 0xfu) HIPC(hipMemsetAsync(qp.part, 0, (size_t)QSEG * SBN_NCH * qp.m * sizeof(u64), st));
+    // AIR head and tail on the main stream, the permutation checks beside them on the second stream (idle here)
+    HIPC(hipEventRecord(P->chunk_ready[3], st));
+    HIPC(hipStreamWaitEvent(P->hstream, P->chunk_ready[3], 0));
+    if ((rc = launch_quotient_parts(P, qp, qblocks))) return rc;
+    HIPC(hipEventRecord(P->hash_done, P->hstream));
+    HIPC(hipStreamWaitEvent(st, P->hash_done, 0));
     hipLaunchKernelGGL(quotient_combine_kernel, blocks(qp.m), dim3(256), 0, st, qp);
     HIPC(hipGetLastError());
     if (S) {

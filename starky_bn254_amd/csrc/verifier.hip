@@ -239,3 +239,47 @@ extern "C" int sbn_verify(const sbn_air_desc* air, const sbn_config* cfg, const 
   }
   return SBN_OK;
 }
+
+// Parity hook (include/sbn.h): the table's AIR constraints -- the regrouped templates of air.cuh, here over the base
+// field as in the quotient kernel -- folded into the two Horner accumulators on ONE (local, next) row pair.  No
+// permutation checks.  Host only; tests compare it with the oracle's constraint-by-constraint evaluation on random rows.
+namespace {
+struct HostRowF {
+  const u64* lv; const u64* nv;
+  F l(int c) const { return F(lv[c]); }
+  F n(int c) const { return F(nv[c]); }
+};
+}  // namespace
+extern "C" int sbn_eval_constraints_host(const sbn_air_desc* air, const uint64_t* local_row, const uint64_t* next_row, const uint64_t* public_inputs,
+                                         size_t n_pi, const uint64_t* alphas, uint64_t z_last, uint64_t l_first, uint64_t l_last, uint64_t* acc_out) {
+  if (!air || !local_row || !next_row || !alphas || !acc_out) return fail(SBN_ERR_BAD_ARG, "null argument");
+  AirShape as;
+  if (!air_shape(air, nullptr, as)) return fail(SBN_ERR_BAD_ARG, "unknown air kind / num_io");
+  if (n_pi != as.npi || (n_pi && !public_inputs)) return fail(SBN_ERR_BAD_ARG, "expected %zu public inputs", as.npi);
+  for (size_t c = 0; c < as.ncols; c++) if (local_row[c] >= GLP || next_row[c] >= GLP) return fail(SBN_ERR_NON_CANONICAL, "row word %zu is not canonical", c);
+  for (size_t i = 0; i < n_pi; i++) if (public_inputs[i] >= GLP) return fail(SBN_ERR_NON_CANONICAL, "public input %zu is not canonical", i);
+  if (z_last >= GLP || l_first >= GLP || l_last >= GLP || alphas[0] >= GLP || alphas[1] >= GLP) return fail(SBN_ERR_NON_CANONICAL, "non-canonical scalar");
+  Cons<F> cs;
+  std::vector<F> apow[SBN_NCH];
+  for (int j = 0; j < SBN_NCH; j++) {
+    apow[j].resize(apow_len(as.npi, as.nzs));
+    F a(1), al(alphas[j]);
+    for (size_t k = 0; k < apow[j].size(); k++) { apow[j][k] = a; a = a * al; }
+    cs.alpha[j] = al; cs.acc[j] = F(0); cs.apow[j] = apow[j].data();
+  }
+  cs.z_last = F(z_last); cs.l_first = F(l_first); cs.l_last = F(l_last);
+  HostRowF row{local_row, next_row};
+  if (as.kind == SBN_AIR_G1_OP) {
+    g1op_eval(cs, row);
+  } else {
+    ExpShape sh = exp_shape(as);
+    std::vector<F> fpi(n_pi); for (size_t i = 0; i < n_pi; i++) fpi[i] = F(public_inputs[i]);
+    static thread_local ExpPiConsts<F> pic;
+    const F* app[SBN_NCH] = {apow[0].data(), apow[1].data()};
+    exp_pi_consts<F>(sh, app, fpi.data(), pic);
+    if (sh.E == 1) exp_eval<1>(cs, row, sh, &pic); else if (sh.E == 2) exp_eval<2>(cs, row, sh, &pic); else if (sh.E == 0) exp_eval<0>(cs, row, sh, &pic);
+    else if (sh.E == 13) exp_eval<13>(cs, row, sh, &pic); else exp_eval<12>(cs, row, sh, &pic);
+  }
+  for (int j = 0; j < SBN_NCH; j++) acc_out[j] = cs.acc[j].v;
+  return SBN_OK;
+}

@@ -303,3 +303,32 @@ def test_rust_shim_declarations_match_the_header():
     at = [conv.index(s) for s in order]
     assert at == sorted(at)
     assert 'from_le_bytes(*b"SNBPROV1")' in conv and int.from_bytes(b"SNBPROV1", "little") == 0x31564F5250424E53
+
+
+@pytest.mark.parametrize("table,num_io", [("G1Stark", 0), ("G1ExpStark", 128), ("G2ExpStark", 128), ("Fq12ExpStark", 16), ("FqExpStark", 128),
+                                           ("Fq12ExpU64Stark", 16)])
+def test_regrouped_constraints_equal_the_oracle_on_random_rows(S, O, table, num_io):
+    """air.cuh folds the constraints in regrouped form (local Horner sums, shared and factored limb convolutions, collapsed
+    public-input block); the result must be the SAME field element as folding them one by one in the reference's order
+    (the oracle's restatement of eval_packed_generic) -- on arbitrary rows, not only on valid traces: random field
+    elements in every column, random public inputs, random challenges and selector values, several row pairs."""
+    stark = getattr(S, table)(num_io) if num_io else getattr(S, table)()
+    kind = {"G1Stark": O.AIR_G1_OP, "G1ExpStark": O.AIR_G1_EXP, "G2ExpStark": O.AIR_G2_EXP, "Fq12ExpStark": O.AIR_FQ12_EXP, "FqExpStark": O.AIR_FQ_EXP,
+            "Fq12ExpU64Stark": O.AIR_FQ12_EXP_U64}[table]
+    rng = np.random.default_rng(hash(table) % 1000 + 17)
+    ncol, npi = stark.num_columns, stark.num_public_inputs
+    for trial in range(3):
+        lv = rng.integers(0, P, size=ncol, dtype=np.uint64)
+        nv = rng.integers(0, P, size=ncol, dtype=np.uint64)
+        pi = rng.integers(0, P, size=npi, dtype=np.uint64)
+        if trial == 1:                                   # small values as on a real trace: limbs, flags
+            lv = rng.integers(0, 65536, size=ncol, dtype=np.uint64)
+            nv = rng.integers(0, 2, size=ncol, dtype=np.uint64)
+        alphas = [int(x) for x in rng.integers(1, P, size=2, dtype=np.uint64)]
+        z_last, l_first, l_last = (int(x) for x in rng.integers(0, P, size=3, dtype=np.uint64))
+        got = S.eval_constraints_host(stark, lv, nv, pi, alphas, z_last, l_first, l_last)
+        want = O.eval_constraints(kind, num_io, lv, nv, pi, alphas, z_last, l_first, l_last)
+        assert got == want, (table, trial)
+    # a zero challenge (probability 2^-64 in a proof): the fold keeps only the last constraint
+    got = S.eval_constraints_host(stark, lv, nv, pi, [0, alphas[1]], z_last, l_first, l_last)
+    assert got == O.eval_constraints(kind, num_io, lv, nv, pi, [0, alphas[1]], z_last, l_first, l_last)
