@@ -19,8 +19,9 @@
 #include "gl.cuh"
 
 static constexpr int SBN_NCH = 2;              // StarkConfig.num_challenges (standard_fast_config)
-// alpha^k tables are sized per table at run time: max(num_public_inputs, num_zs, 1024) + 1 entries.
-GL_HD size_t apow_len(size_t npi, size_t nzs) { size_t m = npi > nzs ? npi : nzs; return (m > 1024 ? m : 1024) + 1; }
+// alpha^k tables are sized per table at run time: one entry per constraint of the whole stream (AIR + permutation checks:
+// a constraint's weight is alpha^(number of constraints after it)), at least 1,025.
+GL_HD size_t apow_len(size_t nconstraints, size_t nzs) { size_t m = nconstraints + 2 * nzs; return (m > 1024 ? m : 1024) + 1; }
 static constexpr int G1EXP_MAX_IO = 512;        // largest num_io of any Exp table (Fq12ExpStark(512) = 2^18 rows)
 
 // BN254 base-field modulus in 16-bit limbs (src/modular/modular.rs:298-309).
@@ -30,36 +31,101 @@ GL_HD u64 bn254_modulus_limb(int j) {
   return M[j];
 }
 
+// sum of products x * w.  Generic form: one field multiply and add per term.  On the device over the base field the
+// products are accumulated UNREDUCED: x = x1 2^32 + x0, w = w1 2^32 + w0, three 64-bit column sums a0 += x0 w0,
+// a1 += x0 w1 + x1 w0, a2 += x1 w1 (v_mad_u64_u32, each with a carry counter), one reduction mod p in value().
+// 8 instructions per term instead of ~28 (16 for the multiply's product + reduction, 8 + hazard padding for the
+// canonical add); the four carries live in four SGPR pairs and every carry is read three instructions after it is
+// written, so the block needs no wait-state padding.  The folds of this file (constraints times powers of alpha) are
+// all of this shape, and they are ~55 % of the quotient kernel's multiplies.
+template <class P>
+struct Acc {
+  P v;
+  GL_HD void clear() { v = lift<P>(0); }
+  GL_HD void mac(P x, P w) { v = v + x * w; }
+  GL_HD void add(P x) { v = v + x; }
+  GL_HD P value() const { return v; }
+};
+#if defined(__HIP_DEVICE_COMPILE__)
+template <>
+struct Acc<F> {
+  u64 a0, a1, a2; u32 c0, c1, c2;
+  __device__ __forceinline__ void clear() { a0 = a1 = a2 = 0; c0 = c1 = c2 = 0; }
+  __device__ __forceinline__ void mac(F x, F w) {
+    // w is uniform over the wave wherever this file calls mac (alpha-power tables, per-proof constants): scalar operands
+    const u32 wl = (u32)__builtin_amdgcn_readfirstlane((int)(u32)w.v), wh = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(w.v >> 32));
+    u64 k0, k1, k2, k3;
+    asm("s_nop 1\n\t"   // the scalar operands may come straight from v_readfirstlane: two wait states before a VALU reads them
+        "v_mad_u64_u32 %0, %6, %10, %12, %0\n\t"
+        "v_mad_u64_u32 %1, %7, %10, %13, %1\n\t"
+        "v_mad_u64_u32 %2, %9, %11, %13, %2\n\t"
+        "v_mad_u64_u32 %1, %8, %11, %12, %1\n\t"
+        "v_addc_co_u32_e64 %3, vcc, 0, %3, %6\n\t"
+        "v_addc_co_u32_e64 %4, vcc, 0, %4, %7\n\t"
+        "v_addc_co_u32_e64 %5, vcc, 0, %5, %9\n\t"
+        "v_addc_co_u32_e64 %4, vcc, 0, %4, %8\n\t"
+        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(c0), "+v"(c1), "+v"(c2), "=&s"(k0), "=&s"(k1), "=&s"(k2), "=&s"(k3)
+        : "v"((u32)x.v), "v"((u32)(x.v >> 32)), "s"(wl), "s"(wh)
+        : "vcc");
+  }
+  __device__ __forceinline__ void add(F x) { const u64 t = a0 + x.v; c0 += t < a0 ? 1u : 0u; a0 = t; }
+  __device__ __forceinline__ F value() const {
+    // a0 + c0 2^64 + (a1 + c1 2^64) 2^32 + (a2 + c2 2^64) 2^64, with 2^64 = 2^32 - 1, 2^96 = -1, 2^128 = -2^32 (mod p)
+    const F t32((u64)1 << 32), eps(GLEPS);
+    return F::from_u64(a0) + F::from_u64(a1) * t32 + (F::from_u64(a2) + F((u64)c0)) * eps - F((u64)c1) - F((u64)c2) * t32;
+  }
+};
+#endif
+
+// The consumer (starky ConstraintConsumer): acc_j = sum_t c_t alpha_j^(n-1-t) over the n constraints of the evaluation, in
+// emission order.  `rem` counts the constraints still to come, so the constraint being emitted has exponent rem - 1 and
+// the sum is one running dot product with the alpha-power table (no Horner chain).  The caller sets the exact count with
+// start(n); rem must be back at 0 afterwards (checked on the host).
 template <class P>
 struct Cons {
   P alpha[SBN_NCH];
-  P acc[SBN_NCH];
+  Acc<P> a[SBN_NCH];
+  int rem;
   const P* apow[SBN_NCH];  // apow[j][k] = alpha_j^k, k < apow_len(...)
   P z_last, l_first, l_last;
-  GL_HD void c(P x) {
+  GL_HD void start(int n) {
+    rem = n;
 #pragma unroll
-    for (int j = 0; j < SBN_NCH; j++) acc[j] = acc[j] * alpha[j] + x;
+    for (int j = 0; j < SBN_NCH; j++) a[j].clear();
+  }
+  GL_HD P result(int j) const { return a[j].value(); }
+  GL_HD void c(P x) {
+    --rem;
+#pragma unroll
+    for (int j = 0; j < SBN_NCH; j++) a[j].mac(x, apow[j][rem]);
   }
   GL_HD void ct(P x) { c(x * z_last); }
   GL_HD void cf(P x) { c(x * l_first); }
   GL_HD void cl(P x) { c(x * l_last); }
-  // acc = acc*alpha^count + filter*h
+  // `count` constraints whose local sums (first of them weighted alpha^(count-1)) are h[j], all times `filter`
   GL_HD void merge(const P* h, P filter, int count) {
+    rem -= count;
 #pragma unroll
-    for (int j = 0; j < SBN_NCH; j++) acc[j] = acc[j] * apow[j][count] + filter * h[j];
+    for (int j = 0; j < SBN_NCH; j++) a[j].mac(filter * h[j], apow[j][rem]);
   }
 };
 
 template <class P>
-struct Horner2 {  // local two-challenge Horner sum
-  P h[SBN_NCH];
-  GL_HD void push(const Cons<P>& cs, P x) {
+struct Horner2 {  // local two-challenge sum over `count` constraints, the first weighted alpha^(count-1)
+  Acc<P> a[SBN_NCH];
+  int rem;
+  GL_HD explicit Horner2(int count) : rem(count) {
 #pragma unroll
-    for (int j = 0; j < SBN_NCH; j++) h[j] = h[j] * cs.alpha[j] + x;
+    for (int j = 0; j < SBN_NCH; j++) a[j].clear();
   }
-  GL_HD void shift(const Cons<P>& cs, int k) {
+  GL_HD void push(const Cons<P>& cs, P x) {
+    --rem;
 #pragma unroll
-    for (int j = 0; j < SBN_NCH; j++) h[j] = h[j] * cs.apow[j][k];
+    for (int j = 0; j < SBN_NCH; j++) a[j].mac(x, cs.apow[j][rem]);
+  }
+  GL_HD void value(P* out) const {
+#pragma unroll
+    for (int j = 0; j < SBN_NCH; j++) out[j] = a[j].value();
   }
 };
 
@@ -90,12 +156,17 @@ static constexpr int END = GB + 320;  // 384
 // constraint-by-constraint fold on random rows.
 template <class P, class Row>
 GL_HD P rev_limbs(const Cons<P>& cs, const Row& row, int j, int col, int n) {   // sum_i row[col + i] alpha_j^(n-1-i)
-  // as a dot product with the alpha-power table (uniform index: scalar loads), not as a Horner chain: the products are
-  // independent, so a lane has several multiplies in flight instead of one 16-deep dependent chain
+  // a dot product with the alpha-power table (uniform index: scalar loads), not a Horner chain: the products are independent
   const P* ap = cs.apow[j];
-  P h = row.l(col + n - 1);
-  for (int i = 0; i < n - 1; i++) h = h + row.l(col + i) * ap[n - 1 - i];
-  return h;
+  Acc<P> h; h.clear();
+  h.add(row.l(col + n - 1));
+#pragma unroll 4   // (the loads of four limbs in flight: the evaluators are bound by load latency, not by issue)
+  for (int i = 0; i < n - 1; i++) h.mac(row.l(col + i), ap[n - 1 - i]);
+  const P r = h.value();
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_sched_barrier(0);   // keep the folds of different limb vectors apart: interleaving them all costs the G1 kernel 190 spilled registers
+#endif
+  return r;
 }
 template <class P>
 GL_HD P rev_modulus(const Cons<P>& cs, int j) {   // sum_i m_i alpha_j^(15-i), m = the BN254 base-field modulus in 16-bit limbs
@@ -103,36 +174,40 @@ GL_HD P rev_modulus(const Cons<P>& cs, int j) {   // sum_i m_i alpha_j^(15-i), m
   for (int i = 1; i < 16; i++) h = h * cs.alpha[j] + lift<P>(bn254_modulus_limb(i));
   return h;
 }
-// Local Horner sum (challenge j) of the 34 leading constraints of eval_modular_op: eval_packed_generic_addcy
-// (src/modular/addcy.rs:16-58) for `modulus + out_aux_red = output + 2^256`, then quot_sign^2 = 1 (modular.rs:123);
-// `h` is the sum so far.
+// Local sum (challenge j) of the 34 leading constraints of eval_modular_op: eval_packed_generic_addcy
+// (src/modular/addcy.rs:16-58) for `modulus + out_aux_red = output + 2^256` (16 carry constraints, exponents 33..18;
+// given_cy[0]*(given_cy[0]-1) = 0 with given_cy[0] = 1; cy == given_cy[0], exponent 16; given_cy[1..16] = 0), then
+// quot_sign^2 = 1 (modular.rs:123), exponent 0.
 template <class P, class Row>
-GL_HD P modop_prefix(const Cons<P>& cs, const Row& row, int j, int oar_col, int out_col, P sign, P h) {
+GL_HD P modop_prefix(const Cons<P>& cs, const Row& row, int j, int oar_col, int out_col, P sign) {
   const P overflow = lift<P>(65536), overflow_inv = lift<P>(18446462594437939201ULL), one = lift<P>(1);
-  const P al = cs.alpha[j];
+  const P* ap = cs.apow[j];
+  Acc<P> h; h.clear();
   P cy = lift<P>(0);
   for (int i = 0; i < 16; i++) {
     P t = cy + lift<P>(bn254_modulus_limb(i)) + row.l(oar_col + i) - row.l(out_col + i);
-    h = h * al + t * (overflow - t);
+    h.mac(t * (overflow - t), ap[33 - i]);
     cy = t * overflow_inv;
   }
-  h = h * al;                     // given_cy[0]*(given_cy[0]-1) with given_cy[0] = 1
-  h = h * al + (cy - one);        // cy == given_cy[0]
-  h = h * cs.apow[j][15];         // given_cy[1..16] = 0
-  return h * al + (sign * sign - one);
+  h.mac(cy - one, ap[16]);
+  h.add(sign * sign - one);
+  return h.value();
 }
-// Horner-weighted sum over the 32 coefficient constraints of  sign * (quot * modulus)_k + ((x - beta) * aux)_k :
+// Weighted sum over the 32 coefficient constraints of  sign * (quot * modulus)_k + ((x - beta) * aux)_k :
 // quot_abs at qa_col (17 limbs), aux_lo / aux_hi (31 limbs each; aux = lo - 2^29 + 2^16 hi, modular.rs:118-121).
 template <class P, class Row>
 GL_HD P modop_tail(const Cons<P>& cs, const Row& row, int j, int qa_col, int lo_col, int hi_col, P sign, P mrev) {
   const P base = lift<P>(65536), off = lift<P>(1ULL << 29), one = lift<P>(1);
   const P al = cs.alpha[j];
   P q = rev_limbs(cs, row, j, qa_col, 17);
-  // rev31(aux) = rev31(lo) + 2^16 rev31(hi) - 2^29 (1 + alpha + ... + alpha^30), again as dot products
+  // rev31(aux) = rev31(lo) + 2^16 rev31(hi) - 2^29 (1 + alpha + ... + alpha^30)
   const P* ap = cs.apow[j];
-  P ulo = row.l(lo_col + 30), uhi = row.l(hi_col + 30), geo = one;
-  for (int k = 0; k < 30; k++) { ulo = ulo + row.l(lo_col + k) * ap[30 - k]; uhi = uhi + row.l(hi_col + k) * ap[30 - k]; geo = geo + ap[30 - k]; }
-  const P u = ulo + base * uhi - off * geo;
+  Acc<P> ulo, uhi; ulo.clear(); uhi.clear();
+  ulo.add(row.l(lo_col + 30)); uhi.add(row.l(hi_col + 30));
+  P geo = one;
+#pragma unroll 2
+  for (int k = 0; k < 30; k++) { ulo.mac(row.l(lo_col + k), ap[30 - k]); uhi.mac(row.l(hi_col + k), ap[30 - k]); geo = geo + ap[30 - k]; }
+  const P u = ulo.value() + base * uhi.value() - off * geo;
   return sign * q * mrev + (one - base * al) * u;
 }
 
@@ -143,6 +218,7 @@ GL_HD void g1_gadget(const Cons<P>& cs, const Row& row, P* h_add, P* h_dbl) {
   using namespace g1c;
   const P one = lift<P>(1), two = lift<P>(2), three = lift<P>(3);
   const P sz = row.l(SGN_Z), sx = row.l(SGN_X), sy = row.l(SGN_Y);
+#pragma unroll   // (j must be a compile-time index: a run-time one puts the consumer in scratch memory and its tables behind flat loads)
   for (int j = 0; j < SBN_NCH; j++) {
     const P al = cs.alpha[j], a16 = cs.apow[j][16], a32 = cs.apow[j][32], mrev = rev_modulus(cs, j);
     const P L = rev_limbs(cs, row, j, LAM, 16), ax = rev_limbs(cs, row, j, AX, 16), ay = rev_limbs(cs, row, j, AY, 16);
@@ -154,9 +230,9 @@ GL_HD void g1_gadget(const Cons<P>& cs, const Row& row, P* h_add, P* h_dbl) {
     const P pz = (sz * sz - one) * a32;       // modular_zero prefix: quot_sign_zero^2 - 1 (modular_zero.rs:91), then 32 coefficients
     const P za = pz + tz - al * (L * (bx - ax)) + a16 * (by - ay);
     const P zd = pz + tz - al * (two * (L * ay) - three * (ax * ax));
-    const P px = modop_prefix(cs, row, j, X_OAR, NX, sx, lift<P>(0)) * a32 + tx - al * (L * L);
+    const P px = modop_prefix(cs, row, j, X_OAR, NX, sx) * a32 + tx - al * (L * L);
     const P xa = px + a16 * (nx + ax + bx), xd = px + a16 * (nx + ax + ax);
-    const P y = modop_prefix(cs, row, j, Y_OAR, NY, sy, lift<P>(0)) * a32 + ty - al * (L * (ax - nx)) + a16 * (ny + ay);
+    const P y = modop_prefix(cs, row, j, Y_OAR, NY, sy) * a32 + ty - al * (L * (ax - nx)) + a16 * (ny + ay);
     const P a132 = cs.apow[j][132], a66 = cs.apow[j][66];
     h_add[j] = za * a132 + xa * a66 + y;
     h_dbl[j] = zd * a132 + xd * a66 + y;
@@ -279,6 +355,7 @@ GL_HD void g2_gadget(const Cons<P>& cs, const Row& row, P* h_add, P* h_dbl) {
   const P one = lift<P>(1), zero = lift<P>(0), two = lift<P>(2), three = lift<P>(3);
   P sz[2], sx[2], sy[2];
   for (int c = 0; c < 2; c++) { sz[c] = row.l(SGN_Z + c); sx[c] = row.l(SGN_X + c); sy[c] = row.l(SGN_Y + c); }
+#pragma unroll   // (j must be a compile-time index: a run-time one puts the consumer in scratch memory and its tables behind flat loads)
   for (int j = 0; j < SBN_NCH; j++) {
     const P al = cs.alpha[j], a16 = cs.apow[j][16], a32 = cs.apow[j][32], mrev = rev_modulus(cs, j);
     P L[2], ax[2], ay[2], bx[2], by[2], nx[2], ny[2];
@@ -304,10 +381,10 @@ GL_HD void g2_gadget(const Cons<P>& cs, const Row& row, P* h_add, P* h_dbl) {
       const P pz = (sz[c] * sz[c] - one) * a32;
       za[c] = pz + tz - al * c1[c] + a16 * (by[c] - ay[c]);
       zd[c] = pz + tz - al * (two * c2[c] - three * c3[c]);
-      const P px = modop_prefix(cs, row, j, x_base(c), NX + 16 * c, sx[c], zero) * a32 + tx - al * c4[c];
+      const P px = modop_prefix(cs, row, j, x_base(c), NX + 16 * c, sx[c]) * a32 + tx - al * c4[c];
       xa[c] = px + a16 * (nx[c] + ax[c] + bx[c]);
       xd[c] = px + a16 * (nx[c] + ax[c] + ax[c]);
-      y[c] = modop_prefix(cs, row, j, y_base(c), NY + 16 * c, sy[c], zero) * a32 + ty - al * c5[c] + a16 * (ny[c] + ay[c]);
+      y[c] = modop_prefix(cs, row, j, y_base(c), NY + 16 * c, sy[c]) * a32 + ty - al * c5[c] + a16 * (ny[c] + ay[c]);
     }
     const P* ap = cs.apow[j];
     h_add[j] = za[0] * ap[297] + za[1] * ap[264] + xa[0] * ap[198] + xa[1] * ap[132] + y[0] * ap[66] + y[1];
@@ -330,6 +407,7 @@ template <class P, class Row>
 GL_HD void fq12_gadget(const Cons<P>& cs, const Row& row, P* h_sq, P* h_mul) {
   using namespace f12c;
   const P zero = lift<P>(0), nine = lift<P>(9);
+#pragma unroll   // (j must be a compile-time index: a run-time one puts the consumer in scratch memory and its tables behind flat loads)
   for (int j = 0; j < SBN_NCH; j++) {
     const P al = cs.alpha[j], a16 = cs.apow[j][16], a32 = cs.apow[j][32], mrev = rev_modulus(cs, j);
     P ar[12], br[12];   // reversed evaluations of the 12 + 12 coefficient limb vectors
@@ -352,7 +430,7 @@ GL_HD void fq12_gadget(const Cons<P>& cs, const Row& row, P* h_sq, P* h_mul) {
       for (int q = 0; q < 2; q++) {
         const int c = m + 6 * q, ab = AUX + 95 * c;
         const P sgn = row.l(SGN + c);
-        const P pre = modop_prefix(cs, row, j, ab, OUT + 16 * c, sgn, zero) * a32 + modop_tail(cs, row, j, ab + 16, ab + 33, ab + 64, sgn, mrev) +
+        const P pre = modop_prefix(cs, row, j, ab, OUT + 16 * c, sgn) * a32 + modop_tail(cs, row, j, ab + 16, ab + 33, ab + 64, sgn, mrev) +
                       a16 * rev_limbs(cs, row, j, OUT + 16 * c, 16);
         const P w = cs.apow[j][66 * (q ? 5 - m : 11 - m)];
         hs = hs + (pre - al * in_s[q]) * w;
@@ -371,10 +449,11 @@ template <class P, class Row>
 GL_HD void fq_gadget(const Cons<P>& cs, const Row& row, P* h_sq, P* h_mul) {
   constexpr int A = 0, B = 16, OUT = 32, AUX = 48, SGN = 143;
   const P sgn = row.l(SGN);
+#pragma unroll   // (j must be a compile-time index: a run-time one puts the consumer in scratch memory and its tables behind flat loads)
   for (int j = 0; j < SBN_NCH; j++) {
     const P al = cs.alpha[j];
     const P a = rev_limbs(cs, row, j, A, 16), b = rev_limbs(cs, row, j, B, 16);
-    const P pre = modop_prefix(cs, row, j, AUX, OUT, sgn, lift<P>(0)) * cs.apow[j][32] + modop_tail(cs, row, j, AUX + 16, AUX + 33, AUX + 64, sgn, rev_modulus(cs, j)) +
+    const P pre = modop_prefix(cs, row, j, AUX, OUT, sgn) * cs.apow[j][32] + modop_tail(cs, row, j, AUX + 16, AUX + 33, AUX + 64, sgn, rev_modulus(cs, j)) +
                   cs.apow[j][16] * rev_limbs(cs, row, j, OUT, 16);
     h_sq[j] = pre - al * (a * a);
     h_mul[j] = pre - al * (a * b);
@@ -495,9 +574,9 @@ GL_HD void exp_eval(Cons<P>& cs, const Row& row, const ExpShape& sh, const ExpPi
   // [1] is_final - sum(output pulses)                                         g1/exp.rs:359-365
   // [2] public-input binding, regrouped                                       g1/exp.rs:368-392, g2/exp.rs:382-414
   {
-    P vin[SBN_NCH], vout[SBN_NCH];
+    Acc<P> vin[SBN_NCH], vout[SBN_NCH];
 #pragma unroll
-    for (int j = 0; j < SBN_NCH; j++) { vin[j] = lift<P>(0); vout[j] = lift<P>(0); }
+    for (int j = 0; j < SBN_NCH; j++) { vin[j].clear(); vout[j].clear(); }
     for (int m = 0; m < S; m++) {
       P v;
       int col = sh.slot_col(m);
@@ -511,39 +590,35 @@ GL_HD void exp_eval(Cons<P>& cs, const Row& row, const ExpShape& sh, const ExpPi
       }
       bool is_out = sh.slot_is_out(m);
 #pragma unroll
-      for (int j = 0; j < SBN_NCH; j++) {
-        P t = cs.apow[j][S - 1 - m] * v;
-        if (is_out) vout[j] = vout[j] + t; else vin[j] = vin[j] + t;
-      }
+      for (int j = 0; j < SBN_NCH; j++) { if (is_out) vout[j].mac(v, cs.apow[j][S - 1 - m]); else vin[j].mac(v, cs.apow[j][S - 1 - m]); }
     }
     P sum_out = lift<P>(0);
-    P s_in_wa[SBN_NCH], s_in_w[SBN_NCH], s_out_wo[SBN_NCH], s_out_w[SBN_NCH];
+    Acc<P> s_in_wa[SBN_NCH], s_in_w[SBN_NCH], s_out_wo[SBN_NCH], s_out_w[SBN_NCH];
 #pragma unroll
-    for (int j = 0; j < SBN_NCH; j++) { s_in_wa[j] = s_in_w[j] = s_out_wo[j] = s_out_w[j] = lift<P>(0); }
+    for (int j = 0; j < SBN_NCH; j++) { s_in_wa[j].clear(); s_in_w[j].clear(); s_out_wo[j].clear(); s_out_w[j].clear(); }
+#pragma unroll 2
     for (int i = 0; i < sh.num_io; i++) {
       P pin = row.l(sh.pulse_col(2 * i)), pout = row.l(sh.pulse_col(2 * i + 1));
       sum_out = sum_out + pout;
 #pragma unroll
       for (int j = 0; j < SBN_NCH; j++) {
-        s_in_wa[j] += pin * pic->WA[j][i];
-        s_in_w[j] += pin * pic->W[j][i];
-        s_out_wo[j] += pout * pic->WO[j][i];
-        s_out_w[j] += pout * pic->W[j][i];
+        s_in_wa[j].mac(pin, pic->WA[j][i]);
+        s_in_w[j].mac(pin, pic->W[j][i]);
+        s_out_wo[j].mac(pout, pic->WO[j][i]);
+        s_out_w[j].mac(pout, pic->W[j][i]);
       }
     }
     cs.c(is_final - sum_out);
+    P b[SBN_NCH];
 #pragma unroll
-    for (int j = 0; j < SBN_NCH; j++) {
-      P b = s_in_wa[j] - vin[j] * s_in_w[j] + s_out_wo[j] - vout[j] * s_out_w[j];
-      cs.acc[j] = cs.acc[j] * cs.apow[j][sh.num_pi] + b;
-    }
+    for (int j = 0; j < SBN_NCH; j++) b[j] = s_in_wa[j].value() - vin[j].value() * s_in_w[j].value() + s_out_wo[j].value() - vout[j].value() * s_out_w[j].value();
+    cs.merge(b, one, sh.num_pi);   // the num_pi binding constraints, already folded
   }
   // [3] state transitions (fq_equal_transition / fq2_equal_transition x12)      g1/exp.rs:395-461, g2/exp.rs:416-473
   {
     constexpr int W = F12 ? 192 : (E == 0 ? 16 : 32 * E);  // columns of one operand (point / Fq12 element / Fq element)
-    Horner2<P> d_na_a, d_nb_b, d_na_new, d_nb_new;  // (next_a - a), (next_b - b), (next_a - new), (next_b - new)
-#pragma unroll
-    for (int j = 0; j < SBN_NCH; j++) d_na_a.h[j] = d_nb_b.h[j] = d_na_new.h[j] = d_nb_new.h[j] = lift<P>(0);
+    Horner2<P> d_na_a(W), d_nb_b(W), d_na_new(W), d_nb_new(W);  // (next_a - a), (next_b - b), (next_a - new), (next_b - new)
+#pragma unroll 2
     for (int k = 0; k < W; k++) {
       P na = row.n(k), nb = row.n(W + k), nw = row.l(sh.nx_col + k);  // a, b and (new_x, new_y) are contiguous blocks
       d_na_a.push(cs, na - row.l(k));
@@ -551,13 +626,14 @@ GL_HD void exp_eval(Cons<P>& cs, const Row& row, const ExpShape& sh, const ExpPi
       d_na_new.push(cs, na - nw);
       d_nb_new.push(cs, nb - nw);
     }
-    P hd[SBN_NCH], ha[SBN_NCH], hn[SBN_NCH];
+    P hd[SBN_NCH], ha[SBN_NCH], hn[SBN_NCH], v_na_a[SBN_NCH], v_nb_b[SBN_NCH], v_na_new[SBN_NCH], v_nb_new[SBN_NCH];
+    d_na_a.value(v_na_a); d_nb_b.value(v_nb_b); d_na_new.value(v_na_new); d_nb_new.value(v_nb_new);
 #pragma unroll
     for (int j = 0; j < SBN_NCH; j++) {
       P aw = cs.apow[j][W];
-      hd[j] = d_na_new.h[j] * aw + d_nb_b.h[j];
-      ha[j] = d_na_a.h[j] * aw + d_nb_new.h[j];
-      hn[j] = d_na_a.h[j] * aw + d_nb_b.h[j];
+      hd[j] = v_na_new[j] * aw + v_nb_b[j];
+      ha[j] = v_na_a[j] * aw + v_nb_new[j];
+      hn[j] = v_na_a[j] * aw + v_nb_b[j];
     }
     P zl = cs.z_last * is_not_final;
     cs.merge(hd, zl * is_double, 2 * W);
@@ -565,12 +641,12 @@ GL_HD void exp_eval(Cons<P>& cs, const Row& row, const ExpShape& sh, const ExpPi
     cs.merge(hn, zl * (one - is_double - is_add), 2 * W);
   }
   // [4] eval_flags, [5] eval_g*_add, [6] eval_g*_double, [7] eval_flags again   g1/exp.rs:462-472, g2/exp.rs:474-484
-  Horner2<P> hf;
-#pragma unroll
-  for (int j = 0; j < SBN_NCH; j++) hf.h[j] = lift<P>(0);
   constexpr int FC = E == 13 ? FLAGS_U64_CONSTRAINTS : FLAGS_CONSTRAINTS;
+  Horner2<P> hf(FC);
   if (E == 13) flags_u64_block(cs, row, sf, hf); else flags_block(cs, row, sf, hf);
-  cs.merge(hf.h, one, FC);
+  P hfv[SBN_NCH];
+  hf.value(hfv);
+  cs.merge(hfv, one, FC);
   {
     P h_add[SBN_NCH], h_dbl[SBN_NCH];
     // curve tables: eval_g*_add (filter is_add) then eval_g*_double (is_double); fq12 / fq: eval_fq*_mul(is_sq, a, a)
@@ -580,7 +656,7 @@ GL_HD void exp_eval(Cons<P>& cs, const Row& row, const ExpShape& sh, const ExpPi
     if (F12 || E == 0) { cs.merge(h_dbl, is_double, sh.gadget_cons); cs.merge(h_add, is_add, sh.gadget_cons); }
     else { cs.merge(h_add, is_add, sh.gadget_cons); cs.merge(h_dbl, is_double, sh.gadget_cons); }
   }
-  cs.merge(hf.h, one, FC);
+  cs.merge(hfv, one, FC);
   // [8] eval_periodic_pulse(pulse_col = is_rotate, period 64, first_pulse 62)   pulse.rs:146-170 (not in the u64 table)
   if (E != 13) {
     const int st = sh.start_periodic;
@@ -600,6 +676,7 @@ GL_HD void exp_eval(Cons<P>& cs, const Row& row, const ExpShape& sh, const ExpPi
     P counter = row.l(st);
     cs.cf(counter);
     cs.ct(row.n(st) - counter - one);
+#pragma unroll 4
     for (int i = 0; i < 2 * sh.num_io; i++) {
       u64 pos = (u64)(i >> 1) * sh.rpb + ((i & 1) ? sh.rpb - 1 : 0);  // get_pulse_positions, g1/exp.rs:153-163
       P cmp = counter - lift<P>(pos);
@@ -612,10 +689,13 @@ GL_HD void exp_eval(Cons<P>& cs, const Row& row, const ExpShape& sh, const ExpPi
   if (F12) {
     const P c256 = lift<P>(256);
     const int mc = sh.start_lookups;
+#pragma unroll 4
     for (int i = 0; i < sh.num_rc; i++) cs.c(row.l(sh.rc_start + i) - (row.l(mc + 1 + 6 * i) + row.l(mc + 4 + 6 * i) * c256));
+#pragma unroll 2
     for (int i = mc + 1; i < mc + 1 + 6 * sh.num_rc; i += 6) { lookup_pair(cs, row, i + 1, i + 2); lookup_pair(cs, row, i + 4, i + 5); }
     range_table_block(cs, row, mc, 255);
   } else {
+#pragma unroll 4
     for (int k = 0; k < sh.num_rc; k++) lookup_pair(cs, row, sh.start_lookups + 1 + 2 * k, sh.start_lookups + 2 + 2 * k);
     range_table_block(cs, row, sh.start_lookups, 65535);
   }
@@ -632,12 +712,14 @@ GL_HD void permutation_checks(Cons<P>& cs, const Row& row, const ZRow& zrow, con
   const P one = lift<P>(1);
   if (z1 < 0) z1 = num_zs;
   if (first_row) {
-    Horner2<P> h;
-#pragma unroll
-    for (int j = 0; j < SBN_NCH; j++) h.h[j] = lift<P>(0);
+    Horner2<P> h(num_zs);
+#pragma unroll 8
     for (int z = 0; z < num_zs; z++) h.push(cs, zrow.zl(z) - one);
-    cs.merge(h.h, cs.l_first, num_zs);
+    P hv[SBN_NCH];
+    h.value(hv);
+    cs.merge(hv, cs.l_first, num_zs);
   }
+#pragma unroll 4
   for (int z = z0; z < z1; z++) {
     int lc, rc;
     sh.pair(z, lc, rc);

@@ -606,6 +606,7 @@ struct QuotientParams {
   u64* qout;        // [SBN_NCH][m]
   u64* part;        // [QSEG segments][SBN_NCH][m] partial accumulators
   u64 seg_shift[4][SBN_NCH];  // alpha_j^(number of constraints that follow the segment)
+  int seg_count[4];           // constraints of each segment (its first one is weighted alpha^(count-1) inside the segment)
   int zsplit;       // permutation transition constraints [0, zsplit) go with segment 2, [zsplit, num_zs) with segment 3
 };
 
@@ -623,8 +624,13 @@ struct QuotientParams {
 // not between segments but inside segment 0 (3.0 GB for 0.45 GB of columns: every limb re-read for each convolution
 // coefficient it feeds), which the factored gadgets of air.cuh removed (profiles/r2_quotient_segments.txt).
 static constexpr u32 QSEG = 4;
+// The alpha-power tables and the public-input constants come in as `const __restrict__` kernel arguments of their own (not
+// inside the parameter struct): only then does the compiler know that the kernel never writes them and fetches the
+// uniformly indexed entries with SCALAR loads (s_load through the scalar cache, operand straight into the multiply-add);
+// through the struct they were vector loads + v_readfirstlane with a memory latency in front of every term.
 template <int KIND, int PART>
-__global__ __launch_bounds__(256) void quotient_kernel(QuotientParams p) {
+__global__ __launch_bounds__(256, 2) void quotient_kernel(QuotientParams p, const u64* __restrict__ apow0, const u64* __restrict__ apow1,
+                                                          const void* __restrict__ pic_arg) {   // at least two waves per SIMD: at most 256 VGPRs
   const u32 seg = PART == 2 ? 2 + blockIdx.y : (u32)PART;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= p.m || !((p.seg_mask >> seg) & 1)) return;
@@ -632,7 +638,9 @@ __global__ __launch_bounds__(256) void quotient_kernel(QuotientParams p) {
   const size_t ig = (i << p.row_shift) | p.row_rho;   // LDE point of local row i
   Cons<F> cs;
 #pragma unroll
-  for (int j = 0; j < SBN_NCH; j++) { cs.alpha[j] = F(p.alpha[j]); cs.acc[j] = F(0); cs.apow[j] = (const F*)p.apow[j]; }
+  for (int j = 0; j < SBN_NCH; j++) cs.alpha[j] = F(p.alpha[j]);
+  cs.apow[0] = (const F*)apow0; cs.apow[1] = (const F*)apow1;
+  cs.start(p.seg_count[seg]);
   cs.z_last = F(p.xs[ig]) - F(p.last);
   cs.l_first = F(p.lag_first[ig]);
   cs.l_last = F(p.lag_last[ig]);
@@ -647,12 +655,12 @@ __global__ __launch_bounds__(256) void quotient_kernel(QuotientParams p) {
   } else {
     constexpr int E = KIND == 4 ? 12 : (KIND == 6 ? 13 : (KIND == 3 ? 2 : (KIND == 5 ? 0 : 1)));
     ExpShape sh(E, p.num_io);
-    if (PART < 2) exp_eval<E>(cs, row, sh, (const ExpPiConsts<F>*)p.pic, 1 + PART);
+    if (PART < 2) exp_eval<E>(cs, row, sh, (const ExpPiConsts<F>*)pic_arg, 1 + PART);
     else if (seg == 2) permutation_checks(cs, row, zrow, sh, p.num_zs, F(p.gamma0), F(p.gamma1), true, 0, p.zsplit);
     else permutation_checks(cs, row, zrow, sh, p.num_zs, F(p.gamma0), F(p.gamma1), false, p.zsplit, p.num_zs);
   }
 #pragma unroll
-  for (int j = 0; j < SBN_NCH; j++) p.part[((size_t)seg * SBN_NCH + j) * p.m + i] = cs.acc[j].v;
+  for (int j = 0; j < SBN_NCH; j++) p.part[((size_t)seg * SBN_NCH + j) * p.m + i] = cs.result(j).v;
 }
 __global__ __launch_bounds__(256) void quotient_combine_kernel(QuotientParams p) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

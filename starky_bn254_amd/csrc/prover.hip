@@ -477,7 +477,7 @@ static int create_ctx(const sbn_air_desc* air, const sbn_config* cfg, uint32_t d
   acc(tree_alloc(P->tree_q, m, cfg->cap_height));
   acc(dmalloc(&P->d_tw_f, m / 2)); acc(dmalloc(&P->d_tw_i, m / 2)); acc(dmalloc(&P->d_shift, m)); acc(dmalloc(&P->d_shift_inv, m));
   acc(dmalloc(&P->d_xs, m)); acc(dmalloc(&P->d_lag_first, m)); acc(dmalloc(&P->d_lag_last, m));
-  P->apow_n = apow_len(as.npi, as.nzs);
+  P->apow_n = apow_len(as.nconstraints, as.nzs);
   acc(dmalloc(&P->d_apow, (size_t)SBN_NCH * P->apow_n));
   acc(dmalloc(&P->d_zpow, 4 * n)); acc(dmalloc(&P->d_open, (C + Z + 4) * 4));
   hipc(hipHostMalloc((void**)&P->h_open, (C + Z + 4) * 4 * sizeof(u64), hipHostMallocDefault), "hipHostMalloc");
@@ -888,9 +888,9 @@ extern "C" const char* sbn_prover_stage_name(int i) { return (i >= 0 && i < ST_C
 template <int KIND>
 static void launch_quotient_kind(sbn_prover* P, const QuotientParams& qp, size_t qblocks) {
   const dim3 g1((unsigned)qblocks, 1), g2((unsigned)qblocks, 2);
-  if (qp.seg_mask & 12u) hipLaunchKernelGGL((quotient_kernel<KIND, 2>), g2, dim3(256), 0, P->hstream, qp);
-  if (qp.seg_mask & 1u) hipLaunchKernelGGL((quotient_kernel<KIND, 0>), g1, dim3(256), 0, P->stream, qp);
-  if (qp.seg_mask & 2u) hipLaunchKernelGGL((quotient_kernel<KIND, 1>), g1, dim3(256), 0, P->stream, qp);
+  if (qp.seg_mask & 12u) hipLaunchKernelGGL((quotient_kernel<KIND, 2>), g2, dim3(256), 0, P->hstream, qp, qp.apow[0], qp.apow[1], qp.pic);
+  if (qp.seg_mask & 1u) hipLaunchKernelGGL((quotient_kernel<KIND, 0>), g1, dim3(256), 0, P->stream, qp, qp.apow[0], qp.apow[1], qp.pic);
+  if (qp.seg_mask & 2u) hipLaunchKernelGGL((quotient_kernel<KIND, 1>), g1, dim3(256), 0, P->stream, qp, qp.apow[0], qp.apow[1], qp.pic);
 }
 static int launch_quotient_parts(sbn_prover* P, const QuotientParams& qp, size_t qblocks) {
   switch (P->air.kind) {
@@ -1002,6 +1002,8 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
       qp.zsplit = (int)(Z / 3);   // a first-row constraint costs about a third of a transition
       const u64 n_tail = is_exp_air(P->air.kind) ? (u64)ExpShape(exp_e(P->air.kind), (int)P->air.num_io).num_tail_constraints() : 0;
       const u64 after[4] = {n_tail + 2 * (u64)Z, 2 * (u64)Z, (u64)Z - (u64)qp.zsplit, 0};
+      qp.seg_count[0] = (int)(P->air.nconstraints - n_tail); qp.seg_count[1] = (int)n_tail;
+      qp.seg_count[2] = (int)Z + qp.zsplit; qp.seg_count[3] = (int)Z - qp.zsplit;
       for (int sgm = 0; sgm < 4; sgm++) for (int j = 0; j < SBN_NCH; j++) qp.seg_shift[sgm][j] = f_pow(alphas[j], after[sgm]).v;
     }
     const size_t qblocks = (qp.m + 255) / 256;

@@ -161,11 +161,12 @@ extern "C" int sbn_verify(const sbn_air_desc* air, const sbn_config* cfg, const 
   Cons<E2> cs;
   std::vector<E2> apow[SBN_NCH];
   for (int j = 0; j < SBN_NCH; j++) {
-    apow[j].resize(apow_len(as.npi, as.nzs));
+    apow[j].resize(apow_len(as.nconstraints, as.nzs));
     E2 a{F(1), F(0)}, al(alphas[j]);
     for (size_t k = 0; k < apow[j].size(); k++) { apow[j][k] = a; a = a * al; }
-    cs.alpha[j] = al; cs.acc[j] = E2(F(0), F(0)); cs.apow[j] = apow[j].data();
+    cs.alpha[j] = al; cs.apow[j] = apow[j].data();
   }
+  cs.start((int)(as.nconstraints + 2 * nz));   // the AIR's constraints, then nz first-row and nz transition permutation checks
   cs.z_last = zeta - f_inv(g);
   cs.l_first = z_h_zeta * e2_inv((zeta - F(1)) * nn);        // eval_l_0_and_l_last
   cs.l_last = z_h_zeta * e2_inv((zeta * g - F(1)) * nn);
@@ -187,7 +188,8 @@ extern "C" int sbn_verify(const sbn_air_desc* air, const sbn_config* cfg, const 
   for (u32 i = 0; i < cfg->num_challenges; i++) {
     // quotient_degree_factor = 2 chunks per challenge: t(zeta) = t0 + zeta^N t1
     E2 t = quot[2 * i] + zeta_pow_deg * quot[2 * i + 1];
-    if (cs.acc[i] != z_h_zeta * t) return fail(SBN_ERR_VERIFY_FAILED, "mismatch between evaluation and opening of quotient polynomial");
+    if (cs.rem != 0) return fail(SBN_ERR_VERIFY_FAILED, "internal: constraint count mismatch (%d left)", cs.rem);
+    if (cs.result((int)i) != z_h_zeta * t) return fail(SBN_ERR_VERIFY_FAILED, "mismatch between evaluation and opening of quotient polynomial");
   }
 
   // verify_fri_proof
@@ -262,11 +264,12 @@ extern "C" int sbn_eval_constraints_host(const sbn_air_desc* air, const uint64_t
   Cons<F> cs;
   std::vector<F> apow[SBN_NCH];
   for (int j = 0; j < SBN_NCH; j++) {
-    apow[j].resize(apow_len(as.npi, as.nzs));
+    apow[j].resize(apow_len(as.nconstraints, as.nzs));
     F a(1), al(alphas[j]);
     for (size_t k = 0; k < apow[j].size(); k++) { apow[j][k] = a; a = a * al; }
-    cs.alpha[j] = al; cs.acc[j] = F(0); cs.apow[j] = apow[j].data();
+    cs.alpha[j] = al; cs.apow[j] = apow[j].data();
   }
+  cs.start((int)as.nconstraints);
   cs.z_last = F(z_last); cs.l_first = F(l_first); cs.l_last = F(l_last);
   HostRowF row{local_row, next_row};
   if (as.kind == SBN_AIR_G1_OP) {
@@ -280,6 +283,7 @@ extern "C" int sbn_eval_constraints_host(const sbn_air_desc* air, const uint64_t
     if (sh.E == 1) exp_eval<1>(cs, row, sh, &pic); else if (sh.E == 2) exp_eval<2>(cs, row, sh, &pic); else if (sh.E == 0) exp_eval<0>(cs, row, sh, &pic);
     else if (sh.E == 13) exp_eval<13>(cs, row, sh, &pic); else exp_eval<12>(cs, row, sh, &pic);
   }
-  for (int j = 0; j < SBN_NCH; j++) acc_out[j] = cs.acc[j].v;
+  if (cs.rem != 0) return fail(SBN_ERR_HIP, "internal: the evaluator emitted %d constraints fewer than the table declares", cs.rem);
+  for (int j = 0; j < SBN_NCH; j++) acc_out[j] = cs.result(j).v;
   return SBN_OK;
 }
