@@ -145,8 +145,9 @@ uint64_t* sbn_prover_trace_device_ptr(sbn_prover* p);
  * ::generate_trace + generate_public_inputs (src/curves/g1/exp.rs:255-327, src/curves/g2/exp.rs:271-342,
  * src/fields/fq12/exp.rs:283-319) without the trace ever crossing PCIe.  Same `ios` layout and the same resulting trace /
  * public inputs, bit for bit, as sbn_generate_trace_{g1,g2,fq12}_exp; afterwards the prover is loaded and
- * sbn_prover_prove can run.  pi_out (optional): [num_public_inputs].  G1_EXP / G2_EXP / FQ_EXP: tables of exactly 2^16
- * rows (SBN_ERR_UNSUPPORTED otherwise: use the host generators + sbn_prover_load_trace); FQ12_EXP, FQ12_EXP_U64: any size. */
+ * sbn_prover_prove can run.  pi_out (optional): [num_public_inputs].  G1_EXP / G2_EXP / FQ_EXP: 2^16 .. 2^18 rows (the
+ * reference pads to any power of two >= 128 instances, src/curves/g1/circuit.rs:273-277; SBN_ERR_UNSUPPORTED beyond: use
+ * the host generators + sbn_prover_load_trace); FQ12_EXP, FQ12_EXP_U64: any size. */
 int sbn_prover_generate_trace(sbn_prover* p, const uint32_t* ios, size_t num_io, uint64_t* pi_out);
 /* Device -> host copy of the loaded trace, column-major [num_columns][N] (tests, debugging). */
 int sbn_prover_read_trace(sbn_prover* p, uint64_t* trace_out);

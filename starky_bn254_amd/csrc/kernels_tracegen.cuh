@@ -353,46 +353,67 @@ __global__ void __launch_bounds__(256) split_range_check_kernel(u64* __restrict_
 //   slot of rank h-1, which is slot v + h where v is the first value with S[v] < -(h-1) (or a repeat of 65535).
 // Every lane owns 64 consecutive values; "first x >= from with S[x] < target" walks a two-level min tree (32 / 1024).
 static constexpr int RC_THREADS = 1024;
-static constexpr int RC_HEAVY_MAX = 1024;  // values with more than 64 occurrences are expanded by the whole block
+static constexpr int RC_HEAVY_MAX = 1024;  // values with more than 64 (BIG: 256) occurrences are expanded by the whole block
 static constexpr size_t RC_LDS_BYTES = 65536 * 2 + 2 * 2048 * 4 + 64 * 4 + 64 * 4 + RC_HEAVY_MAX * 8;
 
-__global__ void __launch_bounds__(RC_THREADS) range_check_kernel(u64* __restrict__ trace, size_t n, int first_col, int start_lookups, int* __restrict__ err) {
+// Tables with MORE than 2^16 rows (G1ExpStark(256) ... : the reference pads to any power of two >= 128 instances,
+// src/curves/g1/circuit.rs:273-277): multiplicities no longer fit the u16 LDS counters, so range_count_kernel builds
+// the histogram of every target column in HBM (u32, one atomic per row) and the BIG variant of range_check_kernel reads
+// it.  The prefix counts T[v] <= n stay in LDS as T mod 2^16 (u16) plus the <= 3 values at which T crosses a multiple
+// of 2^16 (T is monotone, so the high part is the number of those thresholds <= v).
+__global__ void range_count_kernel(const u64* __restrict__ trace, size_t n, int first_col, unsigned int* __restrict__ cnt, int* __restrict__ err) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u64 v = trace[(size_t)(first_col + blockIdx.y) * n + i];
+  if (v >= 65536) { atomicOr(err, TG_ERR_RANGE); return; }
+  atomicAdd(&cnt[(size_t)blockIdx.y * 65536 + v], 1u);
+}
+
+// The table column is 0..65534 once each, then 65535 K = n - 65535 times (range_check.rs:20-47: min(i, 65535)); the merge
+// gives the first min(c, K) occurrences of 65535 their own table entry (Ordering::Equal), further occurrences run off
+// the table and are deferred, and table copies left over when the inputs end are appended to the pool (lookup.rs:100-101).
+template <bool BIG>
+__global__ void __launch_bounds__(RC_THREADS) range_check_kernel(u64* __restrict__ trace, size_t n, int first_col, int start_lookups, int* __restrict__ err,
+                                                                 const unsigned int* __restrict__ cnt) {
   extern __shared__ unsigned int lds[];
-  unsigned int* t32 = lds;                                                  // 32768 words = 65536 u16 counters, then T
+  unsigned int* t32 = lds;                                                  // 32768 words = 65536 u16 counters, then T (mod 2^16)
   const unsigned short* t16 = reinterpret_cast<const unsigned short*>(lds);
   int* L1 = reinterpret_cast<int*>(lds + 32768);                            // min S over 32 values
   int* SM1 = L1 + 2048;                                                     // suffix minima of L1
   int* L2 = SM1 + 2048;                                                     // min over 32 L1 entries
-  unsigned int* misc = reinterpret_cast<unsigned int*>(L2 + 64);            // [0..15] wave sums, [32] differs, [33] vmax, [34] heavy count
-  uint2* heavy = reinterpret_cast<uint2*>(misc + 64);                       // (value, start) of values with > 64 occurrences
+  unsigned int* misc = reinterpret_cast<unsigned int*>(L2 + 64);            // [0..15] wave sums, [32] differs, [33] vmax, [34] heavy count, [40..42] thresholds
+  uint2* heavy = reinterpret_cast<uint2*>(misc + 64);                       // (value, start) of values with many occurrences
   const int tid = threadIdx.x, kcol = blockIdx.x;
   const u64* col = trace + (size_t)(first_col + kcol) * n;
   u64* sorted_out = trace + (size_t)(start_lookups + 1 + 2 * kcol) * n;
   u64* perm_out = sorted_out + n;
   constexpr int INF = 0x3fffffff;
+  const int N = (int)n, KT = N - 65535;             // rows; copies of 65535 in the table
+  constexpr int HEAVY = BIG ? 256 : 64;
 
   for (int i = tid; i < 32768; i += RC_THREADS) t32[i] = 0;
-  if (tid < 64) misc[tid] = 0;
+  if (tid < 64) misc[tid] = tid >= 40 && tid < 44 ? 65536u : 0u;
   __syncthreads();
-  const u64 v0 = col[0];
-  bool differs = false, bad = false; unsigned vm = 0;
-  for (size_t i = tid; i < n; i += RC_THREADS) {
-    const u64 v = col[i];
-    if (v >= 65536) { bad = true; continue; }
-    differs |= v != v0; vm = vm > (unsigned)v ? vm : (unsigned)v;
-    atomicAdd(&t32[v >> 1], 1u << (16 * (v & 1)));
+  if (!BIG) {
+    const u64 v0 = col[0];
+    bool differs = false, bad = false; unsigned vm = 0;
+    for (size_t i = tid; i < n; i += RC_THREADS) {
+      const u64 v = col[i];
+      if (v >= 65536) { bad = true; continue; }
+      differs |= v != v0; vm = vm > (unsigned)v ? vm : (unsigned)v;
+      atomicAdd(&t32[v >> 1], 1u << (16 * (v & 1)));
+    }
+    if (bad) atomicOr(err, TG_ERR_RANGE);
+    if (differs) misc[32] = 1;
+    atomicMax(&misc[33], vm);
+    __syncthreads();
+    // a constant column wrapped its single u16 counter (65536 occurrences): clear it, T is implied by vmax alone
+    if (misc[32] == 0 && tid == 0) t32[v0 >> 1] = 0;
+    __syncthreads();
   }
-  if (bad) atomicOr(err, TG_ERR_RANGE);
-  if (differs) misc[32] = 1;
-  atomicMax(&misc[33], vm);
-  __syncthreads();
-  // a constant column wrapped its single u16 counter (65536 occurrences): clear it, T is implied by vmax alone
-  if (misc[32] == 0 && tid == 0) t32[v0 >> 1] = 0;
-  __syncthreads();
-  const int vmax = (int)misc[33];
 
   // counts -> inclusive prefix counts T (mod 2^16), in place
-  {
+  if (!BIG) {
     uint4* p = reinterpret_cast<uint4*>(t32 + 32 * tid);
     unsigned cw[32];
     for (int j = 0; j < 8; j++) { uint4 q = p[j]; cw[4 * j] = q.x; cw[4 * j + 1] = q.y; cw[4 * j + 2] = q.z; cw[4 * j + 3] = q.w; }
@@ -406,9 +427,33 @@ __global__ void __launch_bounds__(RC_THREADS) range_check_kernel(u64* __restrict
     for (int w = 0; w < (tid >> 6); w++) run += misc[w];
     for (int j = 0; j < 32; j++) { unsigned lo = run + (cw[j] & 0xffff), hi = lo + (cw[j] >> 16); run = hi; cw[j] = (lo & 0xffff) | (hi << 16); }
     for (int j = 0; j < 8; j++) p[j] = make_uint4(cw[4 * j], cw[4 * j + 1], cw[4 * j + 2], cw[4 * j + 3]);
+  } else {
+    // this lane's 64 values: counts from the HBM histogram (twice: total first, then the running prefix)
+    const unsigned int* cg = cnt + (size_t)kcol * 65536 + 64 * tid;
+    unsigned tot = 0, vm = 0;
+    for (int j = 0; j < 64; j++) { const unsigned c = cg[j]; tot += c; if (c) vm = (unsigned)(64 * tid + j); }
+    atomicMax(&misc[33], vm);
+    unsigned incl = tot;
+    for (int o = 1; o < 64; o <<= 1) { unsigned t = __shfl_up(incl, o, 64); if ((tid & 63) >= o) incl += t; }
+    if ((tid & 63) == 63) misc[tid >> 6] = incl;
+    __syncthreads();
+    unsigned run = incl - tot;
+    for (int w = 0; w < (tid >> 6); w++) run += misc[w];
+    for (int j = 0; j < 32; j++) {
+      const unsigned before = run;
+      const unsigned lo = run + cg[2 * j], hi = lo + cg[2 * j + 1];
+      run = hi;
+      t32[32 * tid + j] = (lo & 0xffff) | (hi << 16);
+      // thresholds: the first value at which T reaches k * 2^16 (k = 1..3)
+      for (unsigned k = (before >> 16) + 1; k <= (lo >> 16) && k < 4; k++) atomicMin(&misc[39 + k], (unsigned)(64 * tid + 2 * j));
+      for (unsigned k = (lo >> 16) + 1; k <= (hi >> 16) && k < 4; k++) atomicMin(&misc[39 + k], (unsigned)(64 * tid + 2 * j + 1));
+    }
   }
   __syncthreads();
-  auto T = [&](int v) -> int { return v < 0 ? 0 : (v >= vmax ? 65536 : (int)t16[v]); };
+  const int vmax = (int)misc[33];
+  const int thr1 = (int)misc[40], thr2 = (int)misc[41], thr3 = (int)misc[42];
+  auto Thi = [&](int v) -> int { return BIG ? ((v >= thr1) + (v >= thr2) + (v >= thr3)) << 16 : 0; };
+  auto T = [&](int v) -> int { return v < 0 ? 0 : (v >= vmax ? N : (int)t16[v] + Thi(v)); };
   auto S = [&](int v) -> int { return v >= 65535 ? INF : v + 1 - T(v); };
   for (int b = 0; b < 2; b++) {
     int m = INF;
@@ -437,7 +482,7 @@ __global__ void __launch_bounds__(RC_THREADS) range_check_kernel(u64* __restrict
       const unsigned w[4] = {q.x, q.y, q.z, q.w};
       for (int e = 0; e < 8; e++) {
         const int x = a + e;
-        const int tv = x >= vmax ? 65536 : (int)((w[e >> 1] >> (16 * (e & 1))) & 0xffff);
+        const int tv = x >= vmax ? N : (int)((w[e >> 1] >> (16 * (e & 1))) & 0xffff) + Thi(x);
         const int sx = x >= 65535 ? INF : x + 1 - tv;
         if (x >= from && sx < target) return x;
       }
@@ -467,27 +512,29 @@ __global__ void __launch_bounds__(RC_THREADS) range_check_kernel(u64* __restrict
     return scan32(fb * 32, target);
   };
   const int t_last = T(65534);  // = start of the 65535 run
+  // deferred slot of rank `rank`: the first -mfin of them are repeats met with an empty pool below 65535, the rest are the
+  // occurrences of 65535 beyond the table's KT copies (slots t_last + KT ...)
   auto assign_deferred = [&](int rank, int val) {
     int slot;
     if (rank < -mfin) { const int v = firstbelow(0, -rank); slot = v + rank + 1; }
-    else slot = t_last + 1 + (rank + mfin);
+    else slot = t_last + KT + (rank + mfin);
     perm_out[slot] = (u64)val;
   };
 
   int tprev = T(tid * 64 - 1);
   for (int j = 0; j < 64; j++) {
-    const int v = tid * 64 + j, tv = T(v), c = tv - tprev;
+    const int v = tid * 64 + j;
+    if (v == 65535) break;                           // handled by the whole block below
+    const int tv = T(v), c = tv - tprev;
     if (c > 0) {
       perm_out[tprev] = (u64)v;  // first occurrence takes its own table entry
-      if (c <= 64) { for (int d = 0; d < c; d++) sorted_out[tprev + d] = (u64)v; }
+      if (c <= HEAVY) { for (int d = 0; d < c; d++) sorted_out[tprev + d] = (u64)v; }
       else { const unsigned h = atomicAdd(&misc[34], 1u); heavy[h] = make_uint2((unsigned)v, (unsigned)tprev); }
-    } else if (v < 65535) {
+    } else {
       const int s = v + 1 - tv;
       const int x = firstbelow(v + 1, s);
       if (x >= 0) perm_out[x - s + 1] = (u64)v;
       else assign_deferred(s - mfin - 1, v);
-    } else {
-      assign_deferred(S(65534) + 1 - mfin - 1, 65535);
     }
     tprev = tv;
   }
@@ -496,6 +543,14 @@ __global__ void __launch_bounds__(RC_THREADS) range_check_kernel(u64* __restrict
   for (unsigned h = 0; h < nheavy; h++) {
     const int v = (int)heavy[h].x, st = (int)heavy[h].y, c = T(v) - st;
     for (int d = tid; d < c; d += RC_THREADS) sorted_out[st + d] = (u64)v;
+  }
+  // the run of 65535: c65 occurrences against KT table copies
+  {
+    const int c65 = N - t_last, eq = c65 < KT ? c65 : KT;
+    for (int d = tid; d < c65; d += RC_THREADS) sorted_out[t_last + d] = 65535;
+    for (int d = tid; d < eq; d += RC_THREADS) perm_out[t_last + d] = 65535;
+    const int pooled = S(65534) - mfin;              // pool height after the values below 65535 = rank of the first left-over 65535
+    for (int r = tid; r < KT - c65; r += RC_THREADS) assign_deferred(pooled + r, 65535);
   }
 }
 

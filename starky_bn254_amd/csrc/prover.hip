@@ -609,7 +609,11 @@ extern "C" int sbn_prover_load_trace_device(sbn_prover* P, const uint64_t* d_tra
 static int range_check_setup(int device) {
   static std::atomic<bool> done[SBN_MAX_DEVICES];
   const int d = device >= 0 && device < SBN_MAX_DEVICES ? device : 0;
-  if (!done[d].load()) { HIPC(hipFuncSetAttribute((const void*)tg::range_check_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tg::RC_LDS_BYTES)); done[d].store(true); }
+  if (!done[d].load()) {
+    HIPC(hipFuncSetAttribute((const void*)tg::range_check_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tg::RC_LDS_BYTES));
+    HIPC(hipFuncSetAttribute((const void*)tg::range_check_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tg::RC_LDS_BYTES));
+    done[d].store(true);
+  }
   return 0;
 }
 template <int E>
@@ -637,6 +641,7 @@ static int generate_trace_device(sbn_prover* P, const uint32_t* ios, size_t K, u
   unsigned char* row_op = (unsigned char*)take(n / 8 + 1);
   uint32_t* d_ios = (uint32_t*)take(IOW * K / 2 + 1);
   int* d_err = (int*)take(1);
+  unsigned int* d_cnt = n > 65536 ? (unsigned int*)take((size_t)sh.num_rc * 32768) : nullptr;   // u32 histograms of the range-checked columns
   if ((size_t)(w - wbase) > P->lde_scratch_words) return fail(SBN_ERR_UNSUPPORTED, "scratch does not fit");
   if (int rc = range_check_setup(P->device)) return rc;
 
@@ -674,7 +679,13 @@ static int generate_trace_device(sbn_prover* P, const uint32_t* ios, size_t K, u
   mark();
   hipLaunchKernelGGL(tg::row_witness_kernel<E>, blocks(n, 128), dim3(128), 0, st, sv, row_op, n, sh.gadget_col, P->d_trace, d_err);
   mark();
-  hipLaunchKernelGGL(tg::range_check_kernel, dim3((unsigned)sh.num_rc), dim3(tg::RC_THREADS), tg::RC_LDS_BYTES, st, P->d_trace, n, sh.rc_start, sh.start_lookups, d_err);
+  if (n > 65536) {   // multiplicities beyond u16: histogram of every target column in HBM first (kernels_tracegen.cuh)
+    HIPC(hipMemsetAsync(d_cnt, 0, (size_t)sh.num_rc * 65536 * sizeof(unsigned int), st));
+    hipLaunchKernelGGL(tg::range_count_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)sh.num_rc), dim3(256), 0, st, P->d_trace, n, sh.rc_start, d_cnt, d_err);
+    hipLaunchKernelGGL(tg::range_check_kernel<true>, dim3((unsigned)sh.num_rc), dim3(tg::RC_THREADS), tg::RC_LDS_BYTES, st, P->d_trace, n, sh.rc_start, sh.start_lookups, d_err, d_cnt);
+  } else {
+    hipLaunchKernelGGL(tg::range_check_kernel<false>, dim3((unsigned)sh.num_rc), dim3(tg::RC_THREADS), tg::RC_LDS_BYTES, st, P->d_trace, n, sh.rc_start, sh.start_lookups, d_err, (const unsigned int*)nullptr);
+  }
   mark();
   HIPC(hipGetLastError());
   std::vector<u64> out(16 * E * K); int err = 0;
@@ -813,6 +824,8 @@ static int generate_trace_device_fq(sbn_prover* P, const uint32_t* ios, size_t K
   u64* inv = take(n);
   uint32_t* d_ios = (uint32_t*)take(IOW * K / 2 + 1);
   int* d_err = (int*)take(1);
+  unsigned int* d_cnt = n > 65536 ? (unsigned int*)take((size_t)sh.num_rc * 32768) : nullptr;   // u32 histograms of the range-checked columns
+  if ((size_t)(w - wbase) > P->lde_scratch_words) return fail(SBN_ERR_UNSUPPORTED, "scratch does not fit");
   if (int rc = range_check_setup(P->device)) return rc;
   hipEvent_t e0 = P->abs_ev[0], e1 = P->abs_ev[1];
   HIPC(hipEventRecord(e0, st));
@@ -832,7 +845,13 @@ static int generate_trace_device_fq(sbn_prover* P, const uint32_t* ios, size_t K
   tracegen_host_chains_fq(ios, K, P->h_chain, P->h_chain + cw);
   HIPC(hipMemcpyAsync(ca, P->h_chain, 2 * cw * sizeof(u64), hipMemcpyHostToDevice, st));  // ca and cb are adjacent
   hipLaunchKernelGGL(tg::fq_row_kernel, blocks(n, 128), dim3(128), 0, st, d_ios, ca, cb, n, P->d_trace, d_err);
-  hipLaunchKernelGGL(tg::range_check_kernel, dim3((unsigned)sh.num_rc), dim3(tg::RC_THREADS), tg::RC_LDS_BYTES, st, P->d_trace, n, sh.rc_start, sh.start_lookups, d_err);
+  if (n > 65536) {   // multiplicities beyond u16: histogram of every target column in HBM first (kernels_tracegen.cuh)
+    HIPC(hipMemsetAsync(d_cnt, 0, (size_t)sh.num_rc * 65536 * sizeof(unsigned int), st));
+    hipLaunchKernelGGL(tg::range_count_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)sh.num_rc), dim3(256), 0, st, P->d_trace, n, sh.rc_start, d_cnt, d_err);
+    hipLaunchKernelGGL(tg::range_check_kernel<true>, dim3((unsigned)sh.num_rc), dim3(tg::RC_THREADS), tg::RC_LDS_BYTES, st, P->d_trace, n, sh.rc_start, sh.start_lookups, d_err, d_cnt);
+  } else {
+    hipLaunchKernelGGL(tg::range_check_kernel<false>, dim3((unsigned)sh.num_rc), dim3(tg::RC_THREADS), tg::RC_LDS_BYTES, st, P->d_trace, n, sh.rc_start, sh.start_lookups, d_err, (const unsigned int*)nullptr);
+  }
   HIPC(hipGetLastError());
   int err = 0;
   HIPC(hipMemcpyAsync(&err, d_err, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -861,7 +880,7 @@ extern "C" int sbn_prover_generate_trace(sbn_prover* P, const uint32_t* ios, siz
   if (num_io != P->air.num_io) return fail(SBN_ERR_BAD_ARG, "prover was created for %u instances, got %zu", P->air.num_io, num_io);
   if (P->n != exp_rows_per_instance(P->air.kind) * num_io) return fail(SBN_ERR_BAD_ARG, "degree_bits does not match the rows per instance");
   if (P->air.kind == SBN_AIR_FQ12_EXP || P->air.kind == SBN_AIR_FQ12_EXP_U64) return generate_trace_device_fq12(P, ios, num_io, pi_out);
-  if (P->n != 65536) return fail(SBN_ERR_UNSUPPORTED, "device witness generation needs exactly 2^16 rows (u16 histogram in LDS)");
+  if (P->n < 65536 || P->n > 262144) return fail(SBN_ERR_UNSUPPORTED, "device witness generation of the u16-range-check tables covers 2^16 .. 2^18 rows");
   if (P->air.kind == SBN_AIR_FQ_EXP) return generate_trace_device_fq(P, ios, num_io, pi_out);
   return P->air.kind == SBN_AIR_G1_EXP ? generate_trace_device<1>(P, ios, num_io, pi_out) : generate_trace_device<2>(P, ios, num_io, pi_out);
 }

@@ -206,6 +206,43 @@ def test_g1exp_device_witness_generation_matches_oracle(gpu, O, g1exp_case, g1ex
         prover.close()
 
 
+@pytest.mark.parametrize("table,num_io", [("g1", 256), ("fq", 512)])
+def test_device_witness_above_2pow16_rows(gpu, O, table, num_io):
+    """The reference pads the instance list to any power of two >= 128 (src/curves/g1/circuit.rs:273-277), i.e. tables of
+    2^17, 2^18 ... rows, where the multiplicities of the u16 range check no longer fit 16-bit counters (the table column then
+    ends in n - 65535 copies of 65535).  Device witness == the product's host generator, word for word, on random instances
+    and on instances whose range-checked columns are mostly one value (multiplicity > 2^16); the proof verifies."""
+    if table == "g1":
+        ios, _ = O.g1exp_inputs(num_io, 21)
+        stark = gpu.G1ExpStark(num_io)
+        e0 = 32
+    else:
+        ios, _ = O.fqexp_inputs(num_io, 22)
+        stark = gpu.FqExpStark(num_io)
+        e0 = 16
+    cfg = stark.config()
+    bits = (512 * num_io).bit_length() - 1
+    prover = gpu.Prover(stark, cfg, bits)
+    try:
+        for variant in range(2):
+            if variant == 1:
+                ios = ios.copy()
+                ios[:, e0:e0 + 8] = 0                          # exponent 0: no additions / multiplications at all
+                ios[3, e0:e0 + 8] = 0xFFFFFFFF
+            pi = prover.generate_trace(ios)
+            t_host, pi_host = stark.generate_trace_and_public_inputs(ios)
+            assert np.array_equal(pi, pi_host)
+            dev = prover.read_trace()
+            bad = np.nonzero((dev != t_host).any(axis=1))[0]
+            assert bad.size == 0, f"variant {variant}: first differing columns: {bad[:8].tolist()}"
+            del dev, t_host
+        proof = prover.prove()
+        gpu.verify_stark_proof(stark, proof, cfg)
+        assert proof.recover_degree_bits(cfg) == bits
+    finally:
+        prover.close()
+
+
 def test_prover_argument_errors(gpu, g1op_case):
     stark = gpu.G1Stark()
     cfg = stark.config()
