@@ -104,6 +104,68 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassParams p) 
 // congruent mod p) until the final store.  ~200 instructions per element per pass instead of ~450.
 // -------------------------------------------------------------------------------------------------------------
 namespace nw {
+// Weak Goldilocks arithmetic (any u64 congruent to the value) from SINGLE-INSTRUCTION asm primitives: carries and borrows
+// stay in SGPR pairs (v_add_co / v_addc / v_sub_co / v_subb with explicit carry operands) and are repaid by
+// v_mad_u64_u32 x, -1 (x + c (2^32 - 1)) instead of the 64-bit compare + two selects the compiler emits for
+// `if (s < a) s += EPS`.  The compiler still allocates every register, schedules, and pads the SGPR write -> read wait states
+// itself (it sees each primitive's operands), so there is no fixed register window.  A 16-point DFT drops from 942 VALU
+// instructions (+213 s_nop) to 656, a general multiply from 33 to 21.  Set SBN_NTT_CXX_ARITH at compile time for the plain
+// C++ forms (A/B measurements).
+#if !defined(SBN_NTT_CXX_ARITH)
+__device__ __forceinline__ u32 lo32(u64 x) { return (u32)x; }
+__device__ __forceinline__ u32 hi32(u64 x) { return (u32)(x >> 32); }
+__device__ __forceinline__ u64 pack(u32 lo, u32 hi) { return ((u64)hi << 32) | lo; }
+__device__ __forceinline__ u32 addco(u32 a, u32 b, u64& k) { u32 r; asm("v_add_co_u32_e64 %0, %1, %2, %3" : "=v"(r), "=s"(k) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ u32 addc(u32 a, u32 b, u64 kin, u64& kout) { u32 r; asm("v_addc_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(r), "=s"(kout) : "v"(a), "v"(b), "s"(kin)); return r; }
+__device__ __forceinline__ u32 subco(u32 a, u32 b, u64& k) { u32 r; asm("v_sub_co_u32_e64 %0, %1, %2, %3" : "=v"(r), "=s"(k) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ u32 subb(u32 a, u32 b, u64 kin, u64& kout) { u32 r; asm("v_subb_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(r), "=s"(kout) : "v"(a), "v"(b), "s"(kin)); return r; }
+__device__ __forceinline__ u32 subb0(u32 a, u64 kin, u64& kout) { u32 r; asm("v_subbrev_co_u32_e64 %0, %1, 0, %2, %3" : "=v"(r), "=s"(kout) : "v"(a), "s"(kin)); return r; }
+__device__ __forceinline__ u32 sel01(u64 k) { u32 r; asm("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(r) : "s"(k)); return r; }
+__device__ __forceinline__ u32 selm1(u64 k) { u32 r; asm("v_cndmask_b32_e64 %0, 0, -1, %1" : "=v"(r) : "s"(k)); return r; }
+__device__ __forceinline__ u64 mad(u32 a, u32 b, u64 c, u64& k) { u64 r; asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(r), "=s"(k) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ u64 mad0(u32 a, u32 b) { u64 r, k; asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(r), "=s"(k) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ u64 madm1(u32 a, u64 c, u64& k) { u64 r; asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(r), "=s"(k) : "v"(a), "v"(c)); return r; }   // a * (2^32 - 1) + c
+// x + carry * (2^32 - 1), twice (the first repayment can wrap again only from the top 2^32 values)
+__device__ __forceinline__ u64 repay_carry(u64 s, u64 k) { u64 k2, k3; u64 t = madm1(sel01(k), s, k2); return madm1(sel01(k2), t, k3); }
+__device__ __forceinline__ u64 add(u64 a, u64 b) {
+  u64 k1, k2; u32 lo = addco(lo32(a), lo32(b), k1); u32 hi = addc(hi32(a), hi32(b), k1, k2);
+  return repay_carry(pack(lo, hi), k2);
+}
+__device__ __forceinline__ u64 sub(u64 a, u64 b) {   // a - b - borrow * (2^32 - 1), twice
+  u64 k1, k2, k3, k4, k5, k6;
+  u32 lo = subco(lo32(a), lo32(b), k1); u32 hi = subb(hi32(a), hi32(b), k1, k2);
+  u32 l2 = subco(lo, selm1(k2), k3); u32 h2 = subb0(hi, k3, k4);
+  u32 l3 = subco(l2, selm1(k4), k5); u32 h3 = subb0(h2, k5, k6);
+  return pack(l3, h3);
+}
+// (hi : lo) mod p for hi < 2^32:  lo + hi * (2^32 - 1)
+__device__ __forceinline__ u64 red32(u64 lo, u32 hi) { u64 k; u64 t = madm1(hi, lo, k); u64 k2; return madm1(sel01(k), t, k2); }
+// (hi : lo) mod p, weak:  lo - hi_hi + hi_lo * (2^32 - 1)
+__device__ __forceinline__ u64 red(u64 lo, u64 hi) {
+  u64 k1, k2, k3, k4;
+  u32 l = subco(lo32(lo), hi32(hi), k1); u32 h = subb0(hi32(lo), k1, k2);
+  u32 l2 = subco(l, selm1(k2), k3); u32 h2 = subb0(h, k3, k4);          // borrow: 2^64 = 2^32 - 1 more to take off; cannot borrow again
+  return red32(pack(l2, h2), lo32(hi));
+}
+template <int E> __device__ __forceinline__ u64 mul_pow2(u64 x) {  // x * 2^E, 0 <= E < 96
+  if constexpr (E == 0) return x;
+  else if constexpr (E < 32) return red32(x << E, hi32(x) >> (32 - E));
+  else if constexpr (E == 32) return red32(pack(0, lo32(x)), hi32(x));
+  else if constexpr (E < 64) return red(pack(0, lo32(x) << (E - 32)), x >> (64 - E));
+  else return mul_pow2<E - 48>(mul_pow2<48>(x));
+}
+__device__ __forceinline__ u64 mul(u64 a, u64 b) {
+  const u32 a0 = lo32(a), a1 = hi32(a), b0 = lo32(b), b1 = hi32(b);
+  u64 k;
+  const u64 p0 = mad0(a0, b0);
+  const u64 p1 = mad(a0, b1, (u64)hi32(p0), k);
+  const u64 p2 = mad(a1, b0, (u64)lo32(p1), k);
+  u64 kc; const u32 sl = addco(hi32(p1), hi32(p2), kc);
+  const u64 p3 = mad(a1, b1, pack(sl, sel01(kc)), k);
+  return red(pack(lo32(p0), lo32(p2)), p3);
+}
+__device__ __forceinline__ u64 canon(u64 x) { return x >= GLP ? x - GLP : x; }
+#else
 __device__ __forceinline__ u64 add(u64 a, u64 b) {
   u64 s = a + b;
   u64 c = s < a ? GLEPS : 0;
@@ -134,6 +196,7 @@ template <int E> __device__ __forceinline__ u64 mul_pow2(u64 x) {  // x * 2^E, 0
 }
 __device__ __forceinline__ u64 mul(u64 a, u64 b) { return red(a * b, __umul64hi(a, b)); }
 __device__ __forceinline__ u64 canon(u64 x) { return x >= GLP ? x - GLP : x; }
+#endif
 
 #define NW_BF(i, j, E) { u64 a_ = x[i], b_ = x[j]; x[i] = add(a_, b_); x[j] = mul_pow2<E>(sub(a_, b_)); }
 // 16-point DIF DFT with root rho = 2^12; x[p] <- DFT_rho[bitrev4(p)]

@@ -394,7 +394,7 @@ __global__ void __launch_bounds__(RC_THREADS) range_check_kernel(u64* __restrict
   for (int i = tid; i < 32768; i += RC_THREADS) t32[i] = 0;
   if (tid < 64) misc[tid] = tid >= 40 && tid < 44 ? 65536u : 0u;
   __syncthreads();
-  if (!BIG) {
+  if constexpr (!BIG) {
     const u64 v0 = col[0];
     bool differs = false, bad = false; unsigned vm = 0;
     for (size_t i = tid; i < n; i += RC_THREADS) {
@@ -413,7 +413,7 @@ __global__ void __launch_bounds__(RC_THREADS) range_check_kernel(u64* __restrict
   }
 
   // counts -> inclusive prefix counts T (mod 2^16), in place
-  if (!BIG) {
+  if constexpr (!BIG) {
     uint4* p = reinterpret_cast<uint4*>(t32 + 32 * tid);
     unsigned cw[32];
     for (int j = 0; j < 8; j++) { uint4 q = p[j]; cw[4 * j] = q.x; cw[4 * j + 1] = q.y; cw[4 * j + 2] = q.z; cw[4 * j + 3] = q.w; }
@@ -452,9 +452,9 @@ __global__ void __launch_bounds__(RC_THREADS) range_check_kernel(u64* __restrict
   __syncthreads();
   const int vmax = (int)misc[33];
   const int thr1 = (int)misc[40], thr2 = (int)misc[41], thr3 = (int)misc[42];
-  auto Thi = [&](int v) -> int { return BIG ? ((v >= thr1) + (v >= thr2) + (v >= thr3)) << 16 : 0; };
-  auto T = [&](int v) -> int { return v < 0 ? 0 : (v >= vmax ? N : (int)t16[v] + Thi(v)); };
-  auto S = [&](int v) -> int { return v >= 65535 ? INF : v + 1 - T(v); };
+  auto Thi = [&](int v) __attribute__((always_inline)) -> int { return BIG ? ((v >= thr1) + (v >= thr2) + (v >= thr3)) << 16 : 0; };
+  auto T = [&](int v) __attribute__((always_inline)) -> int { return v < 0 ? 0 : (v >= vmax ? N : (int)t16[v] + Thi(v)); };
+  auto S = [&](int v) __attribute__((always_inline)) -> int { return v >= 65535 ? INF : v + 1 - T(v); };
   for (int b = 0; b < 2; b++) {
     int m = INF;
     for (int j = 0; j < 32; j++) { int s = S(tid * 64 + b * 32 + j); m = s < m ? s : m; }
@@ -475,7 +475,7 @@ __global__ void __launch_bounds__(RC_THREADS) range_check_kernel(u64* __restrict
   __syncthreads();
 
   // first x in [from, from | 31] with S(x) < target, or -1 (8 prefix counts per LDS read)
-  auto scan32 = [&](int from, int target) -> int {
+  auto scan32 = [&](int from, int target) __attribute__((always_inline)) -> int {
     const int hi = from | 31;
     for (int a = from & ~7; a <= hi; a += 8) {
       const uint4 q = *reinterpret_cast<const uint4*>(t16 + a);
@@ -490,7 +490,7 @@ __global__ void __launch_bounds__(RC_THREADS) range_check_kernel(u64* __restrict
     return -1;
   };
   // first index in [from, hi] with arr[index] < target, or -1 (arr 16-byte aligned, hi + 1 a multiple of 4)
-  auto scan_min = [&](const int* arr, int from, int hi, int target) -> int {
+  auto scan_min = [&](const int* arr, int from, int hi, int target) __attribute__((always_inline)) -> int {
     for (int a = from & ~3; a <= hi; a += 4) {
       const int4 q = *reinterpret_cast<const int4*>(arr + a);
       if (a >= from && q.x < target) return a;
@@ -501,7 +501,7 @@ __global__ void __launch_bounds__(RC_THREADS) range_check_kernel(u64* __restrict
     return -1;
   };
   // first x in [from, 65534] with S(x) < target, or -1
-  auto firstbelow = [&](int from, int target) -> int {
+  auto firstbelow = [&](int from, int target) __attribute__((always_inline)) -> int {
     if (from > 65534) return -1;
     const int x = scan32(from, target);
     if (x >= 0) return x;
@@ -514,7 +514,7 @@ __global__ void __launch_bounds__(RC_THREADS) range_check_kernel(u64* __restrict
   const int t_last = T(65534);  // = start of the 65535 run
   // deferred slot of rank `rank`: the first -mfin of them are repeats met with an empty pool below 65535, the rest are the
   // occurrences of 65535 beyond the table's KT copies (slots t_last + KT ...)
-  auto assign_deferred = [&](int rank, int val) {
+  auto assign_deferred = [&](int rank, int val) __attribute__((always_inline)) {
     int slot;
     if (rank < -mfin) { const int v = firstbelow(0, -rank); slot = v + rank + 1; }
     else slot = t_last + KT + (rank + mfin);
