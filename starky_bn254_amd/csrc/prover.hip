@@ -102,9 +102,6 @@ struct sbn_prover {
   size_t ntt_chunk;
   bool fast_ntt = true;                      // SBN_FAST_NTT=0 selects the generic radix-2 pass everywhere
   hipStream_t hstream = nullptr;             // sponge absorption / Merkle stream
-  hipStream_t lstream = nullptr;             // coset LDE of the commit pipeline (the iNTT of the next chunk runs on the main stream)
-  hipEvent_t intt_ready[MAX_CHUNKS];         // main -> LDE stream: coefficients of chunk k are complete
-  u64* d_tmp2 = nullptr;                     // NTT scratch of the LDE stream
   hipEvent_t chunk_ready[MAX_CHUNKS];        // main -> hash: LDE chunk k is complete
   hipEvent_t abs_ev[2 * MAX_CHUNKS];         // hash stream: before/after each absorb launch
   hipEvent_t hash_done;                      // hash -> main
@@ -262,22 +259,16 @@ static int commit_pipeline(sbn_prover* P, const u64* vals, u64* coef, u64* lde, 
   size_t ch = P->ntt_chunk;
   size_t nchunks = (ncols + ch - 1) / ch;
   if (nchunks > (size_t)MAX_CHUNKS) return fail(SBN_ERR_UNSUPPORTED, "too many column chunks");
-  // Three streams: iNTT of chunk k on the main stream, its coset LDE on the LDE stream (own scratch), the sponge over the
-  // chunk's LDE on the hash stream.  A pass kernel is latency-bound (~0.12 ms whatever the chunk, 1,024 workgroups = one
-  // wave of them), so iNTT + LDE back to back on one stream (0.5 ms per chunk) was as long as the chunk's sponge launch
-  // (0.46 ms) and set the pace of the stage; split over two streams the transform of chunk k+1 hides behind the LDE of k.
-  HIPC(hipEventRecord(P->hash_done, P->stream));          // the values are final on the main stream
-  HIPC(hipStreamWaitEvent(P->lstream, P->hash_done, 0));
+  // Two streams: iNTT + coset LDE of chunk k on the main stream, the sponge over the chunk's LDE on the hash stream.
+  // MEASURED and dropped (profiles/r2_bench_3stream.json): a third stream for the LDE, so that the iNTT of chunk k+1 hides
+  // behind the LDE of chunk k -- 28.3 -> 29.6 ms per proof: the stage is bound by the VALU work of sponge + transforms
+  // together, not by the latency of the transform stream, and more transform waves in flight only slow the sponge launches
+  // (12.3 -> 14.8 ms of sponge kernel time).
   for (size_t k = 0; k < nchunks; k++) {
     size_t c0 = k * ch, nc = std::min(ch, ncols - c0);
-    int rc = ntt_columns(P, vals + c0 * P->n, P->n, coef + c0 * P->n, P->n, P->d_tmp, P->m, nc, P->degree_bits, true, P->n, nullptr, nullptr,
-                         host_inv_pow2(P->degree_bits));
+    int rc = intt_then_lde_chunk(P, vals, coef, lde, c0, nc);
     if (rc) return rc;
-    HIPC(hipEventRecord(P->intt_ready[k], P->stream));
-    HIPC(hipStreamWaitEvent(P->lstream, P->intt_ready[k], 0));
-    rc = ntt_columns(P, coef + c0 * P->n, P->n, lde + c0 * P->m, P->m, P->d_tmp2, P->m, nc, P->lde_log, false, P->n, P->d_shift, nullptr, 1, P->lstream);
-    if (rc) return rc;
-    HIPC(hipEventRecord(P->chunk_ready[k], P->lstream));
+    HIPC(hipEventRecord(P->chunk_ready[k], P->stream));
     HIPC(hipStreamWaitEvent(P->hstream, P->chunk_ready[k], 0));
     HIPC(hipEventRecord(P->abs_ev[2 * k], P->hstream));
     hipLaunchKernelGGL(leaf_absorb_kernel, dim3((unsigned)((P->m + 255) / 256)), dim3(256), 0, P->hstream, lde + c0 * P->m, P->m, P->lde_log, (u32)nc,
@@ -445,8 +436,6 @@ static int create_ctx(const sbn_air_desc* air, const sbn_config* cfg, uint32_t d
   acc(ntt_fast_setup());
   hipc(hipStreamCreate(&P->stream), "hipStreamCreate");
   hipc(hipStreamCreate(&P->hstream), "hipStreamCreate");
-  hipc(hipStreamCreate(&P->lstream), "hipStreamCreate");
-  for (auto& e : P->intt_ready) hipc(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
   for (auto& e : P->ev) hipc(hipEventCreate(&e), "hipEventCreate");
   for (auto& e : P->abs_ev) hipc(hipEventCreate(&e), "hipEventCreate");
   for (auto& e : P->chunk_ready) hipc(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
@@ -490,7 +479,6 @@ static int create_ctx(const sbn_air_desc* air, const sbn_config* cfg, uint32_t d
     acc(tree_alloc(P->tree_t, m, cfg->cap_height)); acc(tree_alloc(P->tree_z, m, cfg->cap_height));
   }
   acc(dmalloc(&P->d_tmp, std::max(P->ntt_chunk, (size_t)4) * m));
-  acc(dmalloc(&P->d_tmp2, std::max(P->ntt_chunk, (size_t)4) * m));
   acc(dmalloc(&P->d_q, 2 * m)); acc(dmalloc(&P->d_qlde, 4 * m));
   acc(tree_alloc(P->tree_q, m, cfg->cap_height));
   acc(dmalloc(&P->d_tw_f, m / 2)); acc(dmalloc(&P->d_tw_i, m / 2)); acc(dmalloc(&P->d_shift, m)); acc(dmalloc(&P->d_shift_inv, m));
@@ -573,9 +561,6 @@ extern "C" void sbn_prover_destroy(sbn_prover* P) {
   for (auto& e : P->ev) if (e) (void)hipEventDestroy(e);   // a partly built context (failed create) holds null handles
   for (auto& e : P->abs_ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : P->chunk_ready) if (e) (void)hipEventDestroy(e);
-  for (auto& e : P->intt_ready) if (e) (void)hipEventDestroy(e);
-  if (P->d_tmp2) (void)hipFree(P->d_tmp2);
-  if (P->lstream) (void)hipStreamDestroy(P->lstream);
   if (P->hash_done) (void)hipEventDestroy(P->hash_done);
   if (P->d_sponge) (void)hipFree(P->d_sponge);
   if (P->h_chain) (void)hipHostFree(P->h_chain);
