@@ -78,6 +78,9 @@ pub struct Prover {
     raw: *mut ffi::sbn_prover,
     num_io: usize,
     n_pi: usize,
+    n_cols: usize,
+    degree_bits: usize,
+    io_words: usize,
 }
 // one prover belongs to one thread at a time (include/sbn.h, "Threading")
 unsafe impl Send for Prover {}
@@ -88,13 +91,33 @@ impl Prover {
         let cfg = to_sbn_config(config)?;
         let mut raw = ptr::null_mut();
         check(unsafe { ffi::sbn_prover_create(&a, &cfg, degree_bits as u32, &mut raw) }, "sbn_prover_create")?;
-        Ok(Self { raw, num_io: a.num_io as usize, n_pi: unsafe { ffi::sbn_air_num_public_inputs(&a) } })
+        // u32 words of one instance in `ios` (include/sbn.h, per table)
+        let io_words = match a.kind {
+            ffi::SBN_AIR_G1_EXP => 40,
+            ffi::SBN_AIR_G2_EXP => 72,
+            ffi::SBN_AIR_FQ12_EXP => 200,
+            ffi::SBN_AIR_FQ_EXP => 24,
+            ffi::SBN_AIR_FQ12_EXP_U64 => 194,
+            _ => 0,
+        };
+        Ok(Self {
+            raw,
+            num_io: a.num_io as usize,
+            n_pi: unsafe { ffi::sbn_air_num_public_inputs(&a) },
+            n_cols: unsafe { ffi::sbn_air_num_columns(&a) },
+            degree_bits,
+            io_words,
+        })
     }
 
     /// `prove(stark, &config, trace, pi, &mut timing)` with a host-built trace: column-major already, one copy to
     /// flatten it and one PCIe transfer (0.88 GB for G1ExpStark(128)).
     pub fn prove(&mut self, trace: Vec<PolynomialValues<F>>, public_inputs: &[F]) -> Result<Proof> {
         let n = trace.first().map(|c| c.len()).unwrap_or(0);
+        // sbn_prover_load_trace reads num_columns * 2^degree_bits words and n_pi public inputs: check before the FFI call
+        ensure!(trace.len() == self.n_cols, "the table has {} columns, the trace {}", self.n_cols, trace.len());
+        ensure!(n == 1usize << self.degree_bits, "the prover was created for 2^{} rows, the trace has {}", self.degree_bits, n);
+        ensure!(public_inputs.len() == self.n_pi, "expected {} public inputs, got {}", self.n_pi, public_inputs.len());
         let mut flat = Vec::with_capacity(trace.len() * n);
         for col in &trace {
             ensure!(col.len() == n, "ragged trace");
@@ -110,7 +133,8 @@ impl Prover {
     /// include/sbn.h documents per table); no trace on the host at all.  Returns the proof; its `public_inputs` are the
     /// ones `generate_public_inputs` would have produced.
     pub fn prove_ios(&mut self, ios: &[u32]) -> Result<Proof> {
-        ensure!(self.num_io > 0 && ios.len() % self.num_io == 0, "ios length is not a multiple of num_io");
+        ensure!(self.io_words > 0, "device witness generation covers the Exp tables");
+        ensure!(ios.len() == self.io_words * self.num_io, "ios must hold {} u32 words per instance x {} instances", self.io_words, self.num_io);
         let mut pi = vec![0u64; self.n_pi];
         check(unsafe { ffi::sbn_prover_generate_trace(self.raw, ios.as_ptr(), self.num_io, pi.as_mut_ptr()) }, "sbn_prover_generate_trace")?;
         self.finish()
@@ -160,8 +184,10 @@ pub fn prove_batch<S: SbnTable>(stark: &S, config: &StarkConfig, degree_bits: us
         .collect()
 }
 
-/// `verify_stark_proof(stark, proof, &config)` on the library's host verifier (no GPU needed).  The reference's own
-/// starky verifier accepts the converted proof as well; this one exists so that the two can be compared.
+/// `verify_stark_proof(stark, proof, &config)` on the library's host verifier (no GPU needed).  Whether the reference's
+/// own starky verifier accepts the converted proof is UNTESTED (this crate has never been compiled: no Rust toolchain in
+/// the build image); it hinges on the recalled protocol details of DESIGN.md section 4, first of all on
+/// `FRI_FINAL_POLY_TIMES_X` matching the linked plonky2.  This function exists so that the two verifiers can be compared.
 pub fn verify_stark_proof_words<S: SbnTable>(stark: &S, words: &[u64], config: &StarkConfig) -> Result<()> {
     let a = air(stark);
     let cfg = to_sbn_config(config)?;
