@@ -83,6 +83,27 @@ GL_HD F operator*(F a, F b) { return F(gl_mul_dev(a.v, b.v)); }
 #else
 GL_HD F operator*(F a, F b) { return F(gl_reduce128(a.v * b.v, gl_mulhi(a.v, b.v))); }
 #endif
+#if defined(__HIP_DEVICE_COMPILE__)
+// Single-instruction asm primitives with explicit carry operands (SGPR pairs): the building blocks of the weak arithmetic
+// in the NTT (kernels.cuh, namespace nw) and of the sponge's constant additions (poseidon.cuh).  The compiler allocates
+// every register and pads the SGPR write -> read wait states (it sees the operands of each statement).
+namespace gp {
+__device__ __forceinline__ u32 lo32(u64 x) { return (u32)x; }
+__device__ __forceinline__ u32 hi32(u64 x) { return (u32)(x >> 32); }
+__device__ __forceinline__ u64 pack(u32 lo, u32 hi) { return ((u64)hi << 32) | lo; }
+__device__ __forceinline__ u32 addco(u32 a, u32 b, u64& k) { u32 r; asm("v_add_co_u32_e64 %0, %1, %2, %3" : "=v"(r), "=s"(k) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ u32 addc(u32 a, u32 b, u64 kin, u64& kout) { u32 r; asm("v_addc_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(r), "=s"(kout) : "v"(a), "v"(b), "s"(kin)); return r; }
+__device__ __forceinline__ u32 subco(u32 a, u32 b, u64& k) { u32 r; asm("v_sub_co_u32_e64 %0, %1, %2, %3" : "=v"(r), "=s"(k) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ u32 subb(u32 a, u32 b, u64 kin, u64& kout) { u32 r; asm("v_subb_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(r), "=s"(kout) : "v"(a), "v"(b), "s"(kin)); return r; }
+__device__ __forceinline__ u32 subb0(u32 a, u64 kin, u64& kout) { u32 r; asm("v_subbrev_co_u32_e64 %0, %1, 0, %2, %3" : "=v"(r), "=s"(kout) : "v"(a), "s"(kin)); return r; }
+__device__ __forceinline__ u32 sel01(u64 k) { u32 r; asm("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(r) : "s"(k)); return r; }
+__device__ __forceinline__ u32 selm1(u64 k) { u32 r; asm("v_cndmask_b32_e64 %0, 0, -1, %1" : "=v"(r) : "s"(k)); return r; }
+__device__ __forceinline__ u64 mad(u32 a, u32 b, u64 c, u64& k) { u64 r; asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(r), "=s"(k) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ u64 mad0(u32 a, u32 b) { u64 r, k; asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(r), "=s"(k) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ u64 madm1(u32 a, u64 c, u64& k) { u64 r; asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(r), "=s"(k) : "v"(a), "v"(c)); return r; }   // a * (2^32 - 1) + c
+__device__ __forceinline__ u64 cmp_lt_s(u64 x, u64 c) { u64 k; asm("v_cmp_lt_u64_e64 %0, %1, %2" : "=s"(k) : "v"(x), "s"(c)); return k; }   // lanes with x < c (c uniform)
+}  // namespace gp
+#endif
 GL_HD F& operator+=(F& a, F b) { a = a + b; return a; }
 GL_HD F& operator-=(F& a, F b) { a = a - b; return a; }
 GL_HD F& operator*=(F& a, F b) { a = a * b; return a; }

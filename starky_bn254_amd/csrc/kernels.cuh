@@ -112,19 +112,7 @@ namespace nw {
 // instructions (+213 s_nop) to 656, a general multiply from 33 to 21.  Set SBN_NTT_CXX_ARITH at compile time for the plain
 // C++ forms (A/B measurements).
 #if !defined(SBN_NTT_CXX_ARITH)
-__device__ __forceinline__ u32 lo32(u64 x) { return (u32)x; }
-__device__ __forceinline__ u32 hi32(u64 x) { return (u32)(x >> 32); }
-__device__ __forceinline__ u64 pack(u32 lo, u32 hi) { return ((u64)hi << 32) | lo; }
-__device__ __forceinline__ u32 addco(u32 a, u32 b, u64& k) { u32 r; asm("v_add_co_u32_e64 %0, %1, %2, %3" : "=v"(r), "=s"(k) : "v"(a), "v"(b)); return r; }
-__device__ __forceinline__ u32 addc(u32 a, u32 b, u64 kin, u64& kout) { u32 r; asm("v_addc_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(r), "=s"(kout) : "v"(a), "v"(b), "s"(kin)); return r; }
-__device__ __forceinline__ u32 subco(u32 a, u32 b, u64& k) { u32 r; asm("v_sub_co_u32_e64 %0, %1, %2, %3" : "=v"(r), "=s"(k) : "v"(a), "v"(b)); return r; }
-__device__ __forceinline__ u32 subb(u32 a, u32 b, u64 kin, u64& kout) { u32 r; asm("v_subb_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(r), "=s"(kout) : "v"(a), "v"(b), "s"(kin)); return r; }
-__device__ __forceinline__ u32 subb0(u32 a, u64 kin, u64& kout) { u32 r; asm("v_subbrev_co_u32_e64 %0, %1, 0, %2, %3" : "=v"(r), "=s"(kout) : "v"(a), "s"(kin)); return r; }
-__device__ __forceinline__ u32 sel01(u64 k) { u32 r; asm("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(r) : "s"(k)); return r; }
-__device__ __forceinline__ u32 selm1(u64 k) { u32 r; asm("v_cndmask_b32_e64 %0, 0, -1, %1" : "=v"(r) : "s"(k)); return r; }
-__device__ __forceinline__ u64 mad(u32 a, u32 b, u64 c, u64& k) { u64 r; asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(r), "=s"(k) : "v"(a), "v"(b), "v"(c)); return r; }
-__device__ __forceinline__ u64 mad0(u32 a, u32 b) { u64 r, k; asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(r), "=s"(k) : "v"(a), "v"(b)); return r; }
-__device__ __forceinline__ u64 madm1(u32 a, u64 c, u64& k) { u64 r; asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(r), "=s"(k) : "v"(a), "v"(c)); return r; }   // a * (2^32 - 1) + c
+using namespace gp;   // single-instruction primitives (gl.cuh)
 // x + carry * (2^32 - 1), twice (the first repayment can wrap again only from the top 2^32 values)
 __device__ __forceinline__ u64 repay_carry(u64 s, u64 k) { u64 k2, k3; u64 t = madm1(sel01(k), s, k2); return madm1(sel01(k2), t, k3); }
 __device__ __forceinline__ u64 add(u64 a, u64 b) {
