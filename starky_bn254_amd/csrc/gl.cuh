@@ -65,7 +65,7 @@ GL_HD u64 gl_reduce128(u64 lo, u64 hi) {
   if (r >= GLP) r -= GLP;
   return r;
 }
-#if defined(__HIP_DEVICE_COMPILE__)
+// (declared in both compilation passes: kernels.cuh's device functions name them, and the host pass parses those too)
 // Single-instruction asm primitives with explicit carry operands (SGPR pairs): the building blocks of the weak arithmetic
 // in the NTT (kernels.cuh, namespace nw) and of the sponge's constant additions (poseidon.cuh).  The compiler allocates
 // every register and pads the SGPR write -> read wait states (it sees the operands of each statement).
@@ -85,7 +85,6 @@ __device__ __forceinline__ u64 mad0(u32 a, u32 b) { u64 r, k; asm("v_mad_u64_u32
 __device__ __forceinline__ u64 madm1(u32 a, u64 c, u64& k) { u64 r; asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(r), "=s"(k) : "v"(a), "v"(c)); return r; }   // a * (2^32 - 1) + c
 __device__ __forceinline__ u64 cmp_lt_s(u64 x, u64 c) { u64 k; asm("v_cmp_lt_u64_e64 %0, %1, %2" : "=s"(k) : "v"(x), "s"(c)); return k; }   // lanes with x < c (c uniform)
 }  // namespace gp
-#endif
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(SBN_NO_ASM_MUL)
 // gfx950 canonical multiply from the primitives above: the 128-bit product as four chained v_mad_u64_u32 (+ one 33-bit
 // column add), reduction lo - hi_hi + hi_lo (2^32 - 1) with borrow / carry repaid through SGPR-pair carries, then one

@@ -236,13 +236,15 @@ __global__ __launch_bounds__(256) void ntt_fast_pass_kernel(NttPassParams p, u32
     }
   // ---- leading radix-2 DIF stage for R = 512: (u, v) = (a + b, (a - b) w_512^r); block 0 -> even, block 1 -> odd outputs
   if (LOG_B == 1) {
+    // the zero-padded LDE (n_in = half the rows): the upper block is all zeros, so (u, v) = (a, a w) without the add / sub
+    const bool upper_zero = p.in_st == 1 && (size_t)256 * p.in_sr >= p.n_in;
 #pragma unroll
     for (u32 q = 0; q < 16; q++) {
       u32 r = g + 16 * q;
       u64 a = x[0][q], bb = x[NB - 1][q];
       u64 w = tw_lookup(p.tw, p.tw_log, r, 9).v;
-      x[0][q] = nw::add(a, bb);
-      x[NB - 1][q] = nw::mul(nw::sub(a, bb), w);
+      if (upper_zero) { x[NB - 1][q] = nw::mul(a, w); }
+      else { x[0][q] = nw::add(a, bb); x[NB - 1][q] = nw::mul(nw::sub(a, bb), w); }
     }
   }
   // ---- round 1: DFT-16 over q, twiddle by w_256^(g k1), exchange through LDS

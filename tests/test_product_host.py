@@ -332,3 +332,26 @@ def test_regrouped_constraints_equal_the_oracle_on_random_rows(S, O, table, num_
     # a zero challenge (probability 2^-64 in a proof): the fold keeps only the last constraint
     got = S.eval_constraints_host(stark, lv, nv, pi, [0, alphas[1]], z_last, l_first, l_last)
     assert got == O.eval_constraints(kind, num_io, lv, nv, pi, [0, alphas[1]], z_last, l_first, l_last)
+
+
+def test_split_exchange_sizes_and_argument_errors(S):
+    """sbn_split_exchange_bytes (the staging memory a rank of the oversized-trace split needs): the send side holds the rank's
+    own LDE columns once per plane (two planes from four ranks up: the rows i + 2 travel as a second plane), the receive
+    side the row-sharded trace and Z matrices plus the gather scratch; a world that is not a power of two <= 16 is refused
+    when the prover is created (here: no device, so creation fails earlier with NO_DEVICE)."""
+    from starky_bn254_amd import split
+    stark = S.G1ExpStark(128)
+    cfg = stark.config()
+    C, Z, n, m = 1676, 762, 1 << 16, 1 << 17
+    for world, planes in ((1, 1), (2, 1), (4, 2), (8, 2)):
+        sb, rb = split.exchange_bytes(stark, cfg, 16, world)
+        cmax = -(-C // world)
+        assert sb == max(cmax * m * planes, 2 * n) * 8
+        assert rb == ((C + Z) * (m // world) * planes + max(2 * m, 2 * n * world)) * 8
+    import ctypes as C_
+    L = S.lib()
+    comm = split._Comm(None, 0, 3, None, None, 0, 0, split._A2A(lambda *a: 0), split._AGH(lambda *a: 0))
+    h = C_.c_void_p()
+    L.sbn_split_prover_create.argtypes = [C_.POINTER(S.api._AirDesc), C_.POINTER(S.api._Config), C_.c_uint32, C_.POINTER(split._Comm), C_.POINTER(C_.c_void_p)]
+    rc = L.sbn_split_prover_create(C_.byref(stark._d), C_.byref(cfg._c), 16, C_.byref(comm), C_.byref(h))
+    assert rc in (-1, -3) and not h.value          # BAD_ARG on a GPU box, NO_DEVICE here

@@ -49,6 +49,7 @@ def run_split(table, num_io, seed, world, outdir, staged=True, timeout=600):
 
 
 @pytest.mark.parametrize("table,num_io,seed,key,world", [
+    ("fq12", 16, 3, "fq12exp_io16_seed3", 1),      # the sharded code path with trivial collectives
     ("fq12", 16, 3, "fq12exp_io16_seed3", 2),      # the reference's test_fq12_exp_raw size, two ranks: next rows are local
     ("g1", 128, 1, "g1exp_io128_seed1", 2),        # BASELINE config[1] as one split proof
     ("g1", 128, 1, "g1exp_io128_seed1", 4),        # four ranks: the rows i + 2 arrive as a second plane
