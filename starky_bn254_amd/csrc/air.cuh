@@ -140,7 +140,7 @@ static constexpr int SGN_Z = GB + 317, SGN_X = GB + 318, SGN_Y = GB + 319;
 static constexpr int END = GB + 320;  // 384
 }  // namespace g1c
 
-// ---- One challenge at a time: the modular gadgets in FACTORED form ----------------------------------------------------
+// ---- The modular gadgets in FACTORED form ----------------------------------------------------
 // A modular gadget (modular.rs:102-153, modular_zero.rs:82-120) ends with 32 coefficient constraints
 //     coef_k = sign * (quot * modulus)_k + ((x - beta) * aux)_k + [k < 16] lin_k - conv_k,        k = 0..31,
 // where conv = a limb convolution such as lambda * (x2 - x1) (pol_mul_wide, 16 x 16 limbs, 31 coefficients).  The
@@ -150,7 +150,7 @@ static constexpr int END = GB + 320;  // 384
 // and the (x - beta) * aux part is (1 - 2^16 alpha) * rev31(aux).  So the 32 constraints cost a few dot products with
 // powers of alpha instead of 16 x 16 limb products per convolution -- the SAME field element (exact arithmetic, only
 // distributivity is used; no inverse of alpha, so alpha = 0 is fine too), 7 convolutions x 256 multiplies -> ~100 for the
-// G1 gadget, 2 x 144 x 256 -> ~600 for Fq12, and every limb column is read once per challenge instead of once per
+// G1 gadget, 2 x 144 x 256 -> ~600 for Fq12, and every limb column is read once instead of once per
 // coefficient it contributes to (the quotient kernel's first segment moved 3.0 GB for 0.45 GB of columns before).
 // tests/test_product_host.py::test_regrouped_constraints_equal_the_oracle_on_random_rows compares with the oracle's
 // constraint-by-constraint fold on random rows.
@@ -174,68 +174,112 @@ GL_HD P rev_modulus(const Cons<P>& cs, int j) {   // sum_i m_i alpha_j^(15-i), m
   for (int i = 1; i < 16; i++) h = h * cs.alpha[j] + lift<P>(bn254_modulus_limb(i));
   return h;
 }
-// Local sum (challenge j) of the 34 leading constraints of eval_modular_op: eval_packed_generic_addcy
+// Both challenges from ONE pass over the limbs: the evaluators wait for their column loads, so every limb is loaded once
+// and feeds two accumulators (the head kernel of G1ExpStark(128): 1.30 -> 0.69 ms against one pass per challenge).
+template <class P, class Row>
+GL_HD void rev_limbs2(const Cons<P>& cs, const Row& row, int col, int n, P* out) {
+  Acc<P> h[SBN_NCH];
+  const P last = row.l(col + n - 1);
+#pragma unroll
+  for (int j = 0; j < SBN_NCH; j++) { h[j].clear(); h[j].add(last); }
+#pragma unroll 8
+  for (int i = 0; i < n - 1; i++) {
+    const P x = row.l(col + i);
+#pragma unroll
+    for (int j = 0; j < SBN_NCH; j++) h[j].mac(x, cs.apow[j][n - 1 - i]);
+  }
+#pragma unroll
+  for (int j = 0; j < SBN_NCH; j++) out[j] = h[j].value();
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_sched_barrier(0);   // keep the folds of different limb vectors apart: interleaved, their loads in flight spill registers
+#endif
+}
+// Weighted sums over the 32 coefficient constraints of  sign * (quot * modulus)_k + ((x - beta) * aux)_k :
+// quot_abs at qa_col (17 limbs), aux_lo / aux_hi (31 limbs each; aux = lo - 2^29 + 2^16 hi, modular.rs:118-121);
+// rev31(aux) = rev31(lo) + 2^16 rev31(hi) - 2^29 (1 + alpha + ... + alpha^30).
+template <class P, class Row>
+GL_HD void modop_tail2(const Cons<P>& cs, const Row& row, int qa_col, int lo_col, int hi_col, P sign, const P* mrev, P* out) {
+  const P base = lift<P>(65536), off = lift<P>(1ULL << 29), one = lift<P>(1);
+  P q[SBN_NCH];
+  rev_limbs2(cs, row, qa_col, 17, q);
+  Acc<P> ulo[SBN_NCH], uhi[SBN_NCH];
+  P geo[SBN_NCH];
+  const P l30 = row.l(lo_col + 30), h30 = row.l(hi_col + 30);
+#pragma unroll
+  for (int j = 0; j < SBN_NCH; j++) { ulo[j].clear(); uhi[j].clear(); ulo[j].add(l30); uhi[j].add(h30); geo[j] = one; }
+#pragma unroll 5
+  for (int k = 0; k < 30; k++) {
+    const P xl = row.l(lo_col + k), xh = row.l(hi_col + k);
+#pragma unroll
+    for (int j = 0; j < SBN_NCH; j++) { const P w = cs.apow[j][30 - k]; ulo[j].mac(xl, w); uhi[j].mac(xh, w); geo[j] = geo[j] + w; }
+  }
+#pragma unroll
+  for (int j = 0; j < SBN_NCH; j++) {
+    const P u = ulo[j].value() + base * uhi[j].value() - off * geo[j];
+    out[j] = sign * q[j] * mrev[j] + (one - base * cs.alpha[j]) * u;
+  }
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_sched_barrier(0);   // keep the folds of different limb vectors apart: interleaved, their loads in flight spill registers
+#endif
+}
+// Local sums of the 34 leading constraints of eval_modular_op: eval_packed_generic_addcy
 // (src/modular/addcy.rs:16-58) for `modulus + out_aux_red = output + 2^256` (16 carry constraints, exponents 33..18;
 // given_cy[0]*(given_cy[0]-1) = 0 with given_cy[0] = 1; cy == given_cy[0], exponent 16; given_cy[1..16] = 0), then
 // quot_sign^2 = 1 (modular.rs:123), exponent 0.
 template <class P, class Row>
-GL_HD P modop_prefix(const Cons<P>& cs, const Row& row, int j, int oar_col, int out_col, P sign) {
+GL_HD void modop_prefix2(const Cons<P>& cs, const Row& row, int oar_col, int out_col, P sign, P* out) {
   const P overflow = lift<P>(65536), overflow_inv = lift<P>(18446462594437939201ULL), one = lift<P>(1);
-  const P* ap = cs.apow[j];
-  Acc<P> h; h.clear();
+  Acc<P> h[SBN_NCH];
+#pragma unroll
+  for (int j = 0; j < SBN_NCH; j++) h[j].clear();
   P cy = lift<P>(0);
   for (int i = 0; i < 16; i++) {
-    P t = cy + lift<P>(bn254_modulus_limb(i)) + row.l(oar_col + i) - row.l(out_col + i);
-    h.mac(t * (overflow - t), ap[33 - i]);
+    const P t = cy + lift<P>(bn254_modulus_limb(i)) + row.l(oar_col + i) - row.l(out_col + i);
+    const P c = t * (overflow - t);
+#pragma unroll
+    for (int j = 0; j < SBN_NCH; j++) h[j].mac(c, cs.apow[j][33 - i]);
     cy = t * overflow_inv;
   }
-  h.mac(cy - one, ap[16]);
-  h.add(sign * sign - one);
-  return h.value();
-}
-// Weighted sum over the 32 coefficient constraints of  sign * (quot * modulus)_k + ((x - beta) * aux)_k :
-// quot_abs at qa_col (17 limbs), aux_lo / aux_hi (31 limbs each; aux = lo - 2^29 + 2^16 hi, modular.rs:118-121).
-template <class P, class Row>
-GL_HD P modop_tail(const Cons<P>& cs, const Row& row, int j, int qa_col, int lo_col, int hi_col, P sign, P mrev) {
-  const P base = lift<P>(65536), off = lift<P>(1ULL << 29), one = lift<P>(1);
-  const P al = cs.alpha[j];
-  P q = rev_limbs(cs, row, j, qa_col, 17);
-  // rev31(aux) = rev31(lo) + 2^16 rev31(hi) - 2^29 (1 + alpha + ... + alpha^30)
-  const P* ap = cs.apow[j];
-  Acc<P> ulo, uhi; ulo.clear(); uhi.clear();
-  ulo.add(row.l(lo_col + 30)); uhi.add(row.l(hi_col + 30));
-  P geo = one;
-#pragma unroll 2
-  for (int k = 0; k < 30; k++) { ulo.mac(row.l(lo_col + k), ap[30 - k]); uhi.mac(row.l(hi_col + k), ap[30 - k]); geo = geo + ap[30 - k]; }
-  const P u = ulo.value() + base * uhi.value() - off * geo;
-  return sign * q * mrev + (one - base * al) * u;
+#pragma unroll
+  for (int j = 0; j < SBN_NCH; j++) { h[j].mac(cy - one, cs.apow[j][16]); h[j].add(sign * sign - one); out[j] = h[j].value(); }
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_sched_barrier(0);   // keep the folds of different limb vectors apart: interleaved, their loads in flight spill registers
+#endif
 }
 
 // Both eval_g1_add (muladd.rs:179-230) and eval_g1_double (:291-342) on the same row.
-// h_add / h_dbl receive the 165-constraint local Horner sums (filters NOT applied).
+// h_add / h_dbl receive the 165-constraint local sums (filters NOT applied).
 template <class P, class Row>
 GL_HD void g1_gadget(const Cons<P>& cs, const Row& row, P* h_add, P* h_dbl) {
   using namespace g1c;
   const P one = lift<P>(1), two = lift<P>(2), three = lift<P>(3);
   const P sz = row.l(SGN_Z), sx = row.l(SGN_X), sy = row.l(SGN_Y);
-#pragma unroll   // (j must be a compile-time index: a run-time one puts the consumer in scratch memory and its tables behind flat loads)
+  // The gadget emits zero (33 constraints), x (66), y (66): local sums weighted alpha^(132, 66, 0).  Everything that enters
+  // them LINEARLY (modular-reduction sides, outputs, operands outside products) goes straight into `lin` (+ the add-only and
+  // double-only parts), so that only five evaluations stay live for the three products.
+  // zero_pol = lambda*dx - dy (add) / 2*lambda*y - 3*x^2 (double); x: lambda^2 - (x1 + x2); y: lambda*(x1 - new_x) - y1
+  P mrev[SBN_NCH], lin[SBN_NCH], t[SBN_NCH], u[SBN_NCH], L[SBN_NCH], ax[SBN_NCH], ay[SBN_NCH], bx[SBN_NCH], nx[SBN_NCH];
+#pragma unroll
+  for (int j = 0; j < SBN_NCH; j++) mrev[j] = rev_modulus(cs, j);
+  modop_tail2(cs, row, Z_QA, Z_LO, Z_HI, sz, mrev, t);
+#pragma unroll
+  for (int j = 0; j < SBN_NCH; j++) lin[j] = ((sz * sz - one) * cs.apow[j][32] + t[j]) * cs.apow[j][132];   // quot_sign_zero^2 - 1 (modular_zero.rs:91) first
+  modop_tail2(cs, row, X_QA, X_LO, X_HI, sx, mrev, t);
+  modop_prefix2(cs, row, X_OAR, NX, sx, u);
+#pragma unroll
+  for (int j = 0; j < SBN_NCH; j++) lin[j] = lin[j] + (u[j] * cs.apow[j][32] + t[j]) * cs.apow[j][66];
+  modop_tail2(cs, row, Y_QA, Y_LO, Y_HI, sy, mrev, t);
+  modop_prefix2(cs, row, Y_OAR, NY, sy, u);
+#pragma unroll
+  for (int j = 0; j < SBN_NCH; j++) lin[j] = lin[j] + u[j] * cs.apow[j][32] + t[j];
+  rev_limbs2(cs, row, LAM, 16, L); rev_limbs2(cs, row, AX, 16, ax); rev_limbs2(cs, row, AY, 16, ay); rev_limbs2(cs, row, BX, 16, bx);
+  rev_limbs2(cs, row, NX, 16, nx); rev_limbs2(cs, row, BY, 16, t); rev_limbs2(cs, row, NY, 16, u);
+#pragma unroll
   for (int j = 0; j < SBN_NCH; j++) {
-    const P al = cs.alpha[j], a16 = cs.apow[j][16], a32 = cs.apow[j][32], mrev = rev_modulus(cs, j);
-    const P L = rev_limbs(cs, row, j, LAM, 16), ax = rev_limbs(cs, row, j, AX, 16), ay = rev_limbs(cs, row, j, AY, 16);
-    const P bx = rev_limbs(cs, row, j, BX, 16), by = rev_limbs(cs, row, j, BY, 16), nx = rev_limbs(cs, row, j, NX, 16), ny = rev_limbs(cs, row, j, NY, 16);
-    const P tz = modop_tail(cs, row, j, Z_QA, Z_LO, Z_HI, sz, mrev);
-    const P tx = modop_tail(cs, row, j, X_QA, X_LO, X_HI, sx, mrev);
-    const P ty = modop_tail(cs, row, j, Y_QA, Y_LO, Y_HI, sy, mrev);
-    // zero_pol = lambda*dx - dy (add) / 2*lambda*y - 3*x^2 (double); x: lambda^2 - (x1 + x2); y: lambda*(x1 - new_x) - y1
-    const P pz = (sz * sz - one) * a32;       // modular_zero prefix: quot_sign_zero^2 - 1 (modular_zero.rs:91), then 32 coefficients
-    const P za = pz + tz - al * (L * (bx - ax)) + a16 * (by - ay);
-    const P zd = pz + tz - al * (two * (L * ay) - three * (ax * ax));
-    const P px = modop_prefix(cs, row, j, X_OAR, NX, sx) * a32 + tx - al * (L * L);
-    const P xa = px + a16 * (nx + ax + bx), xd = px + a16 * (nx + ax + ax);
-    const P y = modop_prefix(cs, row, j, Y_OAR, NY, sy) * a32 + ty - al * (L * (ax - nx)) + a16 * (ny + ay);
-    const P a132 = cs.apow[j][132], a66 = cs.apow[j][66];
-    h_add[j] = za * a132 + xa * a66 + y;
-    h_dbl[j] = zd * a132 + xd * a66 + y;
+    const P al = cs.alpha[j], a16 = cs.apow[j][16], a66 = cs.apow[j][66], a132 = cs.apow[j][132];
+    const P common = lin[j] + a16 * ((nx[j] + ax[j]) * a66 + u[j] + ay[j]) - al * ((L[j] * L[j]) * a66 + L[j] * (ax[j] - nx[j]));
+    h_add[j] = common + a16 * ((t[j] - ay[j]) * a132 + bx[j] * a66) - al * ((L[j] * (bx[j] - ax[j])) * a132);
+    h_dbl[j] = common + a16 * (ax[j] * a66) - al * ((two * (L[j] * ay[j]) - three * (ax[j] * ax[j])) * a132);
   }
 }
 static constexpr int G1_GADGET_CONSTRAINTS = 165;
@@ -349,46 +393,68 @@ static constexpr int SGN_Z = GB + 634, SGN_X = GB + 636, SGN_Y = GB + 638;
 
 // eval_g2_add (muladd.rs:416-472) and eval_g2_double (:203-261) on one row: 330-constraint local sums.
 // Fq2 limb products (fq2.rs:41-58): (X*Y).c0 = X0*Y0 - X1*Y1, (X*Y).c1 = X0*Y1 + X1*Y0.
+template <class P>
+struct G2Comp {   // the reversed evaluations of one Fq2 component (c0 or c1) that enter products, for both challenges
+  P L[SBN_NCH], ax[SBN_NCH], ay[SBN_NCH], bx[SBN_NCH], nx[SBN_NCH];
+};
+// Everything of component c that enters the 330 constraints LINEARLY (modular-reduction sides, outputs, the operands
+// outside products) goes straight into three running sums per challenge -- common to add and double, add only, double only --
+// so that only five evaluations per component stay live for the Fq2 products.  Weights: the gadget emits zero[c0], zero[c1]
+// (33 each), x[c0], x[c1], y[c0], y[c1] (66 each), so their local sums carry alpha^(297, 264, 198, 132, 66, 0).
+template <class P, class Row>
+GL_HD void g2_component(const Cons<P>& cs, const Row& row, int c, const P* mrev, G2Comp<P>& o, P* lin, P* lin_add, P* lin_dbl) {
+  using namespace g2c;
+  const P one = lift<P>(1);
+  const P sz = row.l(SGN_Z + c), sx = row.l(SGN_X + c), sy = row.l(SGN_Y + c);
+  const int wz = c ? 264 : 297, wx = c ? 132 : 198, wy = c ? 0 : 66;
+  P t[SBN_NCH], u[SBN_NCH];
+  modop_tail2(cs, row, z_qa(c), z_qa(c) + 17, z_qa(c) + 48, sz, mrev, t);
+#pragma unroll
+  for (int j = 0; j < SBN_NCH; j++) lin[j] = lin[j] + ((sz * sz - one) * cs.apow[j][32] + t[j]) * cs.apow[j][wz];   // quot_sign_zero^2 - 1 (modular_zero.rs:91) first
+  modop_tail2(cs, row, x_base(c) + 16, x_base(c) + 33, x_base(c) + 64, sx, mrev, t);
+  modop_prefix2(cs, row, x_base(c), NX + 16 * c, sx, u);
+#pragma unroll
+  for (int j = 0; j < SBN_NCH; j++) lin[j] = lin[j] + (u[j] * cs.apow[j][32] + t[j]) * cs.apow[j][wx];
+  modop_tail2(cs, row, y_base(c) + 16, y_base(c) + 33, y_base(c) + 64, sy, mrev, t);
+  modop_prefix2(cs, row, y_base(c), NY + 16 * c, sy, u);
+#pragma unroll
+  for (int j = 0; j < SBN_NCH; j++) lin[j] = lin[j] + (u[j] * cs.apow[j][32] + t[j]) * cs.apow[j][wy];
+  rev_limbs2(cs, row, LAM + 16 * c, 16, o.L); rev_limbs2(cs, row, AX + 16 * c, 16, o.ax); rev_limbs2(cs, row, AY + 16 * c, 16, o.ay);
+  rev_limbs2(cs, row, BX + 16 * c, 16, o.bx); rev_limbs2(cs, row, NX + 16 * c, 16, o.nx);
+  rev_limbs2(cs, row, BY + 16 * c, 16, t); rev_limbs2(cs, row, NY + 16 * c, 16, u);
+#pragma unroll
+  for (int j = 0; j < SBN_NCH; j++) {
+    const P a16 = cs.apow[j][16];
+    // zero (add): + a16 (y2 - y1);  x: + a16 (new_x + x1 + [x2 | x1]);  y: + a16 (new_y + y1)
+    lin[j] = lin[j] + a16 * ((o.nx[j] + o.ax[j]) * cs.apow[j][wx] + (u[j] + o.ay[j]) * cs.apow[j][wy]);
+    lin_add[j] = lin_add[j] + a16 * ((t[j] - o.ay[j]) * cs.apow[j][wz] + o.bx[j] * cs.apow[j][wx]);
+    lin_dbl[j] = lin_dbl[j] + a16 * (o.ax[j] * cs.apow[j][wx]);
+  }
+}
 template <class P, class Row>
 GL_HD void g2_gadget(const Cons<P>& cs, const Row& row, P* h_add, P* h_dbl) {
-  using namespace g2c;
-  const P one = lift<P>(1), zero = lift<P>(0), two = lift<P>(2), three = lift<P>(3);
-  P sz[2], sx[2], sy[2];
-  for (int c = 0; c < 2; c++) { sz[c] = row.l(SGN_Z + c); sx[c] = row.l(SGN_X + c); sy[c] = row.l(SGN_Y + c); }
+  const P two = lift<P>(2), three = lift<P>(3), zero = lift<P>(0);
+  P mrev[SBN_NCH], lin[SBN_NCH], lin_add[SBN_NCH], lin_dbl[SBN_NCH];
+#pragma unroll
+  for (int j = 0; j < SBN_NCH; j++) { mrev[j] = rev_modulus(cs, j); lin[j] = zero; lin_add[j] = zero; lin_dbl[j] = zero; }
+  G2Comp<P> p0, p1;   // (two named objects, not an array: a component index that is not a constant puts them in scratch memory)
+  g2_component(cs, row, 0, mrev, p0, lin, lin_add, lin_dbl);
+  g2_component(cs, row, 1, mrev, p1, lin, lin_add, lin_dbl);
 #pragma unroll   // (j must be a compile-time index: a run-time one puts the consumer in scratch memory and its tables behind flat loads)
   for (int j = 0; j < SBN_NCH; j++) {
-    const P al = cs.alpha[j], a16 = cs.apow[j][16], a32 = cs.apow[j][32], mrev = rev_modulus(cs, j);
-    P L[2], ax[2], ay[2], bx[2], by[2], nx[2], ny[2];
-    for (int c = 0; c < 2; c++) {
-      L[c] = rev_limbs(cs, row, j, LAM + 16 * c, 16); ax[c] = rev_limbs(cs, row, j, AX + 16 * c, 16); ay[c] = rev_limbs(cs, row, j, AY + 16 * c, 16);
-      bx[c] = rev_limbs(cs, row, j, BX + 16 * c, 16); by[c] = rev_limbs(cs, row, j, BY + 16 * c, 16);
-      nx[c] = rev_limbs(cs, row, j, NX + 16 * c, 16); ny[c] = rev_limbs(cs, row, j, NY + 16 * c, 16);
-    }
     // Fq2 limb products (fq2.rs:41-58) at the level of the reversed evaluations
-    const P d0 = bx[0] - ax[0], d1 = bx[1] - ax[1], e0 = ax[0] - nx[0], e1 = ax[1] - nx[1];
-    const P c1[2] = {L[0] * d0 - L[1] * d1, L[0] * d1 + L[1] * d0};              // lambda * delta_x
-    const P c2[2] = {L[0] * ay[0] - L[1] * ay[1], L[0] * ay[1] + L[1] * ay[0]};  // lambda * y1
-    const P x01 = ax[0] * ax[1];
-    const P c3[2] = {ax[0] * ax[0] - ax[1] * ax[1], x01 + x01};                   // x1^2
-    const P l01 = L[0] * L[1];
-    const P c4[2] = {L[0] * L[0] - L[1] * L[1], l01 + l01};                       // lambda^2
-    const P c5[2] = {L[0] * e0 - L[1] * e1, L[0] * e1 + L[1] * e0};              // lambda * (x1 - new_x)
-    P za[2], zd[2], xa[2], xd[2], y[2];
-    for (int c = 0; c < 2; c++) {
-      const P tz = modop_tail(cs, row, j, z_qa(c), z_qa(c) + 17, z_qa(c) + 48, sz[c], mrev);
-      const P tx = modop_tail(cs, row, j, x_base(c) + 16, x_base(c) + 33, x_base(c) + 64, sx[c], mrev);
-      const P ty = modop_tail(cs, row, j, y_base(c) + 16, y_base(c) + 33, y_base(c) + 64, sy[c], mrev);
-      const P pz = (sz[c] * sz[c] - one) * a32;
-      za[c] = pz + tz - al * c1[c] + a16 * (by[c] - ay[c]);
-      zd[c] = pz + tz - al * (two * c2[c] - three * c3[c]);
-      const P px = modop_prefix(cs, row, j, x_base(c), NX + 16 * c, sx[c]) * a32 + tx - al * c4[c];
-      xa[c] = px + a16 * (nx[c] + ax[c] + bx[c]);
-      xd[c] = px + a16 * (nx[c] + ax[c] + ax[c]);
-      y[c] = modop_prefix(cs, row, j, y_base(c), NY + 16 * c, sy[c]) * a32 + ty - al * c5[c] + a16 * (ny[c] + ay[c]);
-    }
+    const P L0 = p0.L[j], L1 = p1.L[j], x0 = p0.ax[j], x1 = p1.ax[j], y0 = p0.ay[j], y1 = p1.ay[j];
+    const P d0 = p0.bx[j] - x0, d1 = p1.bx[j] - x1, e0 = x0 - p0.nx[j], e1 = x1 - p1.nx[j];
+    const P x01 = x0 * x1, l01 = L0 * L1;
+    const P c1a = L0 * d0 - L1 * d1, c1b = L0 * d1 + L1 * d0;        // lambda * delta_x
+    const P c2a = L0 * y0 - L1 * y1, c2b = L0 * y1 + L1 * y0;        // lambda * y1
+    const P c3a = x0 * x0 - x1 * x1, c3b = x01 + x01;                // x1^2
+    const P c4a = L0 * L0 - L1 * L1, c4b = l01 + l01;                // lambda^2
+    const P c5a = L0 * e0 - L1 * e1, c5b = L0 * e1 + L1 * e0;        // lambda * (x1 - new_x)
     const P* ap = cs.apow[j];
-    h_add[j] = za[0] * ap[297] + za[1] * ap[264] + xa[0] * ap[198] + xa[1] * ap[132] + y[0] * ap[66] + y[1];
-    h_dbl[j] = zd[0] * ap[297] + zd[1] * ap[264] + xd[0] * ap[198] + xd[1] * ap[132] + y[0] * ap[66] + y[1];
+    const P common = lin[j] - cs.alpha[j] * (c4a * ap[198] + c4b * ap[132] + c5a * ap[66] + c5b);
+    h_add[j] = common + lin_add[j] - cs.alpha[j] * (c1a * ap[297] + c1b * ap[264]);
+    h_dbl[j] = common + lin_dbl[j] - cs.alpha[j] * ((two * c2a - three * c3a) * ap[297] + (two * c2b - three * c3b) * ap[264]);
   }
 }
 
@@ -403,42 +469,69 @@ static constexpr int A = 0, B = 192, OUT = 384, AUX = 576, SGN = 576 + 12 * 95;
 // S[m] = sum_{i+j=m} (a_i b_{j+6} + a_{i+6} b_j):  real[m] = D[m] + 9 D[m+6] - S[m+6],
 // imag[m] = S[m] + D[m+6] + 9 S[m+6]  (m < 5; the m = 5 terms have no wrap-around part).
 // Coefficients m and m+6 are processed together so that every limb product is formed exactly once.
+// The 2 x 144 coefficient products of the square and of the product for challenge J.  J and the coefficient index M are
+// template parameters: the body is too large for the compiler to unroll loops over them ("unrolled size is too large"), a
+// run-time j puts the consumer in scratch memory behind flat loads and a run-time m does the same to ar / br.
+template <int J, int M, class P>
+GL_HD void fq12_coeff(const Cons<P>& cs, const P (&ar)[12], const P (&br)[12], P& hs, P& hm) {
+  // pol_mul_fq12 (mul.rs:24-87) on the evaluations: D[t] = sum_{i+j=t} (x_i y_j - x_{i+6} y_{j+6}), S[t] = sum (x_i y_{j+6} + x_{i+6} y_j)
+  const P zero = lift<P>(0), nine = lift<P>(9);
+  P ds = zero, ss = zero, ds6 = zero, ss6 = zero, dm = zero, sm = zero, dm6 = zero, sm6 = zero;
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    const bool wrap = i > M;
+    if (!(wrap && M == 5)) {                   // i + j = 11 has no term with j < 6
+      const int t = wrap ? M + 6 - i : M - i;  // i + t = M  or  i + t = M + 6
+      const P d_s = ar[i] * ar[t] - ar[i + 6] * ar[t + 6], s_s = ar[i] * ar[t + 6] + ar[i + 6] * ar[t];
+      const P d_m = ar[i] * br[t] - ar[i + 6] * br[t + 6], s_m = ar[i] * br[t + 6] + ar[i + 6] * br[t];
+      if (wrap) { ds6 += d_s; ss6 += s_s; dm6 += d_m; sm6 += s_m; }
+      else { ds += d_s; ss += s_s; dm += d_m; sm += s_m; }
+    }
+  }
+  const P w0 = cs.apow[J][66 * (11 - M)], w1 = cs.apow[J][66 * (5 - M)];
+  hs = hs + (ds + nine * ds6 - ss6) * w0 + (ss + ds6 + nine * ss6) * w1;
+  hm = hm + (dm + nine * dm6 - sm6) * w0 + (sm + dm6 + nine * sm6) * w1;
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_sched_barrier(0);   // one coefficient at a time
+#endif
+}
+template <int J, class P, class Row>
+GL_HD void fq12_products(const Cons<P>& cs, const Row& row, P& hs, P& hm) {
+  using namespace f12c;
+  P ar[12], br[12];   // reversed evaluations of the 12 + 12 coefficient limb vectors
+#pragma unroll   // (the compiler does not unroll this one fully -- "unrolled size is too large" -- so ar / br live in scratch memory:
+                 // 24 stores, and the straight-line alternative spills 700 registers)
+  for (int i = 0; i < 12; i++) { ar[i] = rev_limbs(cs, row, J, A + 16 * i, 16); br[i] = rev_limbs(cs, row, J, B + 16 * i, 16); }
+  hs = lift<P>(0); hm = lift<P>(0);
+  fq12_coeff<J, 0>(cs, ar, br, hs, hm); fq12_coeff<J, 1>(cs, ar, br, hs, hm); fq12_coeff<J, 2>(cs, ar, br, hs, hm);
+  fq12_coeff<J, 3>(cs, ar, br, hs, hm); fq12_coeff<J, 4>(cs, ar, br, hs, hm); fq12_coeff<J, 5>(cs, ar, br, hs, hm);
+}
 template <class P, class Row>
 GL_HD void fq12_gadget(const Cons<P>& cs, const Row& row, P* h_sq, P* h_mul) {
   using namespace f12c;
-  const P zero = lift<P>(0), nine = lift<P>(9);
-#pragma unroll   // (j must be a compile-time index: a run-time one puts the consumer in scratch memory and its tables behind flat loads)
-  for (int j = 0; j < SBN_NCH; j++) {
-    const P al = cs.alpha[j], a16 = cs.apow[j][16], a32 = cs.apow[j][32], mrev = rev_modulus(cs, j);
-    P ar[12], br[12];   // reversed evaluations of the 12 + 12 coefficient limb vectors
-    for (int i = 0; i < 12; i++) { ar[i] = rev_limbs(cs, row, j, A + 16 * i, 16); br[i] = rev_limbs(cs, row, j, B + 16 * i, 16); }
-    P hs = zero, hm = zero;
-    for (int m = 0; m < 6; m++) {
-      // pol_mul_fq12 (mul.rs:24-87) on the evaluations: D[t] = sum_{i+j=t} (x_i y_j - x_{i+6} y_{j+6}), S[t] = sum (x_i y_{j+6} + x_{i+6} y_j)
-      P ds = zero, ss = zero, ds6 = zero, ss6 = zero, dm = zero, sm = zero, dm6 = zero, sm6 = zero;
-      for (int i = 0; i < 6; i++) {
-        const bool wrap = i > m;
-        if (wrap && m == 5) continue;            // i + j = 11 has no term with j < 6
-        const int t = wrap ? m + 6 - i : m - i;  // i + t = m  or  i + t = m + 6
-        const P d_s = ar[i] * ar[t] - ar[i + 6] * ar[t + 6], s_s = ar[i] * ar[t + 6] + ar[i + 6] * ar[t];
-        const P d_m = ar[i] * br[t] - ar[i + 6] * br[t + 6], s_m = ar[i] * br[t + 6] + ar[i + 6] * br[t];
-        if (wrap) { ds6 += d_s; ss6 += s_s; dm6 += d_m; sm6 += s_m; }
-        else { ds += d_s; ss += s_s; dm += d_m; sm += s_m; }
-      }
-      const P in_s[2] = {ds + nine * ds6 - ss6, ss + ds6 + nine * ss6};
-      const P in_m[2] = {dm + nine * dm6 - sm6, sm + dm6 + nine * sm6};
-      for (int q = 0; q < 2; q++) {
-        const int c = m + 6 * q, ab = AUX + 95 * c;
-        const P sgn = row.l(SGN + c);
-        const P pre = modop_prefix(cs, row, j, ab, OUT + 16 * c, sgn) * a32 + modop_tail(cs, row, j, ab + 16, ab + 33, ab + 64, sgn, mrev) +
-                      a16 * rev_limbs(cs, row, j, OUT + 16 * c, 16);
-        const P w = cs.apow[j][66 * (q ? 5 - m : 11 - m)];
-        hs = hs + (pre - al * in_s[q]) * w;
-        hm = hm + (pre - al * in_m[q]) * w;
-      }
-    }
-    h_sq[j] = hs; h_mul[j] = hm;
+  static_assert(SBN_NCH == 2, "fq12_products is instantiated for two challenges");
+  const P zero = lift<P>(0);
+  // The modular-reduction side (out_aux_red, output, quot, aux: 111 of the 143 limbs per coefficient) is the same for the
+  // square and the product and enters both sums with the weight alpha^(66 (11 - c)); every one of its limbs is loaded once
+  // and feeds both challenges.
+  P mrev[SBN_NCH], hpre[SBN_NCH];
+#pragma unroll
+  for (int j = 0; j < SBN_NCH; j++) { mrev[j] = rev_modulus(cs, j); hpre[j] = zero; }
+  for (int c = 0; c < 12; c++) {
+    const int ab = AUX + 95 * c;
+    const P sgn = row.l(SGN + c);
+    P pp[SBN_NCH], tt[SBN_NCH], oo[SBN_NCH];
+    modop_prefix2(cs, row, ab, OUT + 16 * c, sgn, pp);
+    modop_tail2(cs, row, ab + 16, ab + 33, ab + 64, sgn, mrev, tt);
+    rev_limbs2(cs, row, OUT + 16 * c, 16, oo);
+#pragma unroll
+    for (int j = 0; j < SBN_NCH; j++) hpre[j] = hpre[j] + (pp[j] * cs.apow[j][32] + tt[j] + cs.apow[j][16] * oo[j]) * cs.apow[j][66 * (11 - c)];
   }
+  P hs0, hm0, hs1, hm1;
+  fq12_products<0>(cs, row, hs0, hm0);
+  fq12_products<1>(cs, row, hs1, hm1);
+  h_sq[0] = hpre[0] - cs.alpha[0] * hs0; h_mul[0] = hpre[0] - cs.alpha[0] * hm0;
+  h_sq[1] = hpre[1] - cs.alpha[1] * hs1; h_mul[1] = hpre[1] - cs.alpha[1] * hm1;
 }
 
 // ---- Fq multiplication gadget (src/fields/fq/mul.rs) -------------------------------------------------------------
@@ -449,14 +542,17 @@ template <class P, class Row>
 GL_HD void fq_gadget(const Cons<P>& cs, const Row& row, P* h_sq, P* h_mul) {
   constexpr int A = 0, B = 16, OUT = 32, AUX = 48, SGN = 143;
   const P sgn = row.l(SGN);
+  P mrev[SBN_NCH], a[SBN_NCH], b[SBN_NCH], pp[SBN_NCH], tt[SBN_NCH], oo[SBN_NCH];
+#pragma unroll
+  for (int j = 0; j < SBN_NCH; j++) mrev[j] = rev_modulus(cs, j);
+  rev_limbs2(cs, row, A, 16, a); rev_limbs2(cs, row, B, 16, b); rev_limbs2(cs, row, OUT, 16, oo);
+  modop_prefix2(cs, row, AUX, OUT, sgn, pp);
+  modop_tail2(cs, row, AUX + 16, AUX + 33, AUX + 64, sgn, mrev, tt);
 #pragma unroll   // (j must be a compile-time index: a run-time one puts the consumer in scratch memory and its tables behind flat loads)
   for (int j = 0; j < SBN_NCH; j++) {
-    const P al = cs.alpha[j];
-    const P a = rev_limbs(cs, row, j, A, 16), b = rev_limbs(cs, row, j, B, 16);
-    const P pre = modop_prefix(cs, row, j, AUX, OUT, sgn) * cs.apow[j][32] + modop_tail(cs, row, j, AUX + 16, AUX + 33, AUX + 64, sgn, rev_modulus(cs, j)) +
-                  cs.apow[j][16] * rev_limbs(cs, row, j, OUT, 16);
-    h_sq[j] = pre - al * (a * a);
-    h_mul[j] = pre - al * (a * b);
+    const P pre = pp[j] * cs.apow[j][32] + tt[j] + cs.apow[j][16] * oo[j];
+    h_sq[j] = pre - cs.alpha[j] * (a[j] * a[j]);
+    h_mul[j] = pre - cs.alpha[j] * (a[j] * b[j]);
   }
 }
 
