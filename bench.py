@@ -26,6 +26,15 @@ NUM_IO = 128
 DEGREE_BITS = 16
 
 
+_RESULT_OUT = None
+
+
+def emit(line):
+    out = _RESULT_OUT if _RESULT_OUT is not None else sys.stdout
+    out.write(json.dumps(line) + "\n")
+    out.flush()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -57,6 +66,13 @@ def main():
     # node share its cores
     os.environ.setdefault("SBN_HOST_THREADS", str(max(1, min(64, (os.cpu_count() or 8) // max(world, 1)))))
 
+    # The contract is ONE JSON line on stdout.  RCCL prints a version banner on file descriptor 1 when its first communicator
+    # comes up, so the descriptor is kept aside for the result and everything else that writes to "stdout" goes to stderr.
+    global _RESULT_OUT
+    if _RESULT_OUT is None:
+        sys.stdout.flush()
+        _RESULT_OUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
     import numpy as np
     import torch
     import starky_bn254_amd as S
@@ -233,7 +249,7 @@ def main():
             line["end_to_end"] = e2e
         if world == 1 and not args.skip_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(trace, pi, args.table)
-        print(json.dumps(line), flush=True)
+        emit(line)
     prover.close()
     if dist is not None:
         dist.barrier()                  # rank 0 did the extra end-to-end leg: leave together
@@ -309,7 +325,7 @@ def bench_batch(args, S, np, torch, dist, rank, world, barrier, max_over_ranks):
                            "host_threads_per_rank": int(os.environ["SBN_HOST_THREADS"])},
                 "batch_check": {"digests_gathered": len(merged), "all_units_present_and_distinct": bool(ok)},
                 "host": {"synthetic_inputs_s": t_inputs}}
-        print(json.dumps(line), flush=True)
+        emit(line)
     bp.close()
     if dist is not None:
         dist.barrier()
@@ -362,7 +378,7 @@ def bench_split(args, S, np, torch, dist, rank, world, barrier, max_over_ranks):
                 "stage_ms_rank0": {k: v / steps for k, v in acc.items()},
                 "exchange": {"bytes_sent_per_proof_rank0": sp.comm.bytes_sent // steps, "exchange_ms_rank0": acc.get("split_exchange_ms", 0.0) / steps},
                 "all_ranks_same_proof": len(set(digests.values())) == 1}
-        print(json.dumps(line), flush=True)
+        emit(line)
     sp.close()
     if dist is not None:
         dist.barrier()

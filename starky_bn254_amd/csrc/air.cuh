@@ -43,6 +43,7 @@ struct Acc {
   P v;
   GL_HD void clear() { v = lift<P>(0); }
   GL_HD void mac(P x, P w) { v = v + x * w; }
+  GL_HD void macv(P x, P w) { v = v + x * w; }
   GL_HD void add(P x) { v = v + x; }
   GL_HD P value() const { return v; }
 };
@@ -66,6 +67,20 @@ struct Acc<F> {
         "v_addc_co_u32_e64 %4, vcc, 0, %4, %8\n\t"
         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(c0), "+v"(c1), "+v"(c2), "=&s"(k0), "=&s"(k1), "=&s"(k2), "=&s"(k3)
         : "v"((u32)x.v), "v"((u32)(x.v >> 32)), "s"(wl), "s"(wh)
+        : "vcc");
+  }
+  __device__ __forceinline__ void macv(F x, F w) {   // the same with a weight that differs from lane to lane (vector operands, no wait states)
+    u64 k0, k1, k2, k3;
+    asm("v_mad_u64_u32 %0, %6, %10, %12, %0\n\t"
+        "v_mad_u64_u32 %1, %7, %10, %13, %1\n\t"
+        "v_mad_u64_u32 %2, %9, %11, %13, %2\n\t"
+        "v_mad_u64_u32 %1, %8, %11, %12, %1\n\t"
+        "v_addc_co_u32_e64 %3, vcc, 0, %3, %6\n\t"
+        "v_addc_co_u32_e64 %4, vcc, 0, %4, %7\n\t"
+        "v_addc_co_u32_e64 %5, vcc, 0, %5, %9\n\t"
+        "v_addc_co_u32_e64 %4, vcc, 0, %4, %8\n\t"
+        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(c0), "+v"(c1), "+v"(c2), "=&s"(k0), "=&s"(k1), "=&s"(k2), "=&s"(k3)
+        : "v"((u32)x.v), "v"((u32)(x.v >> 32)), "v"((u32)w.v), "v"((u32)(w.v >> 32))
         : "vcc");
   }
   __device__ __forceinline__ void add(F x) { const u64 t = a0 + x.v; c0 += t < a0 ? 1u : 0u; a0 = t; }

@@ -1104,13 +1104,17 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
     auto open_k = u4 ? openings_kernel<4> : openings_kernel<1>;
     auto open1_k = u4 ? openings1_kernel<4> : openings1_kernel<1>;
     const u64 *zp0 = P->d_zpow, *zp1 = P->d_zpow + n, *zp2 = P->d_zpow + 2 * n, *zp3 = P->d_zpow + 3 * n;
-    const size_t Ch = C / 2;   // two slices of the trace columns: the host starts after a quarter of an opening pass
-    hipLaunchKernelGGL(open1_k, dim3((unsigned)Ch), dim3(256), 0, st, P->d_coef, n, zp0, zp1, P->d_open, 0u);
-    HIPC(hipMemcpyAsync(P->h_open, P->d_open, Ch * 4 * sizeof(u64), hipMemcpyDeviceToHost, st));
-    HIPC(hipEventRecord(P->chunk_ready[2], st));  // (the commit pipeline's chunk events are idle here)
-    hipLaunchKernelGGL(open1_k, dim3((unsigned)(C - Ch)), dim3(256), 0, st, P->d_coef + Ch * n, n, zp0, zp1, P->d_open + Ch * 4, 0u);
-    HIPC(hipMemcpyAsync(P->h_open + Ch * 4, P->d_open + Ch * 4, (C - Ch) * 4 * sizeof(u64), hipMemcpyDeviceToHost, st));
-    HIPC(hipEventRecord(P->chunk_ready[0], st));
+    // The host hashes ~3 columns per microsecond, the device evaluates ~5: the trace columns at zeta go out in slices that
+    // double in size (C/16, C/8, C/4, rest), so the host starts after a sixteenth of an opening pass and is never starved.
+    size_t sl[5] = {0, C / 16, C / 16 + C / 8, C / 16 + C / 8 + C / 4, C};
+    for (int k = 0; k < 4; k++) {
+      const size_t a = sl[k], cnt = sl[k + 1] - sl[k];
+      if (cnt) {
+        hipLaunchKernelGGL(open1_k, dim3((unsigned)cnt), dim3(256), 0, st, P->d_coef + a * n, n, zp0, zp1, P->d_open + a * 4, 0u);
+        HIPC(hipMemcpyAsync(P->h_open + a * 4, P->d_open + a * 4, cnt * 4 * sizeof(u64), hipMemcpyDeviceToHost, st));
+      }
+      HIPC(hipEventRecord(P->chunk_ready[8 + k], st));  // (the commit pipeline's chunk events are idle here)
+    }
     hipLaunchKernelGGL(open_k, dim3((unsigned)Z), dim3(256), 0, st, P->d_zcoef, n, zp0, zp1, zp2, zp3, P->d_open + C * 4);
     hipLaunchKernelGGL(open_k, dim3(4), dim3(256), 0, st, P->d_q, n, zp0, zp1, zp2, zp3, P->d_open + (C + Z) * 4);
     HIPC(hipMemcpyAsync(P->h_open + C * 4, P->d_open + C * 4, (Z + 4) * 4 * sizeof(u64), hipMemcpyDeviceToHost, st));
@@ -1120,10 +1124,10 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
     HIPC(hipMemcpyAsync(P->h_open2, P->d_open, C * 4 * sizeof(u64), hipMemcpyDeviceToHost, st));   // a second buffer: the host is reading the first
     HIPC(hipEventRecord(P->ev[ST_FRI_COMBINE], st));
     // observe_openings: batch zeta = local ++ perm_zs ++ quotient ; batch g*zeta = next ++ perm_zs_next
-    HIPC(event_wait(P->chunk_ready[2]));
-    for (size_t p = 0; p < Ch; p++) { ch.observe(F(open[4 * p])); ch.observe(F(open[4 * p + 1])); }
-    HIPC(event_wait(P->chunk_ready[0]));
-    for (size_t p = Ch; p < C; p++) { ch.observe(F(open[4 * p])); ch.observe(F(open[4 * p + 1])); }
+    for (int k = 0; k < 4; k++) {
+      HIPC(event_wait(P->chunk_ready[8 + k]));
+      for (size_t p = sl[k]; p < sl[k + 1]; p++) { ch.observe(F(open[4 * p])); ch.observe(F(open[4 * p + 1])); }
+    }
     HIPC(event_wait(P->chunk_ready[1]));
     for (size_t p = C; p < C + Z + 4; p++) { ch.observe(F(open[4 * p])); ch.observe(F(open[4 * p + 1])); }
     HIPC(stream_wait(st));
