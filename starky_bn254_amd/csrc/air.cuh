@@ -197,7 +197,7 @@ GL_HD void rev_limbs2(const Cons<P>& cs, const Row& row, int col, int n, P* out)
   const P last = row.l(col + n - 1);
 #pragma unroll
   for (int j = 0; j < SBN_NCH; j++) { h[j].clear(); h[j].add(last); }
-#pragma unroll 8
+#pragma unroll 16
   for (int i = 0; i < n - 1; i++) {
     const P x = row.l(col + i);
 #pragma unroll
@@ -222,7 +222,7 @@ GL_HD void modop_tail2(const Cons<P>& cs, const Row& row, int qa_col, int lo_col
   const P l30 = row.l(lo_col + 30), h30 = row.l(hi_col + 30);
 #pragma unroll
   for (int j = 0; j < SBN_NCH; j++) { ulo[j].clear(); uhi[j].clear(); ulo[j].add(l30); uhi[j].add(h30); geo[j] = one; }
-#pragma unroll 5
+#pragma unroll 10
   for (int k = 0; k < 30; k++) {
     const P xl = row.l(lo_col + k), xh = row.l(hi_col + k);
 #pragma unroll
@@ -248,6 +248,7 @@ GL_HD void modop_prefix2(const Cons<P>& cs, const Row& row, int oar_col, int out
 #pragma unroll
   for (int j = 0; j < SBN_NCH; j++) h[j].clear();
   P cy = lift<P>(0);
+#pragma unroll 8
   for (int i = 0; i < 16; i++) {
     const P t = cy + lift<P>(bn254_modulus_limb(i)) + row.l(oar_col + i) - row.l(out_col + i);
     const P c = t * (overflow - t);
