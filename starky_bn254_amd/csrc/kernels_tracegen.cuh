@@ -7,8 +7,9 @@
 //   * both chains of an instance are walked in Jacobian coordinates (no inversion): bn254w.cuh g1_chains, run on host
 //     threads by default (512 strictly sequential point operations per instance are 0.1% of the arithmetic and
 //     latency-bound on a lane) or by chain_kernel, one lane per instance;
-//   * affine_kernel / lambda_kernel then invert all Z's and all slope denominators at once, one lane per value
-//     (Fermat, a^(p-2)): the inversions of different rows are independent once the chain is known;
+//   * affine_kernel / lambda_kernel then invert all Z's and all slope denominators at once (the inversions of different
+//     rows are independent once the chain is known): a lane owns eight values and inverts their product (Montgomery's
+//     trick; Fermat, a^(p-2), for the one inversion left);
 //   * row_witness_kernel computes limb columns and the three modular-gadget witnesses of a row (one lane per row);
 //   * flags / pulse columns are closed forms of the row index;
 //   * range_check_kernel: one workgroup per range-checked column, histogram and prefix counts in LDS, and the
@@ -38,12 +39,31 @@ __device__ __noinline__ Fq finv_fermat(const Fq& a) {
 }
 
 
-// inverse of a coordinate: Fq directly, Fq2 through the norm a^2 + b^2 (one Fq inversion)
-__device__ __forceinline__ Co<1> cinv(const Co<1>& a) { Co<1> r; r.c[0] = finv_fermat(a.c[0]); return r; }
-__device__ __forceinline__ Co<2> cinv(const Co<2>& a) {
-  const Fq ni = finv_fermat(fadd(mmul(a.c[0], a.c[0]), mmul(a.c[1], a.c[1])));
+// Inversions are BATCHED inside a lane (Montgomery's trick): a lane multiplies up the TG_INV_BATCH values it owns, inverts the
+// product with one Fermat chain (~330 multiplies) and walks back with two multiplies per value, so an inversion costs ~45
+// multiplies instead of ~330.  A coordinate in Fq2 is inverted through its norm a^2 + b^2 (an Fq value): 1/(a + bi) = (a - bi) / norm.
+static constexpr int TG_INV_BATCH = 8;
+__device__ __forceinline__ Fq cnorm(const Co<1>& a) { return a.c[0]; }
+__device__ __forceinline__ Fq cnorm(const Co<2>& a) { return fadd(mmul(a.c[0], a.c[0]), mmul(a.c[1], a.c[1])); }
+__device__ __forceinline__ Co<1> cinv_from_norm(const Co<1>&, const Fq& ni) { Co<1> r; r.c[0] = ni; return r; }
+__device__ __forceinline__ Co<2> cinv_from_norm(const Co<2>& a, const Fq& ni) {
   Co<2> r; r.c[0] = mmul(a.c[0], ni); r.c[1] = fsub(Fq{{0, 0, 0, 0}}, mmul(a.c[1], ni));
   return r;
+}
+// nrm[j] (all non-zero) -> nrm[j]^-1, j < TG_INV_BATCH
+__device__ __forceinline__ void batch_inverse(Fq (&nrm)[TG_INV_BATCH]) {
+  Fq pre[TG_INV_BATCH];
+  pre[0] = nrm[0];
+#pragma unroll
+  for (int j = 1; j < TG_INV_BATCH; j++) pre[j] = mmul(pre[j - 1], nrm[j]);
+  Fq inv = finv_fermat(pre[TG_INV_BATCH - 1]);
+#pragma unroll
+  for (int j = TG_INV_BATCH - 1; j > 0; j--) {
+    const Fq ni = mmul(inv, pre[j - 1]);
+    inv = mmul(inv, nrm[j]);
+    nrm[j] = ni;
+  }
+  nrm[0] = inv;
 }
 
 // affine storage: coordinate c (x, y) of step t, component q: limb i of instance k at base + aff_off<E>(t, c, q, K) + i*K + k
@@ -65,59 +85,103 @@ __global__ void chain_kernel(const uint32_t* __restrict__ ios, size_t K, u64* __
   if (bad) atomicOr(err, bad);
 }
 
-// One lane per (which, t, k): affine x = X / Z^2, y = Y / Z^3 (Montgomery form) for t = 0..256 of both chains.
+// One lane per TG_INV_BATCH values (which, t, k): affine x = X / Z^2, y = Y / Z^3 (Montgomery form) for t = 0..256 of both chains.
+// Lane L owns the values L, L + NL, L + 2 NL, ... (NL lanes): neighbouring lanes read neighbouring values.
 template <int E>
 __global__ void affine_kernel(const u64* __restrict__ ja, const u64* __restrict__ jb, size_t K, u64* __restrict__ aa, u64* __restrict__ ab, int* __restrict__ err) {
-  const size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  const size_t per = 257 * K;
-  if (g >= 2 * per) return;
-  const bool second = g >= per;
-  const size_t h = second ? g - per : g;
-  const int t = (int)(h / K); const size_t k = h % K;
-  const u64* j = second ? jb : ja; u64* o = second ? ab : aa;
-  const Co<E> X = ldc<E>(j + jac_at<E>(k, t, 0)), Y = ldc<E>(j + jac_at<E>(k, t, 1)), Z = ldc<E>(j + jac_at<E>(k, t, 2));
-  if (czero<E>(Z)) { atomicOr(err, TG_ERR_DEGENERATE); return; }
-  const Co<E> zi = cinv(Z), zi2 = cmul(zi, zi);
-  sta<E>(o, t, 0, k, K, cmul(X, zi2));
-  sta<E>(o, t, 1, k, K, cmul(Y, cmul(zi2, zi)));
+  const size_t L = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  const size_t per = 257 * K, total = 2 * per, NL = (total + TG_INV_BATCH - 1) / TG_INV_BATCH;
+  if (L >= NL) return;
+  Fq nrm[TG_INV_BATCH];
+  for (int j = 0; j < TG_INV_BATCH; j++) {   // (not unrolled: the eight values sit in scratch memory, which costs nothing next to ~45 multiplies each)
+    const size_t g = L + (size_t)j * NL;
+    nrm[j] = fq_one();
+    if (g < total) {
+      const bool second = g >= per;
+      const size_t h = second ? g - per : g;
+      const Co<E> Z = ldc<E>((second ? jb : ja) + jac_at<E>(h % K, (int)(h / K), 2));
+      if (czero<E>(Z)) atomicOr(err, TG_ERR_DEGENERATE); else nrm[j] = cnorm(Z);   // (a zero would poison the batch; the proof is refused anyway)
+    }
+  }
+  batch_inverse(nrm);
+  for (int j = 0; j < TG_INV_BATCH; j++) {   // (not unrolled: the eight values sit in scratch memory, which costs nothing next to ~45 multiplies each)
+    const size_t g = L + (size_t)j * NL;
+    if (g >= total) continue;
+    const bool second = g >= per;
+    const size_t h = second ? g - per : g;
+    const int t = (int)(h / K); const size_t k = h % K;
+    const u64* jj = second ? jb : ja; u64* o = second ? ab : aa;
+    const Co<E> X = ldc<E>(jj + jac_at<E>(k, t, 0)), Y = ldc<E>(jj + jac_at<E>(k, t, 1)), Z = ldc<E>(jj + jac_at<E>(k, t, 2));
+    const Co<E> zi = cinv_from_norm(Z, nrm[j]), zi2 = cmul(zi, zi);
+    sta<E>(o, t, 0, k, K, cmul(X, zi2));
+    sta<E>(o, t, 1, k, K, cmul(Y, cmul(zi2, zi)));
+  }
 }
 
-// One lane per row: the standard-form values ax ay bx by lam nx ny of the row (sv[((v*E + q)*4 + limb) * n + row]) and
-// its operation (0 none, 1 add, 2 double).  Row r of instance k: a = A[r>>1]; even rows: b = B[r>>1], add if bit;
-// odd rows: b = B[(r>>1)+1], double.  Also writes the instance output B[256] (u32 limbs) for the public inputs.
+// One lane per TG_INV_BATCH rows (row = L + j NL): the standard-form values ax ay bx by lam nx ny of the row
+// (sv[((v*E + q)*4 + limb) * n + row]) and its operation (0 none, 1 add, 2 double).  Row r of instance k: a = A[r>>1]; even
+// rows: b = B[r>>1], add if bit; odd rows: b = B[(r>>1)+1], double.  Also writes the instance output B[256] (u32 limbs) for
+// the public inputs.  The slope denominators of a lane's rows are inverted as one batch.
+template <int E>
+struct LambdaRow {
+  size_t k; int t, tb, op; bool dbl;
+  __device__ __forceinline__ LambdaRow(const uint32_t* __restrict__ ios, size_t row) {
+    k = row >> 9; const int r = (int)(row & 511); t = r >> 1; dbl = r & 1;
+    const bool bit = (ios[8 * (4 * E + 1) * k + 32 * E + (t >> 5)] >> (t & 31)) & 1;
+    op = dbl ? 2 : (bit ? 1 : 0);
+    tb = dbl ? t + 1 : t;
+  }
+};
 template <int E>
 __global__ void lambda_kernel(const uint32_t* __restrict__ ios, size_t K, const u64* __restrict__ aa, const u64* __restrict__ ab, size_t n,
                               u64* __restrict__ sv, unsigned char* __restrict__ row_op, u64* __restrict__ pi_out, int* __restrict__ err) {
-  const size_t row = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  if (row >= n) return;
-  const size_t k = row >> 9; const int r = (int)(row & 511), t = r >> 1; const bool dbl = r & 1;
-  const bool bit = (ios[8 * (4 * E + 1) * k + 32 * E + (t >> 5)] >> (t & 31)) & 1;
-  const int op = dbl ? 2 : (bit ? 1 : 0);
-  const int tb = dbl ? t + 1 : t;
-  Co<E> v[7];
-  v[0] = lda<E>(aa, t, 0, k, K); v[1] = lda<E>(aa, t, 1, k, K);
-  v[2] = lda<E>(ab, tb, 0, k, K); v[3] = lda<E>(ab, tb, 1, k, K);
-  if (op) {
-    Co<E> den, num;
-    if (dbl) { den = cadd(v[1], v[1]); Co<E> x2 = cmul(v[0], v[0]); num = cadd(cadd(x2, x2), x2); }
-    else { den = csub(v[2], v[0]); num = csub(v[3], v[1]); }
-    if (czero<E>(den)) atomicOr(err, TG_ERR_DEGENERATE);
-    v[4] = cmul(num, cinv(den));
-    const u64* nsrc = dbl ? aa : ab;
-    v[5] = lda<E>(nsrc, t + 1, 0, k, K); v[6] = lda<E>(nsrc, t + 1, 1, k, K);
-  }
-  for (int w = 0; w < (op ? 7 : 4); w++)
-    for (int q = 0; q < E; q++) {
-      u64 s[4]; from_m(v[w].c[q], s);
-      for (int i = 0; i < 4; i++) sv[(size_t)((w * E + q) * 4 + i) * n + row] = s[i];
-    }
-  row_op[row] = (unsigned char)op;
-  if (r == 511) {  // b at the last row is the output (g1/exp.rs:124-135, g2/exp.rs:139-156)
-    for (int c = 0; c < 2; c++)
-      for (int q = 0; q < E; q++) {
-        u64 s[4]; from_m(v[2 + c].c[q], s);
-        for (int i = 0; i < 8; i++) pi_out[16 * E * k + 8 * (c * E + q) + i] = (s[i >> 1] >> (32 * (i & 1))) & 0xffffffffULL;
+  const size_t L = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  const size_t NL = (n + TG_INV_BATCH - 1) / TG_INV_BATCH;
+  if (L >= NL) return;
+  Fq nrm[TG_INV_BATCH];
+  for (int j = 0; j < TG_INV_BATCH; j++) {   // (not unrolled: the eight values sit in scratch memory, which costs nothing next to ~45 multiplies each)
+    const size_t row = L + (size_t)j * NL;
+    nrm[j] = fq_one();
+    if (row < n) {
+      const LambdaRow<E> R(ios, row);
+      if (R.op) {
+        Co<E> den;
+        if (R.dbl) { const Co<E> y = lda<E>(aa, R.t, 1, R.k, K); den = cadd(y, y); }
+        else den = csub(lda<E>(ab, R.tb, 0, R.k, K), lda<E>(aa, R.t, 0, R.k, K));
+        if (czero<E>(den)) atomicOr(err, TG_ERR_DEGENERATE); else nrm[j] = cnorm(den);
       }
+    }
+  }
+  batch_inverse(nrm);
+  for (int j = 0; j < TG_INV_BATCH; j++) {   // (not unrolled: the eight values sit in scratch memory, which costs nothing next to ~45 multiplies each)
+    const size_t row = L + (size_t)j * NL;
+    if (row >= n) continue;
+    const LambdaRow<E> R(ios, row);
+    const size_t k = R.k; const int t = R.t, op = R.op; const bool dbl = R.dbl;
+    Co<E> v[7];
+    v[0] = lda<E>(aa, t, 0, k, K); v[1] = lda<E>(aa, t, 1, k, K);
+    v[2] = lda<E>(ab, R.tb, 0, k, K); v[3] = lda<E>(ab, R.tb, 1, k, K);
+    if (op) {
+      Co<E> den, num;
+      if (dbl) { den = cadd(v[1], v[1]); Co<E> x2 = cmul(v[0], v[0]); num = cadd(cadd(x2, x2), x2); }
+      else { den = csub(v[2], v[0]); num = csub(v[3], v[1]); }
+      v[4] = cmul(num, cinv_from_norm(den, nrm[j]));
+      const u64* nsrc = dbl ? aa : ab;
+      v[5] = lda<E>(nsrc, t + 1, 0, k, K); v[6] = lda<E>(nsrc, t + 1, 1, k, K);
+    }
+    for (int w = 0; w < (op ? 7 : 4); w++)
+      for (int q = 0; q < E; q++) {
+        u64 s[4]; from_m(v[w].c[q], s);
+        for (int i = 0; i < 4; i++) sv[(size_t)((w * E + q) * 4 + i) * n + row] = s[i];
+      }
+    row_op[row] = (unsigned char)op;
+    if ((row & 511) == 511) {  // b at the last row is the output (g1/exp.rs:124-135, g2/exp.rs:139-156)
+      for (int c = 0; c < 2; c++)
+        for (int q = 0; q < E; q++) {
+          u64 s[4]; from_m(v[2 + c].c[q], s);
+          for (int i = 0; i < 8; i++) pi_out[16 * E * k + 8 * (c * E + q) + i] = (s[i >> 1] >> (32 * (i & 1))) & 0xffffffffULL;
+        }
+    }
   }
 }
 

@@ -679,9 +679,9 @@ static int generate_trace_device(sbn_prover* P, const uint32_t* ios, size_t K, u
     HIPC(hipMemcpyAsync(jb, P->h_chain + cw, cw * sizeof(u64), hipMemcpyHostToDevice, st));
   }
   mark();
-  hipLaunchKernelGGL(tg::affine_kernel<E>, blocks(2 * 257 * K, 64), dim3(64), 0, st, ja, jb, K, aa, ab, d_err);
+  hipLaunchKernelGGL(tg::affine_kernel<E>, blocks((2 * 257 * K + tg::TG_INV_BATCH - 1) / tg::TG_INV_BATCH, 64), dim3(64), 0, st, ja, jb, K, aa, ab, d_err);
   mark();
-  hipLaunchKernelGGL(tg::lambda_kernel<E>, blocks(n, 64), dim3(64), 0, st, d_ios, K, aa, ab, n, sv, row_op, d_out, d_err);
+  hipLaunchKernelGGL(tg::lambda_kernel<E>, blocks((n + tg::TG_INV_BATCH - 1) / tg::TG_INV_BATCH, 64), dim3(64), 0, st, d_ios, K, aa, ab, n, sv, row_op, d_out, d_err);
   mark();
   hipLaunchKernelGGL(tg::row_witness_kernel<E>, blocks(n, 128), dim3(128), 0, st, sv, row_op, n, sh.gadget_col, P->d_trace, d_err);
   mark();
