@@ -53,7 +53,8 @@ typedef enum sbn_status {
 
 /* Table kinds.  G1_OP = reference `G1Stark` (src/curves/g1/muladd.rs:462-624);
  * G1_EXP = reference `G1ExpStark` (src/curves/g1/exp.rs:232-742). */
-typedef enum sbn_air_kind { SBN_AIR_G1_OP = 1, SBN_AIR_G1_EXP = 2, SBN_AIR_G2_EXP = 3, SBN_AIR_FQ12_EXP = 4, SBN_AIR_FQ_EXP = 5, SBN_AIR_FQ12_EXP_U64 = 6 } sbn_air_kind;
+typedef enum sbn_air_kind { SBN_AIR_G1_OP = 1, SBN_AIR_G1_EXP = 2, SBN_AIR_G2_EXP = 3, SBN_AIR_FQ12_EXP = 4, SBN_AIR_FQ_EXP = 5, SBN_AIR_FQ12_EXP_U64 = 6,
+                              SBN_AIR_MODULAR = 7, SBN_AIR_FQ12_MUL = 8 } sbn_air_kind;
 /* G2_EXP = reference `G2ExpStark` (src/curves/g2/exp.rs:248-807): the same machine over Fq2 coordinates.
  * FQ12_EXP = reference `Fq12ExpStark` (src/fields/fq12/exp.rs:223-605): offset * x^e in Fq12 (flat basis of
  * plonky2-bn254 `MyFq12`: coefficient of w^k is c[k] + c[k+6]*i, w^6 = 9 + i), 512 rows per instance, num_io a
@@ -61,7 +62,10 @@ typedef enum sbn_air_kind { SBN_AIR_G1_OP = 1, SBN_AIR_G1_EXP = 2, SBN_AIR_G2_EX
  * FQ_EXP = reference `FqExpStark` (src/fields/fq/exp.rs:193-582): offset * x^e in the base field Fq, the same
  * square-and-multiply machine over one coefficient (960 columns at num_io = 128), u32 public inputs, u16 range check.
  * FQ12_EXP_U64 = reference `Fq12ExpU64Stark` (src/fields/fq12_u64/exp_u64.rs:243-571): Fq12 exponentiation by a u64
- * exponent, 128 rows per instance, 6-column flags (flags_u64.rs), the exponent is ONE public input (< p). */
+ * exponent, 128 rows per instance, 6-column flags (flags_u64.rs), the exponent is ONE public input (< p).
+ * MODULAR = reference `ModularStark` (src/modular/modular.rs:361-537) and FQ12_MUL = reference `Fq12Stark`
+ * (src/fields/fq12/mul.rs:355-517): its single-operation test tables for the modular gadget (a * b mod p per row, 812
+ * columns) and the Fq12 product (9722 columns); no public inputs, num_io ignored, any power-of-two height >= 256. */
 
 typedef struct sbn_air_desc {
   int32_t kind;    /* sbn_air_kind */
@@ -125,6 +129,10 @@ int sbn_generate_trace_fq12_exp_u64(const uint32_t* ios, size_t num_io, uint64_t
 int sbn_generate_trace_fq_exp(const uint32_t* ios, size_t num_io, uint64_t* trace_out, uint64_t* pi_out);
 /* pts: rows x 32 u32 = a.x[8] a.y[8] b.x[8] b.y[8]; trace_out: [num_columns][rows]. */
 int sbn_generate_trace_g1_op(const uint32_t* pts, size_t rows, uint64_t* trace_out);
+/* ModularStark::generate_trace (modular.rs:383-437) with the operands given: ops: rows x 16 u32 = a[8] b[8] (both < p). */
+int sbn_generate_trace_modular(const uint32_t* ops, size_t rows, uint64_t* trace_out);
+/* Fq12Stark::generate_trace (fq12/mul.rs:375-419): ops: rows x 192 u32 = x[12] y[12] (flat-basis coefficients < p, 8 u32 limbs each). */
+int sbn_generate_trace_fq12_mul(const uint32_t* ops, size_t rows, uint64_t* trace_out);
 
 /* Prover ---------------------------------------------------------------------------------------- */
 int sbn_prover_create(const sbn_air_desc* air, const sbn_config* cfg, uint32_t degree_bits, sbn_prover** out);

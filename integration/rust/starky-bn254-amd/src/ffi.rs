@@ -43,6 +43,9 @@ pub const SBN_AIR_G2_EXP: i32 = 3;
 pub const SBN_AIR_FQ12_EXP: i32 = 4;
 pub const SBN_AIR_FQ_EXP: i32 = 5;
 pub const SBN_AIR_FQ12_EXP_U64: i32 = 6;
+/// the reference's single-operation test tables (`ModularStark`, `Fq12Stark`)
+pub const SBN_AIR_MODULAR: i32 = 7;
+pub const SBN_AIR_FQ12_MUL: i32 = 8;
 
 extern "C" {
     pub fn sbn_last_error() -> *const c_char;

@@ -1394,4 +1394,86 @@ struct FqExpAir : AirBase<FqExpAir> {
   }
 };
 
+// ---- the reference's own single-operation test tables (512 rows in its tests; split range check like G1Stark) ----------
+// split_u16_range_check_pairs (range_check.rs:228-246) for targets [main_col + 1 + 6 i ...)
+static inline std::vector<std::pair<size_t, size_t>> split_range_check_pairs(size_t main_cols, size_t num_rc) {
+  std::vector<std::pair<size_t, size_t>> p;
+  for (size_t i = main_cols + 1; i < main_cols + 1 + 6 * num_rc; i += 6) {
+    p.push_back({main_cols, i + 2}); p.push_back({main_cols, i + 5});
+    p.push_back({i, i + 1}); p.push_back({i + 3, i + 4});
+  }
+  return p;
+}
+// ModularStark: src/modular/modular.rs:361-537.  Row: input0[16] input1[16] output[16] ModulusAux(95) quot_sign filter;
+// output and aux are range-checked; constraints: the split range check, then eval_modular_op on input0 * input1.
+struct ModularAir : AirBase<ModularAir> {
+  static const int MAIN_COLS = 9 * N_LIMBS + 1;                                                 // :361
+  static const int START_RC = 2 * N_LIMBS, NUM_RC = 7 * N_LIMBS - 1, END_RC = START_RC + NUM_RC;  // :364-366
+  size_t num_columns() const override { return MAIN_COLS + 1 + 6 * NUM_RC; }                    // :368
+  size_t num_public_inputs() const override { return 0; }
+  std::vector<std::pair<size_t, size_t>> permutation_pairs() const override { return split_range_check_pairs(MAIN_COLS, NUM_RC); }  // :533-535
+  template <class P> void eval_t(const P* lv, const P* nv, const P*, Consumer<P>& yc) const {  // :441-477
+    eval_split_u16_range_check(yc, lv, nv, MAIN_COLS, START_RC, END_RC);
+    int cur = 0;
+    auto input0 = read16(lv, cur), input1 = read16(lv, cur);
+    FqOutput<P> o = read_fq_output(lv, cur);   // output, aux, quot_sign in this order (read_u256, read_modulus_aux, lv[cur])
+    P filter = lv[cur++];
+    assert(cur == MAIN_COLS);
+    eval_modular_op(yc, filter, bn254_modulus_p<P>(), pol_mul_wide(input0, input1), o.output, o.quot_sign, o.aux);
+  }
+  // generate_trace :383-437 with caller-provided operands (the reference draws them at random)
+  std::vector<std::vector<GF>> generate_trace(const std::vector<U256>& a, const std::vector<U256>& b) const {
+    size_t rows = a.size();
+    std::vector<std::vector<GF>> cols(MAIN_COLS, std::vector<GF>(rows));
+#pragma omp parallel for schedule(static)
+    for (size_t r = 0; r < rows; r++) {
+      GF lv[MAIN_COLS];
+      auto x = u256_to_limbs16(a[r]), y = u256_to_limbs16(b[r]);
+      for (int i = 0; i < 16; i++) { lv[i] = GF((u64)x[i]); lv[16 + i] = GF((u64)y[i]); }
+      Arr<int64_t, 16> out;
+      generate_fq_mul(x, y, lv + 32, out);
+      lv[MAIN_COLS - 1] = GF::one();
+      for (int c = 0; c < MAIN_COLS; c++) cols[c][r] = lv[c];
+    }
+    generate_split_u16_range_check(START_RC, END_RC, cols);
+    return cols;
+  }
+};
+// Fq12Stark: src/fields/fq12/mul.rs:355-517.  Row: x[12][16] y[12][16] Fq12Output(1344) filter.
+struct Fq12MulAir : AirBase<Fq12MulAir> {
+  static const int MAIN_COLS = 108 * N_LIMBS + 1;                                                   // :355
+  static const int START_RC = 24 * N_LIMBS, NUM_RC = 84 * N_LIMBS - 12, END_RC = START_RC + NUM_RC;  // :356-358
+  size_t num_columns() const override { return MAIN_COLS + 1 + 6 * NUM_RC; }
+  size_t num_public_inputs() const override { return 0; }
+  std::vector<std::pair<size_t, size_t>> permutation_pairs() const override { return split_range_check_pairs(MAIN_COLS, NUM_RC); }
+  template <class P> void eval_t(const P* lv, const P* nv, const P*, Consumer<P>& yc) const {  // :423-448
+    eval_split_u16_range_check(yc, lv, nv, MAIN_COLS, START_RC, END_RC);
+    int cur = 0;
+    auto x = read_fq12(lv, cur), y = read_fq12(lv, cur);
+    Fq12Output<P> o = read_fq12_output(lv, cur);
+    P filter = lv[cur++];
+    assert(cur == MAIN_COLS);
+    eval_fq12_mul(yc, filter, x, y, o);
+  }
+  // generate_trace :375-419 with caller-provided operands: x[r], y[r] = 12 coefficients each
+  std::vector<std::vector<GF>> generate_trace(const std::vector<std::array<U256, 12>>& xs, const std::vector<std::array<U256, 12>>& ys) const {
+    size_t rows = xs.size();
+    std::vector<std::vector<GF>> cols(MAIN_COLS, std::vector<GF>(rows));
+#pragma omp parallel for schedule(static)
+    for (size_t r = 0; r < rows; r++) {
+      std::vector<GF> lv(MAIN_COLS);
+      Fq12Limbs<int64_t> x, y, out;
+      for (int i = 0; i < 12; i++) {
+        x[i] = u256_to_limbs16(xs[r][i]); y[i] = u256_to_limbs16(ys[r][i]);
+        for (int k = 0; k < 16; k++) { lv[16 * i + k] = GF((u64)x[i][k]); lv[192 + 16 * i + k] = GF((u64)y[i][k]); }
+      }
+      generate_fq12_mul(x, y, lv.data() + 384, out);
+      lv[MAIN_COLS - 1] = GF::one();
+      for (int c = 0; c < MAIN_COLS; c++) cols[c][r] = lv[c];
+    }
+    generate_split_u16_range_check(START_RC, END_RC, cols);
+    return cols;
+  }
+};
+
 }  // namespace orc

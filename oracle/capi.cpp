@@ -15,6 +15,8 @@ static std::unique_ptr<Air> make_air(int kind, size_t num_io) {
   if (kind == 4) return std::unique_ptr<Air>(new Fq12ExpAir(num_io));
   if (kind == 5) return std::unique_ptr<Air>(new FqExpAir(num_io));
   if (kind == 6) return std::unique_ptr<Air>(new Fq12ExpU64Air(num_io));
+  if (kind == 7) return std::unique_ptr<Air>(new ModularAir());
+  if (kind == 8) return std::unique_ptr<Air>(new Fq12MulAir());
   return nullptr;
 }
 static U256 u256_from_u32(const uint32_t* w) {
@@ -219,6 +221,26 @@ int orc_g1op_generate_trace(const uint32_t* pts, size_t rows, uint64_t* trace_ou
     a[r].x = u256_from_u32(w); a[r].y = u256_from_u32(w + 8); b[r].x = u256_from_u32(w + 16); b[r].y = u256_from_u32(w + 24);
   }
   auto cols = air.generate_trace(a, b);
+  for (size_t c = 0; c < cols.size(); c++) for (size_t i = 0; i < rows; i++) trace_out[c * rows + i] = cols[c][i].v;
+  return 0;
+}
+
+// ops: rows x 16 u32 = a b (each < p)
+int orc_modular_generate_trace(const uint32_t* ops, size_t rows, uint64_t* trace_out) {
+  ModularAir air;
+  std::vector<U256> a(rows), b(rows);
+  for (size_t r = 0; r < rows; r++) { a[r] = u256_from_u32(ops + 16 * r); b[r] = u256_from_u32(ops + 16 * r + 8); }
+  auto cols = air.generate_trace(a, b);
+  for (size_t c = 0; c < cols.size(); c++) for (size_t i = 0; i < rows; i++) trace_out[c * rows + i] = cols[c][i].v;
+  return 0;
+}
+// ops: rows x 192 u32 = x[12] y[12] (coefficients < p, flat basis of fq12_to_columns)
+int orc_fq12mul_generate_trace(const uint32_t* ops, size_t rows, uint64_t* trace_out) {
+  Fq12MulAir air;
+  std::vector<std::array<U256, 12>> x(rows), y(rows);
+  for (size_t r = 0; r < rows; r++)
+    for (int i = 0; i < 12; i++) { x[r][i] = u256_from_u32(ops + 192 * r + 8 * i); y[r][i] = u256_from_u32(ops + 192 * r + 96 + 8 * i); }
+  auto cols = air.generate_trace(x, y);
   for (size_t c = 0; c < cols.size(); c++) for (size_t i = 0; i < rows; i++) trace_out[c * rows + i] = cols[c][i].v;
   return 0;
 }

@@ -11,6 +11,8 @@ import os
 import numpy as np
 
 AIR_G1_OP = 1
+AIR_MODULAR = 7
+AIR_FQ12_MUL = 8
 AIR_G1_EXP = 2
 AIR_G2_EXP = 3
 AIR_FQ12_EXP = 4
@@ -25,7 +27,7 @@ EXPORTS = [
     "sbn_version", "sbn_last_error", "sbn_device_count", "sbn_set_device", "sbn_standard_fast_config",
     "sbn_air_num_columns", "sbn_air_num_public_inputs", "sbn_air_num_permutation_zs", "sbn_air_num_constraints",
     "sbn_generate_trace_g1_exp", "sbn_generate_trace_g2_exp", "sbn_generate_trace_fq12_exp", "sbn_generate_trace_fq_exp", "sbn_generate_trace_fq12_exp_u64",
-    "sbn_generate_trace_g1_op",
+    "sbn_generate_trace_g1_op", "sbn_generate_trace_modular", "sbn_generate_trace_fq12_mul",
     "sbn_prover_create", "sbn_prover_destroy", "sbn_prover_load_trace", "sbn_prover_load_trace_device",
     "sbn_prover_prove", "sbn_prover_stage_times", "sbn_prover_stage_name", "sbn_prover_trace_device_ptr",
     "sbn_prover_generate_trace", "sbn_prover_read_trace",
@@ -83,6 +85,8 @@ def lib():
         L.sbn_generate_trace_fq_exp.argtypes = [vp, sz, vp, vp]
         L.sbn_generate_trace_fq12_exp_u64.argtypes = [vp, sz, vp, vp]
         L.sbn_generate_trace_g1_op.argtypes = [vp, sz, vp]
+        L.sbn_generate_trace_modular.argtypes = [vp, sz, vp]
+        L.sbn_generate_trace_fq12_mul.argtypes = [vp, sz, vp]
         L.sbn_prover_create.argtypes = [C.POINTER(_AirDesc), C.POINTER(_Config), u32, C.POINTER(vp)]
         L.sbn_prover_destroy.argtypes = [vp]
         L.sbn_prover_load_trace.argtypes = [vp, vp, vp, sz]
@@ -188,6 +192,40 @@ class G1Stark(_Stark):
         rows = pts.shape[0]
         trace = np.zeros((self.num_columns, rows), dtype=np.uint64)
         _check(lib().sbn_generate_trace_g1_op(_ptr(pts), rows, _ptr(trace)))
+        return trace
+
+
+class ModularStark(_Stark):
+    """Reference `ModularStark` (src/modular/modular.rs:361-537): one a * b mod p per row -- the reference's test table for the modular gadget."""
+    kind = AIR_MODULAR
+
+    def __init__(self):
+        super().__init__(0)
+
+    def generate_trace(self, ops):
+        """ops: (rows, 16) uint32 = a b as 8xu32 LE limbs (both < p) -> column-major (ncols, rows) uint64."""
+        ops = np.ascontiguousarray(ops, dtype=np.uint32)
+        rows = ops.shape[0]
+        assert ops.shape == (rows, 16)
+        trace = np.zeros((self.num_columns, rows), dtype=np.uint64)
+        _check(lib().sbn_generate_trace_modular(_ptr(ops), rows, _ptr(trace)))
+        return trace
+
+
+class Fq12Stark(_Stark):
+    """Reference `Fq12Stark` (src/fields/fq12/mul.rs:355-517): one Fq12 product per row -- the reference's test table for eval_fq12_mul."""
+    kind = AIR_FQ12_MUL
+
+    def __init__(self):
+        super().__init__(0)
+
+    def generate_trace(self, ops):
+        """ops: (rows, 192) uint32 = x[12] y[12] (flat-basis coefficients < p, 8xu32 LE limbs each)."""
+        ops = np.ascontiguousarray(ops, dtype=np.uint32)
+        rows = ops.shape[0]
+        assert ops.shape == (rows, 192)
+        trace = np.zeros((self.num_columns, rows), dtype=np.uint64)
+        _check(lib().sbn_generate_trace_fq12_mul(_ptr(ops), rows, _ptr(trace)))
         return trace
 
 

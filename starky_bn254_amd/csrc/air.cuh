@@ -572,6 +572,51 @@ GL_HD void fq_gadget(const Cons<P>& cs, const Row& row, P* h_sq, P* h_mul) {
   }
 }
 
+// ---- ModularStark (src/modular/modular.rs:361-537) and Fq12Stark (src/fields/fq12/mul.rs:355-517) ----------------------------
+// The reference's own test tables for the modular gadget and the Fq12 product: one operation per row behind a filter column
+// (the last main column), split range check over output + aux columns, constraints = the range check, then the gadget --
+// the shape of G1Stark above.  Their rows are laid out as fq_gadget / fq12_gadget expect (a, b, output, aux.., signs).
+struct OpShape {
+  int kind;        // 7 = ModularStark (a * b mod p), 8 = Fq12Stark (x * y in Fq12): the sbn_air_kind values
+  int main_cols, start_rc, num_rc, gadget_cons;
+  GL_HD explicit OpShape(int k) : kind(k) {
+    if (k == 8) { main_cols = 108 * 16 + 1; start_rc = 24 * 16; num_rc = 84 * 16 - 12; gadget_cons = 12 * 66; }   // mul.rs:355-358
+    else { main_cols = 9 * 16 + 1; start_rc = 2 * 16; num_rc = 7 * 16 - 1; gadget_cons = 66; }                     // modular.rs:361-366
+  }
+  GL_HD int num_cols() const { return main_cols + 1 + 6 * num_rc; }
+  GL_HD int num_pairs() const { return 4 * num_rc; }
+  GL_HD int num_constraints() const { return num_rc + 4 * num_rc + 3 + gadget_cons; }
+  // split_u16_range_check_pairs (range_check.rs:228-246)
+  GL_HD void pair(int z, int& lhs, int& rhs) const {
+    int t = z >> 2, w = z & 3, i = main_cols + 1 + 6 * t;
+    if (w == 0) { lhs = main_cols; rhs = i + 2; }
+    else if (w == 1) { lhs = main_cols; rhs = i + 5; }
+    else if (w == 2) { lhs = i; rhs = i + 1; }
+    else { lhs = i + 3; rhs = i + 4; }
+  }
+};
+template <int KIND, class P, class Row>
+GL_HD void op_eval(Cons<P>& cs, const Row& row, const OpShape& S) {
+  // eval_split_u16_range_check (range_check.rs:162-192)
+  const P c256 = lift<P>(256);
+#pragma unroll 4
+  for (int i = 0; i < S.num_rc; i++) {
+    P lo = row.l(S.main_cols + 1 + 6 * i), hi = row.l(S.main_cols + 4 + 6 * i);
+    cs.c(row.l(S.start_rc + i) - (lo + hi * c256));
+  }
+#pragma unroll 2
+  for (int i = S.main_cols + 1; i < S.main_cols + 1 + 6 * S.num_rc; i += 6) {
+    lookup_pair(cs, row, i + 1, i + 2);
+    lookup_pair(cs, row, i + 4, i + 5);
+  }
+  range_table_block(cs, row, S.main_cols, 255);
+  // eval_modular_op(filter, input0 * input1, ..) (modular.rs:465-476) / eval_fq12_mul(filter, x, y, output) (mul.rs:447): the
+  // product sums of the gadgets; their square sums are not needed here
+  P h_sq[SBN_NCH], h_mul[SBN_NCH];
+  if (KIND == 8) fq12_gadget(cs, row, h_sq, h_mul); else fq_gadget(cs, row, h_sq, h_mul);
+  cs.merge(h_mul, row.l(S.main_cols - 1), S.gadget_cons);
+}
+
 // ---- G1ExpStark / G2ExpStark (src/curves/g1/exp.rs, src/curves/g2/exp.rs) --------------------------------
 // Both tables are the same double-and-add machine; E = 1 (Fq coordinates) or 2 (Fq2 coordinates) scales
 // the point columns (32E per point), the gadget (320E columns, 165E constraints) and the public inputs.

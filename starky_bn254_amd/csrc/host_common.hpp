@@ -67,6 +67,9 @@ static inline bool air_shape(const sbn_air_desc* air, const sbn_config* cfg, Air
   u32 nch = cfg ? cfg->num_challenges : 2;
   if (air->kind == SBN_AIR_G1_OP) {
     s.ncols = G1OpShape::NUM_COLS; s.npi = 0; s.npairs = G1OpShape::NUM_PAIRS; s.nconstraints = G1OpShape::NUM_CONSTRAINTS;
+  } else if (air->kind == SBN_AIR_MODULAR || air->kind == SBN_AIR_FQ12_MUL) {
+    OpShape sh(air->kind);
+    s.ncols = sh.num_cols(); s.npi = 0; s.npairs = sh.num_pairs(); s.nconstraints = sh.num_constraints();
   } else if (air->kind == SBN_AIR_G1_EXP || air->kind == SBN_AIR_G2_EXP || air->kind == SBN_AIR_FQ12_EXP || air->kind == SBN_AIR_FQ_EXP || air->kind == SBN_AIR_FQ12_EXP_U64) {
     if (air->num_io == 0 || air->num_io > (u32)G1EXP_MAX_IO || (air->num_io & (air->num_io - 1))) return false;
     ExpShape sh(exp_e(air->kind), (int)air->num_io);
@@ -76,6 +79,7 @@ static inline bool air_shape(const sbn_air_desc* air, const sbn_config* cfg, Air
   s.nzs = (s.npairs * nch + 1) / 2;
   return true;
 }
+static inline bool is_op_air(int kind) { return kind == SBN_AIR_MODULAR || kind == SBN_AIR_FQ12_MUL; }   // OpShape tables (air.cuh)
 static inline bool is_exp_air(int kind) { return kind == SBN_AIR_G1_EXP || kind == SBN_AIR_G2_EXP || kind == SBN_AIR_FQ12_EXP || kind == SBN_AIR_FQ_EXP || kind == SBN_AIR_FQ12_EXP_U64; }
 static inline size_t exp_rows_per_instance(int kind) { return kind == SBN_AIR_FQ12_EXP_U64 ? 128 : 512; }
 // u32 words of one instance in the `ios` arrays of include/sbn.h (x, offset, exp_val)

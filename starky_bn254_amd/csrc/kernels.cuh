@@ -705,6 +705,13 @@ __global__ __launch_bounds__(256, 2) void quotient_kernel(QuotientParams p, cons
       if (seg == 2) permutation_checks(cs, row, zrow, G1OpShape(), p.num_zs, F(p.gamma0), F(p.gamma1), true, 0, p.zsplit);
       else permutation_checks(cs, row, zrow, G1OpShape(), p.num_zs, F(p.gamma0), F(p.gamma1), false, p.zsplit, p.num_zs);
     }
+  } else if (KIND == 7 || KIND == 8) {   // ModularStark / Fq12Stark: everything but the permutation checks is the head segment
+    const OpShape sh(KIND);
+    if (PART == 0) op_eval<KIND>(cs, row, sh);
+    else if (PART == 2) {
+      if (seg == 2) permutation_checks(cs, row, zrow, sh, p.num_zs, F(p.gamma0), F(p.gamma1), true, 0, p.zsplit);
+      else permutation_checks(cs, row, zrow, sh, p.num_zs, F(p.gamma0), F(p.gamma1), false, p.zsplit, p.num_zs);
+    }
   } else {
     constexpr int E = KIND == 4 ? 12 : (KIND == 6 ? 13 : (KIND == 3 ? 2 : (KIND == 5 ? 0 : 1)));
     ExpShape sh(E, p.num_io);

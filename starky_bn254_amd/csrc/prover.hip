@@ -528,7 +528,9 @@ static int create_ctx(const sbn_air_desc* air, const sbn_config* cfg, uint32_t d
     std::vector<PairCols> pairs(Z);
     for (size_t z = 0; z < Z; z++) {
       int l, r;
-      if (as.kind == SBN_AIR_G1_OP) G1OpShape::pair((int)z, l, r); else exp_shape(as).pair((int)z, l, r);
+      if (as.kind == SBN_AIR_G1_OP) G1OpShape::pair((int)z, l, r);
+      else if (is_op_air(as.kind)) OpShape(as.kind).pair((int)z, l, r);
+      else exp_shape(as).pair((int)z, l, r);
       pairs[z].lhs = l; pairs[z].rhs = r;
     }
     hipc(hipMalloc((void**)&P->d_pairs, Z * sizeof(PairCols)), "hipMalloc");
@@ -924,6 +926,8 @@ static int launch_quotient_parts(sbn_prover* P, const QuotientParams& qp, size_t
     case SBN_AIR_G2_EXP: launch_quotient_kind<3>(P, qp, qblocks); break;
     case SBN_AIR_FQ_EXP: launch_quotient_kind<5>(P, qp, qblocks); break;
     case SBN_AIR_FQ12_EXP_U64: launch_quotient_kind<6>(P, qp, qblocks); break;
+    case SBN_AIR_MODULAR: launch_quotient_kind<7>(P, qp, qblocks); break;
+    case SBN_AIR_FQ12_MUL: launch_quotient_kind<8>(P, qp, qblocks); break;
     default: launch_quotient_kind<4>(P, qp, qblocks); break;
   }
   HIPC(hipGetLastError());

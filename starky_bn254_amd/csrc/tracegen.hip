@@ -365,6 +365,50 @@ extern "C" int sbn_generate_trace_g1_op(const uint32_t* pts, size_t rows, uint64
   return SBN_OK;
 }
 
+// ---- ModularStark (src/modular/modular.rs:383-437) and Fq12Stark (src/fields/fq12/mul.rs:375-419): one product per row ----
+extern "C" int sbn_generate_trace_modular(const uint32_t* ops, size_t rows, uint64_t* trace) {
+  const OpShape S(SBN_AIR_MODULAR);
+  if (!ops || !trace || rows < 256 || (rows & (rows - 1))) return fail(SBN_ERR_BAD_ARG, "rows must be a power of two >= 256");
+  const size_t n = rows;
+  auto col = [&](int c) { return trace + (size_t)c * n; };
+  for (size_t r = 0; r < n; r++)
+    for (int q = 0; q < 2; q++) { u64 t[4]; from_u32(ops + 16 * r + 8 * q, t); if (geq_p(t)) return fail(SBN_ERR_BAD_ARG, "operand >= p (row %zu)", r); }
+  std::atomic<int> bad(0);
+  parallel_for(n, [&](size_t r) {
+    u64 as[4], bs[4], ps[4], lv[112];
+    from_u32(ops + 16 * r, as); from_u32(ops + 16 * r + 8, bs);
+    from_m(mmul(to_m(as), to_m(bs)), ps);
+    put_limbs(col(0) + r, n, as); put_limbs(col(16) + r, n, bs);
+    if (!fq_output_row(as, bs, ps, lv)) { bad = 1; return; }
+    for (int c = 0; c < 112; c++) col(32 + c)[r] = lv[c];   // output, aux, quot_sign
+    col(S.main_cols - 1)[r] = 1;                            // filter
+  });
+  if (bad) return fail(SBN_ERR_WITNESS, "modular witness generation failed");
+  if (!fill_split_range_check(trace, n, S.main_cols, S.start_rc, S.num_rc)) return fail(SBN_ERR_WITNESS, "range-checked column holds a value >= 2^16");
+  return SBN_OK;
+}
+extern "C" int sbn_generate_trace_fq12_mul(const uint32_t* ops, size_t rows, uint64_t* trace) {
+  const OpShape S(SBN_AIR_FQ12_MUL);
+  if (!ops || !trace || rows < 256 || (rows & (rows - 1))) return fail(SBN_ERR_BAD_ARG, "rows must be a power of two >= 256");
+  const size_t n = rows;
+  auto col = [&](int c) { return trace + (size_t)c * n; };
+  for (size_t r = 0; r < n; r++)
+    for (int q = 0; q < 24; q++) { u64 t[4]; from_u32(ops + 192 * r + 8 * q, t); if (geq_p(t)) return fail(SBN_ERR_BAD_ARG, "coefficient >= p (row %zu)", r); }
+  std::atomic<int> bad(0);
+  parallel_for(n, [&](size_t r) {
+    Fq a[12], b[12], prod[12];
+    u64 as[12][4], bs[12][4], ps[12][4];
+    for (int c = 0; c < 12; c++) { from_u32(ops + 192 * r + 8 * c, as[c]); a[c] = to_m(as[c]); from_u32(ops + 192 * r + 96 + 8 * c, bs[c]); b[c] = to_m(bs[c]); }
+    fq12_mul_m(a, b, prod);
+    for (int c = 0; c < 12; c++) { from_m(prod[c], ps[c]); put_limbs(col(16 * c) + r, n, as[c]); put_limbs(col(192 + 16 * c) + r, n, bs[c]); }
+    if (!fq12_output_row(as, bs, ps, [&](int i, u64 v) { col(384 + i)[r] = v; })) { bad = 1; return; }
+    col(S.main_cols - 1)[r] = 1;   // filter
+  });
+  if (bad) return fail(SBN_ERR_WITNESS, "modular witness generation failed");
+  if (!fill_split_range_check(trace, n, S.main_cols, S.start_rc, S.num_rc)) return fail(SBN_ERR_WITNESS, "range-checked column holds a value >= 2^16");
+  return SBN_OK;
+}
+
 // ---- Fq12ExpStark (src/fields/fq12/exp.rs:229-319) --------------------------------------------------------------
 // (fq12_mul_m and fq12_output_row live in bn254w.cuh, shared with the device generator)
 

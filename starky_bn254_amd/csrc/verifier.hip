@@ -176,6 +176,10 @@ extern "C" int sbn_verify(const sbn_air_desc* air, const sbn_config* cfg, const 
   if (as.kind == SBN_AIR_G1_OP) {
     g1op_eval(cs, row);
     permutation_checks(cs, row, zrow, G1OpShape(), (int)nz, g0, g1);
+  } else if (is_op_air(as.kind)) {
+    const OpShape sh(as.kind);
+    if (as.kind == SBN_AIR_FQ12_MUL) op_eval<8>(cs, row, sh); else op_eval<7>(cs, row, sh);
+    permutation_checks(cs, row, zrow, sh, (int)nz, g0, g1);
   } else {
     ExpShape sh = exp_shape(as);
     std::vector<E2> epi(npi); for (size_t i = 0; i < npi; i++) epi[i] = E2(pi[i]);
@@ -274,6 +278,9 @@ extern "C" int sbn_eval_constraints_host(const sbn_air_desc* air, const uint64_t
   HostRowF row{local_row, next_row};
   if (as.kind == SBN_AIR_G1_OP) {
     g1op_eval(cs, row);
+  } else if (is_op_air(as.kind)) {
+    const OpShape sh(as.kind);
+    if (as.kind == SBN_AIR_FQ12_MUL) op_eval<8>(cs, row, sh); else op_eval<7>(cs, row, sh);
   } else {
     ExpShape sh = exp_shape(as);
     std::vector<F> fpi(n_pi); for (size_t i = 0; i < n_pi; i++) fpi[i] = F(public_inputs[i]);

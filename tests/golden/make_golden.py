@@ -10,7 +10,7 @@ What pins what (the reference itself has NO golden vectors -- SURVEY.md section 
   g1_scalar_mult.json    x*s+offset for seeded inputs computed with Python-int affine arithmetic.
   lookup_fixed.json      permuted_cols on the reference's only fixed input (src/utils/lookup.rs:154-161).
   flags_native.json      the reference's test_flag_native property inputs (flags.rs:334-369) for one exponent.
-  proof_digests.json     sha256 of the ORACLE's canonical proof words for seeded G1Stark-512 / G1ExpStark-2^16
+  proof_digests.json     sha256 of the ORACLE's canonical proof words for seeded G1Stark-512 / ModularStark-512 / Fq12Stark-512 / G1ExpStark-2^16
                          traces: pins GPU == oracle without re-running the 100 s CPU prover.
 Run from the repo root:  python3 tests/golden/make_golden.py [--with-g1exp] [--with-g2exp] [--with-fq12exp] [--with-fqexp] [--with-fq12expu64]
 """
@@ -172,6 +172,17 @@ def main():
         w, secs = O.prove(O.AIR_G1_OP, 0, tr, np.zeros(0, dtype=np.uint64))
         assert O.verify(O.AIR_G1_OP, 0, w)[0] == 0
         digests[f"g1op_rows{rows}_seed{seed}"] = {
+            "trace_sha256": hashlib.sha256(tr.tobytes()).hexdigest(), "proof_words": int(len(w)),
+            "proof_sha256": hashlib.sha256(w.astype("<u8").tobytes()).hexdigest(),
+            "trace_cap0": [int(x) for x in w[12:16]], "pow_witness": int(w[-1])}
+    # the reference's single-operation test tables (ModularStark modular.rs:361-537, Fq12Stark fq12/mul.rs:355-517), 512 rows as there
+    for key, kind, inputs, gen in (("modular_rows512_seed6", O.AIR_MODULAR, O.modular_inputs, O.modular_trace),
+                                   ("fq12mul_rows512_seed7", O.AIR_FQ12_MUL, O.fq12mul_inputs, O.fq12mul_trace)):
+        ops, _ = inputs(512, int(key[-1]))
+        tr = gen(ops)
+        w, secs = O.prove(kind, 0, tr, np.zeros(0, dtype=np.uint64))
+        assert O.verify(kind, 0, w)[0] == 0
+        digests[key] = {
             "trace_sha256": hashlib.sha256(tr.tobytes()).hexdigest(), "proof_words": int(len(w)),
             "proof_sha256": hashlib.sha256(w.astype("<u8").tobytes()).hexdigest(),
             "trace_cap0": [int(x) for x in w[12:16]], "pow_witness": int(w[-1])}

@@ -539,3 +539,56 @@ def fq12expu64_trace(ios):
     L.orc_fq12expu64_generate_trace.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     L.orc_fq12expu64_generate_trace(ptr(ios), num_io, ptr(trace), ptr(pi))
     return trace, pi
+
+
+# ---- the reference's single-operation test tables: ModularStark (src/modular/modular.rs:361-537), Fq12Stark (src/fields/fq12/mul.rs:355-517)
+AIR_MODULAR = 7
+AIR_FQ12_MUL = 8
+
+
+def modular_inputs(rows, seed):
+    """Mirror of modular.rs:389-391 with seeded randomness: two random Fq per row."""
+    rng = np.random.default_rng(seed)
+    ops = np.zeros((rows, 16), dtype=np.uint32)
+    native = []
+    for r in range(rows):
+        a = int.from_bytes(rng.bytes(32), "little") % BN_P
+        b = int.from_bytes(rng.bytes(32), "little") % BN_P
+        ops[r, 0:8] = u32_limbs(a); ops[r, 8:16] = u32_limbs(b)
+        native.append((a, b))
+    return ops, native
+
+
+def modular_trace(ops):
+    rows = ops.shape[0]
+    L = lib()
+    trace = np.zeros((L.orc_air_num_columns(AIR_MODULAR, 0), rows), dtype=np.uint64)
+    ops = np.ascontiguousarray(ops, dtype=np.uint32)
+    L.orc_modular_generate_trace.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+    L.orc_modular_generate_trace(ptr(ops), rows, ptr(trace))
+    return trace
+
+
+def fq12mul_inputs(rows, seed):
+    """Mirror of fq12/mul.rs:378-380 with seeded randomness: two random Fq12 per row (12 coefficients each, flat basis)."""
+    rng = np.random.default_rng(seed)
+    ops = np.zeros((rows, 192), dtype=np.uint32)
+    native = []
+    for r in range(rows):
+        x = [int.from_bytes(rng.bytes(32), "little") % BN_P for _ in range(12)]
+        y = [int.from_bytes(rng.bytes(32), "little") % BN_P for _ in range(12)]
+        for c in range(12):
+            ops[r, 8 * c:8 * c + 8] = u32_limbs(x[c])
+            ops[r, 96 + 8 * c:96 + 8 * c + 8] = u32_limbs(y[c])
+        native.append((x, y))
+    return ops, native
+
+
+def fq12mul_trace(ops):
+    rows = ops.shape[0]
+    L = lib()
+    trace = np.zeros((L.orc_air_num_columns(AIR_FQ12_MUL, 0), rows), dtype=np.uint64)
+    ops = np.ascontiguousarray(ops, dtype=np.uint32)
+    L.orc_fq12mul_generate_trace.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+    L.orc_fq12mul_generate_trace(ptr(ops), rows, ptr(trace))
+    return trace

@@ -80,6 +80,32 @@ def test_g1stark_proof_bit_exact(gpu, O, golden, rows, seed):
     assert proof.recover_degree_bits(cfg) == rows.bit_length() - 1
 
 
+@pytest.mark.parametrize("table,rows,seed", [("ModularStark", 512, 6), ("ModularStark", 2048, 26), ("Fq12Stark", 512, 7)])
+def test_single_operation_tables_proof_bit_exact(gpu, O, golden, table, rows, seed):
+    """The reference's test tables for the modular gadget and the Fq12 product (test_modular_stark, modular.rs:540-560;
+    test_fq12_mul, fq12/mul.rs): GPU proof bytes == oracle proof bytes == committed digest, both verifiers accept."""
+    stark = getattr(gpu, table)()
+    kind, inputs = {"ModularStark": (O.AIR_MODULAR, O.modular_inputs), "Fq12Stark": (O.AIR_FQ12_MUL, O.fq12mul_inputs)}[table]
+    ops, _ = inputs(rows, seed)
+    trace = stark.generate_trace(ops)
+    cfg = stark.config()
+    proof = gpu.prove(stark, cfg, trace, np.zeros(0, dtype=np.uint64))
+    ref, _ = O.prove(kind, 0, trace, np.zeros(0, dtype=np.uint64))
+    assert np.array_equal(proof.words, ref)
+    if rows == 512:
+        g = golden["proof_digests"][f"{'modular' if table == 'ModularStark' else 'fq12mul'}_rows512_seed{seed}"]
+        assert hashlib.sha256(proof.to_bytes()).hexdigest() == g["proof_sha256"]
+    assert O.verify(kind, 0, proof.words) == (0, "")
+    gpu.verify_stark_proof(stark, proof, cfg)
+    assert proof.recover_degree_bits(cfg) == rows.bit_length() - 1
+    # an invalid witness (one output limb off by one) still yields a proof, which both verifiers reject
+    bad = trace.copy(); bad[40 if table == "ModularStark" else 400, 3] ^= 1
+    p2 = gpu.prove(stark, cfg, bad, np.zeros(0, dtype=np.uint64))
+    assert O.verify(kind, 0, p2.words)[0] != 0
+    with pytest.raises(gpu.SbnError):
+        gpu.verify_stark_proof(stark, p2, cfg)
+
+
 def test_g1stark_proof_without_the_times_x_step(gpu, O):
     """sbn_config.fri_final_poly_times_x = 0 (later upstream plonky2: no multiply-by-X of the FRI final polynomial):
     GPU proof bytes == the oracle's in the same mode, and differ from the default mode's."""

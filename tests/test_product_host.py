@@ -59,6 +59,51 @@ def test_tracegen_g1op_matches_oracle(S, O):
         assert np.array_equal(S.G1Stark().generate_trace(pts), O.g1op_trace(pts))
 
 
+@pytest.mark.parametrize("table,rows,seed", [("ModularStark", 512, 6), ("ModularStark", 1024, 16), ("Fq12Stark", 512, 7)])
+def test_single_operation_tables_shape_tracegen_and_products(S, O, golden, table, rows, seed):
+    """The reference's own test tables for the modular gadget and the Fq12 product (test_modular_stark modular.rs:540-560,
+    test_fq12_mul fq12/mul.rs): column counts, host generator == the oracle's independent generator word for word, outputs
+    == the products computed with Python integers (the reference asserts the same against arkworks, modular.rs:405-406,
+    mul.rs:388-389), the product verifier accepts the oracle's proof."""
+    stark = getattr(S, table)()
+    kind, inputs, gen = {"ModularStark": (O.AIR_MODULAR, O.modular_inputs, O.modular_trace), "Fq12Stark": (O.AIR_FQ12_MUL, O.fq12mul_inputs, O.fq12mul_trace)}[table]
+    L = O.lib()
+    assert stark.num_columns == L.orc_air_num_columns(kind, 0) == {"ModularStark": 812, "Fq12Stark": 9722}[table]   # modular.rs:368, mul.rs:360
+    assert stark.num_permutation_zs() == L.orc_air_num_permutation_zs(kind, 0) == {"ModularStark": 444, "Fq12Stark": 5328}[table]
+    assert stark.num_public_inputs == 0 and stark.constraint_degree() == 3
+    ops, native = inputs(rows, seed)
+    trace = stark.generate_trace(ops)
+    ref = gen(ops)
+    assert np.array_equal(trace, ref)
+    if rows == 512:
+        g = golden["proof_digests"][f"{'modular' if table == 'ModularStark' else 'fq12mul'}_rows512_seed{seed}"]
+        assert hashlib.sha256(trace.tobytes()).hexdigest() == g["trace_sha256"]
+    limbs = lambda col0, r: sum(int(trace[col0 + i, r]) << (16 * i) for i in range(16))
+    for r in (0, 1, rows // 2, rows - 1):
+        if table == "ModularStark":
+            a, b = native[r]
+            assert limbs(0, r) == a and limbs(16, r) == b and limbs(32, r) == a * b % O.BN_P
+        else:
+            x, y = native[r]
+            assert [limbs(384 + 16 * c, r) for c in range(12)] == O.fq12_mul(x, y)
+    # every range-checked column holds 16-bit limbs; signs are +-1; the filter is 1
+    main = {"ModularStark": 145, "Fq12Stark": 1729}[table]
+    assert trace[main - 1].min() == 1 and trace[main - 1].max() == 1
+    if rows == 512:
+        w, _ = O.prove(kind, 0, ref, np.zeros(0, dtype=np.uint64))
+        assert hashlib.sha256(w.astype("<u8").tobytes()).hexdigest() == g["proof_sha256"]
+        S.verify_stark_proof(stark, S.Proof(w, 9), stark.config())
+        t = w.copy(); t[len(t) // 2] ^= 1
+        with pytest.raises(S.SbnError):
+            S.verify_stark_proof(stark, S.Proof(t, 9), stark.config())
+    # argument errors of the generators: a non-power-of-two height, an operand >= p
+    with pytest.raises(S.SbnError):
+        stark.generate_trace(ops[:300])
+    bad = ops.copy(); bad[5, 0:8] = 0xFFFFFFFF
+    with pytest.raises(S.SbnError):
+        stark.generate_trace(bad)
+
+
 def test_tracegen_g1exp_matches_oracle_and_golden(S, g1exp_case, golden):
     tr, pi = S.G1ExpStark(128).generate_trace_and_public_inputs(g1exp_case["ios"])
     assert np.array_equal(pi, g1exp_case["pi"])
@@ -306,7 +351,7 @@ def test_rust_shim_declarations_match_the_header():
 
 
 @pytest.mark.parametrize("table,num_io", [("G1Stark", 0), ("G1ExpStark", 128), ("G2ExpStark", 128), ("Fq12ExpStark", 16), ("FqExpStark", 128),
-                                           ("Fq12ExpU64Stark", 16)])
+                                           ("Fq12ExpU64Stark", 16), ("ModularStark", 0), ("Fq12Stark", 0)])
 def test_regrouped_constraints_equal_the_oracle_on_random_rows(S, O, table, num_io):
     """air.cuh folds the constraints in regrouped form (local Horner sums, shared and factored limb convolutions, collapsed
     public-input block); the result must be the SAME field element as folding them one by one in the reference's order
@@ -314,7 +359,7 @@ def test_regrouped_constraints_equal_the_oracle_on_random_rows(S, O, table, num_
     elements in every column, random public inputs, random challenges and selector values, several row pairs."""
     stark = getattr(S, table)(num_io) if num_io else getattr(S, table)()
     kind = {"G1Stark": O.AIR_G1_OP, "G1ExpStark": O.AIR_G1_EXP, "G2ExpStark": O.AIR_G2_EXP, "Fq12ExpStark": O.AIR_FQ12_EXP, "FqExpStark": O.AIR_FQ_EXP,
-            "Fq12ExpU64Stark": O.AIR_FQ12_EXP_U64}[table]
+            "Fq12ExpU64Stark": O.AIR_FQ12_EXP_U64, "ModularStark": O.AIR_MODULAR, "Fq12Stark": O.AIR_FQ12_MUL}[table]
     rng = np.random.default_rng(hash(table) % 1000 + 17)
     ncol, npi = stark.num_columns, stark.num_public_inputs
     for trial in range(3):
