@@ -5,6 +5,8 @@ import ctypes as C
 import hashlib
 import os
 import re
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -51,6 +53,13 @@ def test_host_transcript_permutation(S, O, golden):
     with pytest.raises(S.SbnError) as e:
         S.poseidon_permute_host(np.full((1, 12), P, dtype=np.uint64))
     assert e.value.code == -2
+    # the scalar full rounds (CPUs without AVX-512) in a fresh process, where SBN_NO_AVX512 is read
+    code = ("import numpy as np, starky_bn254_amd as S; st = np.random.default_rng(11).integers(0, 0xFFFFFFFF00000001, size=(64, 12), dtype=np.uint64); "
+            "a = S.poseidon_permute_host(st); b = S.poseidon_permute_host(st, use_definition=True); assert np.array_equal(a, b); print(int(a[5, 3]))")
+    env = dict(os.environ, SBN_NO_AVX512="1", PYTHONPATH=ROOT)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert int(out.stdout.strip()) == int(S.poseidon_permute_host(st[:64])[5, 3])
 
 
 def test_tracegen_g1op_matches_oracle(S, O):
