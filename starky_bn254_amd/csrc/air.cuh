@@ -861,26 +861,29 @@ GL_HD void exp_eval(Cons<P>& cs, const Row& row, const ExpShape& sh, const ExpPi
 // starky permutation.rs `eval_permutation_checks` for singleton pairs with batch size 2:
 // Z index z <-> pair z; instance 0 uses challenge_sets[0].challenges[0].gamma, instance 1 uses
 // challenge_sets[1].challenges[1].gamma.  ZRow: zl(z) / zn(z) = local / next Z values.
-// `first_row` selects the num_zs first-row constraints, [z0, z1) the range of transition constraints: the whole stream is
-// (true, 0, num_zs); the quotient kernel splits it over two workgroups.
+// The block is num_zs first-row constraints l_first (Z_z - 1), then num_zs transitions.  The consumer is a dot product with
+// powers of alpha, so BOTH constraints of a Z column are emitted where its local value is loaded once: exponent
+// base + 2 num_zs - 1 - z for the first-row constraint and base + num_zs - 1 - z for the transition, base = the constraints
+// that follow the block (cs.rem on entry counts the block too).  [z0, z1) selects the Z columns of this call: the whole
+// block is (0, num_zs); the quotient kernel splits it over two workgroups, which read disjoint halves of the Z matrix
+// (the first-row constraints used to cost one of them a second pass over all of it: 0.8 GB of the 5.1 GB of the stage).
 template <class P, class Row, class ZRow, class Shape>
-GL_HD void permutation_checks(Cons<P>& cs, const Row& row, const ZRow& zrow, const Shape& sh, int num_zs, P gamma0, P gamma1, bool first_row = true,
-                              int z0 = 0, int z1 = -1) {
+GL_HD void permutation_checks(Cons<P>& cs, const Row& row, const ZRow& zrow, const Shape& sh, int num_zs, P gamma0, P gamma1, int z0 = 0, int z1 = -1) {
   const P one = lift<P>(1);
   if (z1 < 0) z1 = num_zs;
-  if (first_row) {
-    Horner2<P> h(num_zs);
-#pragma unroll 8
-    for (int z = 0; z < num_zs; z++) h.push(cs, zrow.zl(z) - one);
-    P hv[SBN_NCH];
-    h.value(hv);
-    cs.merge(hv, cs.l_first, num_zs);
-  }
+  const int base = cs.rem - 2 * num_zs;
 #pragma unroll 4
   for (int z = z0; z < z1; z++) {
     int lc, rc;
     sh.pair(z, lc, rc);
-    P l = row.l(lc), r = row.l(rc);
-    cs.c(zrow.zn(z) * ((r + gamma0) * (r + gamma1)) - zrow.zl(z) * ((l + gamma0) * (l + gamma1)));
+    const P l = row.l(lc), r = row.l(rc), zl = zrow.zl(z);
+    const P t = zrow.zn(z) * ((r + gamma0) * (r + gamma1)) - zl * ((l + gamma0) * (l + gamma1));
+    const P f = (zl - one) * cs.l_first;   // (one multiply more than a separate first-row sum, but no second pair of accumulators: the kernel must stay at 64 registers)
+#pragma unroll
+    for (int j = 0; j < SBN_NCH; j++) {
+      cs.a[j].mac(f, cs.apow[j][base + 2 * num_zs - 1 - z]);
+      cs.a[j].mac(t, cs.apow[j][base + num_zs - 1 - z]);
+    }
   }
+  if (z0 == 0 && z1 == num_zs) cs.rem = base;
 }

@@ -660,12 +660,12 @@ struct QuotientParams {
   u64* part;        // [QSEG segments][SBN_NCH][m] partial accumulators
   u64 seg_shift[4][SBN_NCH];  // alpha_j^(number of constraints that follow the segment)
   int seg_count[4];           // constraints of each segment (its first one is weighted alpha^(count-1) inside the segment)
-  int zsplit;       // permutation transition constraints [0, zsplit) go with segment 2, [zsplit, num_zs) with segment 3
+  int zsplit;       // both permutation constraints of the Z columns [0, zsplit) go with segment 2, those of [zsplit, num_zs) with segment 3
 };
 
 // The constraint stream is one Horner sum in alpha, so it splits exactly into four segments: 0 = AIR sections [1]-[8]
 // (public inputs, transitions, flags, the add / double gadget), 1 = AIR sections [9]-[10] (io pulses, range check),
-// 2 = the permutation checks' first-row constraints and the first part of their transitions, 3 = the rest;
+// 2 / 3 = the permutation checks of the first / second half of the Z columns (first-row constraint and transition of a column together);
 // quotient_combine_kernel joins them as sum_s acc_s * alpha^(constraints after segment s).  With one lane per LDE point
 // there are only two waves per SIMD at 2^17 points and one long dependent chain per lane (2.65 ms); four segments in
 // flight give eight waves and quarter the chain (1.56 ms).  Each PART is its own kernel (0: segment 0, 1: segment 1,
@@ -702,22 +702,22 @@ __global__ __launch_bounds__(256, 2) void quotient_kernel(QuotientParams p, cons
   if (KIND == 1) {
     if (PART == 0) g1op_eval(cs, row);
     else if (PART == 2) {
-      if (seg == 2) permutation_checks(cs, row, zrow, G1OpShape(), p.num_zs, F(p.gamma0), F(p.gamma1), true, 0, p.zsplit);
-      else permutation_checks(cs, row, zrow, G1OpShape(), p.num_zs, F(p.gamma0), F(p.gamma1), false, p.zsplit, p.num_zs);
+      if (seg == 2) permutation_checks(cs, row, zrow, G1OpShape(), p.num_zs, F(p.gamma0), F(p.gamma1), 0, p.zsplit);
+      else permutation_checks(cs, row, zrow, G1OpShape(), p.num_zs, F(p.gamma0), F(p.gamma1), p.zsplit, p.num_zs);
     }
   } else if (KIND == 7 || KIND == 8) {   // ModularStark / Fq12Stark: everything but the permutation checks is the head segment
     const OpShape sh(KIND);
     if (PART == 0) op_eval<KIND>(cs, row, sh);
     else if (PART == 2) {
-      if (seg == 2) permutation_checks(cs, row, zrow, sh, p.num_zs, F(p.gamma0), F(p.gamma1), true, 0, p.zsplit);
-      else permutation_checks(cs, row, zrow, sh, p.num_zs, F(p.gamma0), F(p.gamma1), false, p.zsplit, p.num_zs);
+      if (seg == 2) permutation_checks(cs, row, zrow, sh, p.num_zs, F(p.gamma0), F(p.gamma1), 0, p.zsplit);
+      else permutation_checks(cs, row, zrow, sh, p.num_zs, F(p.gamma0), F(p.gamma1), p.zsplit, p.num_zs);
     }
   } else {
     constexpr int E = KIND == 4 ? 12 : (KIND == 6 ? 13 : (KIND == 3 ? 2 : (KIND == 5 ? 0 : 1)));
     ExpShape sh(E, p.num_io);
     if (PART < 2) exp_eval<E>(cs, row, sh, (const ExpPiConsts<F>*)pic_arg, 1 + PART);
-    else if (seg == 2) permutation_checks(cs, row, zrow, sh, p.num_zs, F(p.gamma0), F(p.gamma1), true, 0, p.zsplit);
-    else permutation_checks(cs, row, zrow, sh, p.num_zs, F(p.gamma0), F(p.gamma1), false, p.zsplit, p.num_zs);
+    else if (seg == 2) permutation_checks(cs, row, zrow, sh, p.num_zs, F(p.gamma0), F(p.gamma1), 0, p.zsplit);
+    else permutation_checks(cs, row, zrow, sh, p.num_zs, F(p.gamma0), F(p.gamma1), p.zsplit, p.num_zs);
   }
 #pragma unroll
   for (int j = 0; j < SBN_NCH; j++) p.part[((size_t)seg * SBN_NCH + j) * p.m + i] = cs.result(j).v;
