@@ -10,7 +10,7 @@
 //   * affine_kernel / lambda_kernel then invert all Z's and all slope denominators at once (the inversions of different
 //     rows are independent once the chain is known): a lane owns eight values and inverts their product (Montgomery's
 //     trick; Fermat, a^(p-2), for the one inversion left);
-//   * row_witness_kernel computes limb columns and the three modular-gadget witnesses of a row (one lane per row);
+//   * gadget_witness_kernel computes the limb columns and the modular-gadget witnesses, one lane per (row, gadget);
 //   * flags / pulse columns are closed forms of the row index;
 //   * range_check_kernel: one workgroup per range-checked column, histogram and prefix counts in LDS, and the
 //     reference's sorted-merge with its LIFO pool of unused table values (src/utils/lookup.rs:60-111) restated as
@@ -185,30 +185,86 @@ __global__ void lambda_kernel(const uint32_t* __restrict__ ios, size_t K, const 
   }
 }
 
-// One lane per row: limb columns of a and b (columns 0..64E-1) and the 320E gadget columns at gadget_col.
+// One lane per (row, modular gadget): lane (row, g), g = blk * E + q, computes gadget blk (0: the zero polynomial of the
+// slope, 1: new_x, 2: new_y; generate_g1_add / _double muladd.rs:124-177, 409-460 and their G2 twins) for the Fq2 component
+// q -- its limb convolutions (component q of an Fq2 product is two 16 x 16 convolutions), its modular witness -- and writes
+// that gadget's columns; the blk 0 lanes also write the limb columns of lambda / new_x / new_y, the blk 1 / 2 lanes those of
+// a / b.  Lanes of a wave share g (lane index = g * n + row), so they neither diverge nor scatter their stores.
+// Round 1 had one lane per ROW with all three (six) gadgets: 7.4 KB (13.5 KB) of scratch arrays per lane, 3,458 spilled
+// registers, 1.98 GB of traffic for a 0.88 GB trace.
 template <int E>
-__global__ void __launch_bounds__(128) row_witness_kernel(const u64* __restrict__ sv, const unsigned char* __restrict__ row_op, size_t n, int gadget_col,
-                                                          u64* __restrict__ trace, int* __restrict__ err) {
-  const size_t row = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  if (row >= n) return;
-  u64 s[7][4 * E];
+__device__ __forceinline__ void prod_comp(const int64_t (*X)[16], const int64_t (*Y)[16], int q, int64_t* out) {
+  if (E == 1) { conv16(X[0], Y[0], out); return; }
+  int64_t t[31];   // Fq2 limb product (src/fields/fq2.rs:41-58): c0 = x0*y0 - x1*y1, c1 = x0*y1 + x1*y0
+  if (q == 0) { conv16(X[0], Y[0], out); conv16(X[E - 1], Y[E - 1], t); for (int k = 0; k < 31; k++) out[k] -= t[k]; }
+  else { conv16(X[0], Y[E - 1], out); conv16(X[E - 1], Y[0], t); for (int k = 0; k < 31; k++) out[k] += t[k]; }
+}
+template <int E>
+__global__ void __launch_bounds__(256) gadget_witness_kernel(const u64* __restrict__ sv, const unsigned char* __restrict__ row_op, size_t n, int gadget_col,
+                                                             u64* __restrict__ trace, int* __restrict__ err) {
+  const size_t tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (tid >= 3 * E * n) return;
+  const size_t row = tid % n;
+  const int g = (int)(tid / n), blk = g / E, q = g % E;
   const int op = row_op[row];
-  for (int w = 0; w < (op ? 7 : 4); w++) for (int i = 0; i < 4 * E; i++) s[w][i] = sv[(size_t)(w * 4 * E + i) * n + row];
-  for (int w = 0; w < 4; w++)
-    for (int q = 0; q < E; q++)
-      for (int i = 0; i < 16; i++) trace[(size_t)(16 * (w * E + q) + i) * n + row] = (s[w][4 * q + (i >> 2)] >> (16 * (i & 3))) & 0xffff;
-  u64* g = trace + (size_t)gadget_col * n + row;
-  constexpr int GW = 320 * E;
-  if (op) {
-    u64 lv[GW];
-    const bool ok = E == 1 ? g1_output_row(op == 2, s[0], s[1], s[2], s[3], s[4], s[5], s[6], lv)
-                           : g2_output_row(op == 2, s[0], s[1], s[2], s[3], s[4], s[5], s[6], lv);
-    if (!ok) { atomicOr(err, TG_ERR_WITNESS); return; }
-    for (int c = 0; c < GW; c++) g[(size_t)c * n] = lv[c];
-  } else {  // G1Output / G2Output::default: zeros, quotient signs = 1
-    for (int c = 0; c < GW - 3 * E; c++) g[(size_t)c * n] = 0;
-    for (int c = GW - 3 * E; c < GW; c++) g[(size_t)c * n] = 1;
+  // sv (lambda_kernel): value w in {ax ay bx by lam nx ny}, component c, 64-bit word i at ((w * E + c) * 4 + i) * n + row
+  auto ld = [&](int w, int c, u64* out4) { for (int i = 0; i < 4; i++) out4[i] = sv[(size_t)((w * E + c) * 4 + i) * n + row]; };
+  auto ldl = [&](int w, int c, int64_t* out16) { u64 t4[4]; ld(w, c, t4); limbs16(t4, out16); };
+  u64* gc = trace + (size_t)gadget_col * n + row;
+  auto putc = [&](int c, u64 v) { gc[(size_t)c * n] = v; };
+  if (blk >= 1)   // limb columns of a (blk 1: ax, ay) / b (blk 2: bx, by), component q: trace columns 16 (w E + q) ..
+    for (int c = 0; c < 2; c++) {
+      const int w = 2 * (blk - 1) + c;
+      u64 s4[4]; ld(w, q, s4);
+      for (int i = 0; i < 16; i++) trace[(size_t)(16 * (w * E + q) + i) * n + row] = (s4[i >> 2] >> (16 * (i & 3))) & 0xffff;
+    }
+  // G1Output / G2Output columns (muladd.rs:79-94, g2/muladd.rs:56-80): limbs of lambda, new_x, new_y (48 E), the zero gadgets
+  // (79 each), the x and y gadgets (95 each), 3 E quotient signs
+  const int base = blk == 0 ? 48 * E + 79 * q : (blk == 1 ? 127 * E + 95 * q : 222 * E + 95 * q), sgn = 317 * E + blk * E + q;
+  if (!op) {   // G1Output / G2Output::default: zeros, quotient signs = 1
+    if (blk == 0) for (int i = 0; i < 16; i++) { putc(16 * q + i, 0); putc(16 * E + 16 * q + i, 0); putc(32 * E + 16 * q + i, 0); }
+    for (int c = 0; c < (blk ? 95 : 79); c++) putc(base + c, 0);
+    putc(sgn, 1);
+    return;
   }
+  const bool dbl = op == 2;
+  int64_t l[E][16], X[E][16], Y[E][16], pol[31], v16[16];
+  u64 outv[4] = {0, 0, 0, 0};
+  for (int c = 0; c < E; c++) ldl(4, c, l[c]);
+  if (blk == 0) {
+    for (int i = 0; i < 16; i++) putc(16 * q + i, (u64)l[q][i]);
+    ldl(5, q, v16); for (int i = 0; i < 16; i++) putc(16 * E + 16 * q + i, (u64)v16[i]);
+    ldl(6, q, v16); for (int i = 0; i < 16; i++) putc(32 * E + 16 * q + i, (u64)v16[i]);
+    if (dbl) {   // 2 lambda y - 3 x^2
+      int64_t t2[31];
+      for (int c = 0; c < E; c++) { ldl(1, c, Y[c]); ldl(0, c, X[c]); }
+      prod_comp<E>(l, Y, q, pol); prod_comp<E>(X, X, q, t2);
+      for (int k = 0; k < 31; k++) pol[k] = 2 * pol[k] - 3 * t2[k];
+    } else {     // lambda (x2 - x1) - (y2 - y1)
+      for (int c = 0; c < E; c++) { ldl(2, c, X[c]); ldl(0, c, Y[c]); for (int i = 0; i < 16; i++) X[c][i] -= Y[c][i]; }
+      prod_comp<E>(l, X, q, pol);
+      ldl(3, q, v16); for (int i = 0; i < 16; i++) pol[i] -= v16[i];
+      ldl(1, q, v16); for (int i = 0; i < 16; i++) pol[i] += v16[i];
+    }
+  } else if (blk == 1) {   // lambda^2 - x1 - x2
+    prod_comp<E>(l, l, q, pol);
+    ldl(0, q, v16); for (int i = 0; i < 16; i++) pol[i] -= v16[i];
+    ldl(dbl ? 0 : 2, q, v16); for (int i = 0; i < 16; i++) pol[i] -= v16[i];
+    ld(5, q, outv);
+  } else {                 // lambda (x1 - new_x) - y1
+    for (int c = 0; c < E; c++) { ldl(0, c, X[c]); ldl(5, c, Y[c]); for (int i = 0; i < 16; i++) X[c][i] -= Y[c][i]; }
+    prod_comp<E>(l, X, q, pol);
+    ldl(1, q, v16); for (int i = 0; i < 16; i++) pol[i] -= v16[i];
+    ld(6, q, outv);
+  }
+  ModW w;
+  if (!mod_witness(pol, outv, blk > 0, w)) { atomicOr(err, TG_ERR_WITNESS); return; }
+  int cur = base;
+  if (blk) for (int i = 0; i < 16; i++) putc(cur++, (u64)w.out_aux_red[i]);
+  for (int i = 0; i < 17; i++) putc(cur++, (u64)w.quot_abs[i]);
+  for (int i = 0; i < 31; i++) putc(cur++, (u64)w.aux_lo[i]);
+  for (int i = 0; i < 31; i++) putc(cur++, (u64)w.aux_hi[i]);
+  putc(sgn, w.sign > 0 ? (u64)1 : GLP - 1);
 }
 
 // flags columns (flags.rs:46-134) in closed form: within the 64-row block q of an instance the u32 limb e[q] is

@@ -685,7 +685,7 @@ static int generate_trace_device(sbn_prover* P, const uint32_t* ios, size_t K, u
   mark();
   hipLaunchKernelGGL(tg::lambda_kernel<E>, blocks((n + tg::TG_INV_BATCH - 1) / tg::TG_INV_BATCH, 64), dim3(64), 0, st, d_ios, K, aa, ab, n, sv, row_op, d_out, d_err);
   mark();
-  hipLaunchKernelGGL(tg::row_witness_kernel<E>, blocks(n, 128), dim3(128), 0, st, sv, row_op, n, sh.gadget_col, P->d_trace, d_err);
+  hipLaunchKernelGGL(tg::gadget_witness_kernel<E>, blocks(3 * E * n, 256), dim3(256), 0, st, sv, row_op, n, sh.gadget_col, P->d_trace, d_err);
   mark();
   if (n > 65536) {   // multiplicities beyond u16: histogram of every target column in HBM first (kernels_tracegen.cuh)
     HIPC(hipMemsetAsync(d_cnt, 0, (size_t)sh.num_rc * 65536 * sizeof(unsigned int), st));
