@@ -109,7 +109,7 @@ struct sbn_prover {
   u64* h_chain = nullptr;                    // pinned staging for the host-computed curve chains (device tracegen)
   size_t h_chain_words = 0;
   u64* h_open = nullptr;                     // pinned landing buffer of the opened values [(ncols + nzs + 4)][4]
-  u64* h_open2 = nullptr;                    // second landing buffer of the trace rows (their values at g*zeta arrive last)
+  u64* h_open2 = nullptr;                    // second landing buffer: the values at g*zeta of the trace and Z columns (the host is still reading the first)
 };
 
 static int dmalloc(u64** p, size_t words) {
@@ -487,7 +487,7 @@ static int create_ctx(const sbn_air_desc* air, const sbn_config* cfg, uint32_t d
   acc(dmalloc(&P->d_apow, (size_t)SBN_NCH * P->apow_n));
   acc(dmalloc(&P->d_zpow, 4 * n)); acc(dmalloc(&P->d_open, (C + Z + 4) * 4));
   hipc(hipHostMalloc((void**)&P->h_open, (C + Z + 4) * 4 * sizeof(u64), hipHostMallocDefault), "hipHostMalloc");
-  hipc(hipHostMalloc((void**)&P->h_open2, C * 4 * sizeof(u64), hipHostMallocDefault), "hipHostMalloc");
+  hipc(hipHostMalloc((void**)&P->h_open2, (C + Z) * 4 * sizeof(u64), hipHostMallocDefault), "hipHostMalloc");
   acc(dmalloc(&P->d_part, 2 * 32 * n)); acc(dmalloc(&P->d_w, 4096)); acc(dmalloc(&P->d_sponge, 12 * m));
   acc(dmalloc(&P->d_fa, 4 * n)); acc(dmalloc(&P->d_fcoef, 2 * m)); acc(dmalloc(&P->d_fcoef2, 2 * m));
   acc(dmalloc(&P->d_pow, 1));
@@ -1107,7 +1107,6 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
     for (size_t p = 0; p < C + Z; p++) { ch.observe(F(open[4 * p + 2])); ch.observe(F(open[4 * p + 3])); }
   } else {
     const bool u4 = n % 1024 == 0;
-    auto open_k = u4 ? openings_kernel<4> : openings_kernel<1>;
     auto open1_k = u4 ? openings1_kernel<4> : openings1_kernel<1>;
     const u64 *zp0 = P->d_zpow, *zp1 = P->d_zpow + n, *zp2 = P->d_zpow + 2 * n, *zp3 = P->d_zpow + 3 * n;
     // The host hashes ~3 columns per microsecond, the device evaluates ~5: the trace columns at zeta go out in slices that
@@ -1121,13 +1120,25 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
       }
       HIPC(hipEventRecord(P->chunk_ready[8 + k], st));  // (the commit pipeline's chunk events are idle here)
     }
-    hipLaunchKernelGGL(open_k, dim3((unsigned)Z), dim3(256), 0, st, P->d_zcoef, n, zp0, zp1, zp2, zp3, P->d_open + C * 4);
-    hipLaunchKernelGGL(open_k, dim3(4), dim3(256), 0, st, P->d_q, n, zp0, zp1, zp2, zp3, P->d_open + (C + Z) * 4);
+    // Z and quotient at zeta, then everything at g*zeta, again in slices: the host (0.86 us per permutation, 4 columns each)
+    // is the slower side, and it must never find the next values missing -- with the trace at g*zeta evaluated last in one
+    // kernel it idled 0.3 ms before it.
+    hipLaunchKernelGGL(open1_k, dim3((unsigned)Z), dim3(256), 0, st, P->d_zcoef, n, zp0, zp1, P->d_open + C * 4, 0u);
+    hipLaunchKernelGGL(open1_k, dim3(4), dim3(256), 0, st, P->d_q, n, zp0, zp1, P->d_open + (C + Z) * 4, 0u);
     HIPC(hipMemcpyAsync(P->h_open + C * 4, P->d_open + C * 4, (Z + 4) * 4 * sizeof(u64), hipMemcpyDeviceToHost, st));
     HIPC(hipEventRecord(P->chunk_ready[1], st));
-    hipLaunchKernelGGL(open1_k, dim3((unsigned)C), dim3(256), 0, st, P->d_coef, n, zp2, zp3, P->d_open, 2u);
+    size_t sn[5] = {0, C / 4, C / 2, C / 2 + C / 4, C};
+    for (int k = 0; k < 4; k++) {
+      const size_t a = sn[k], cnt = sn[k + 1] - sn[k];
+      if (cnt) {
+        hipLaunchKernelGGL(open1_k, dim3((unsigned)cnt), dim3(256), 0, st, P->d_coef + a * n, n, zp2, zp3, P->d_open + a * 4, 2u);
+        HIPC(hipMemcpyAsync(P->h_open2 + a * 4, P->d_open + a * 4, cnt * 4 * sizeof(u64), hipMemcpyDeviceToHost, st));
+      }
+      HIPC(hipEventRecord(P->chunk_ready[12 + k], st));
+    }
+    hipLaunchKernelGGL(open1_k, dim3((unsigned)Z), dim3(256), 0, st, P->d_zcoef, n, zp2, zp3, P->d_open + C * 4, 2u);
     HIPC(hipGetLastError());
-    HIPC(hipMemcpyAsync(P->h_open2, P->d_open, C * 4 * sizeof(u64), hipMemcpyDeviceToHost, st));   // a second buffer: the host is reading the first
+    HIPC(hipMemcpyAsync(P->h_open2 + C * 4, P->d_open + C * 4, Z * 4 * sizeof(u64), hipMemcpyDeviceToHost, st));
     HIPC(hipEventRecord(P->ev[ST_FRI_COMBINE], st));
     // observe_openings: batch zeta = local ++ perm_zs ++ quotient ; batch g*zeta = next ++ perm_zs_next
     for (int k = 0; k < 4; k++) {
@@ -1136,10 +1147,12 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
     }
     HIPC(event_wait(P->chunk_ready[1]));
     for (size_t p = C; p < C + Z + 4; p++) { ch.observe(F(open[4 * p])); ch.observe(F(open[4 * p + 1])); }
+    for (int k = 0; k < 4; k++) {
+      HIPC(event_wait(P->chunk_ready[12 + k]));
+      for (size_t p = sn[k]; p < sn[k + 1]; p++) { ch.observe(F(open2[4 * p + 2])); ch.observe(F(open2[4 * p + 3])); }
+    }
     HIPC(stream_wait(st));
-    for (size_t p = 0; p < C; p++) { ch.observe(F(open2[4 * p + 2])); ch.observe(F(open2[4 * p + 3])); }
-    for (size_t p = C; p < C + Z; p++) { ch.observe(F(open[4 * p + 2])); ch.observe(F(open[4 * p + 3])); }
-
+    for (size_t p = C; p < C + Z; p++) { ch.observe(F(open2[4 * p + 2])); ch.observe(F(open2[4 * p + 3])); }
   }
 
   // P5 FRI ------------------------------------------------------------------------------------------
@@ -1347,7 +1360,7 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
   for (size_t p = 0; p < C; p++) { w.push_back(open[4 * p]); w.push_back(open[4 * p + 1]); }          // local_values
   for (size_t p = 0; p < C; p++) { w.push_back(open2[4 * p + 2]); w.push_back(open2[4 * p + 3]); }    // next_values
   for (size_t p = C; p < C + Z; p++) { w.push_back(open[4 * p]); w.push_back(open[4 * p + 1]); }      // permutation_zs
-  for (size_t p = C; p < C + Z; p++) { w.push_back(open[4 * p + 2]); w.push_back(open[4 * p + 3]); }  // permutation_zs_next
+  for (size_t p = C; p < C + Z; p++) { w.push_back(open2[4 * p + 2]); w.push_back(open2[4 * p + 3]); }  // permutation_zs_next
   for (size_t p = C + Z; p < C + Z + 4; p++) { w.push_back(open[4 * p]); w.push_back(open[4 * p + 1]); }  // quotient_polys
   for (auto& cap : fri_caps) w.insert(w.end(), cap.begin(), cap.end());
   w.insert(w.end(), qwords.begin(), qwords.end());
