@@ -191,6 +191,29 @@ def test_g1exp_more_seeds_full_oracle_proof_equality(gpu, O, seed):
     gpu.verify_stark_proof(stark, got, cfg)
 
 
+@pytest.mark.parametrize("table,num_io,seed", [("g2", 128, 22), ("fq12", 16, 23), ("fq", 128, 24)])
+def test_other_exp_tables_second_seed_full_oracle_proof_equality(gpu, O, table, num_io, seed):
+    """A second seed (beside the committed digests) for G2ExpStark(128), Fq12ExpStark(16) and FqExpStark(128), the witness
+    generated on the device: public inputs and every proof word equal the CPU oracle's own prove() of its own trace."""
+    kind, inputs, gen, cls, bits = {
+        "g2": (O.AIR_G2_EXP, O.g2exp_inputs, O.g2exp_trace, gpu.G2ExpStark, 16),
+        "fq12": (O.AIR_FQ12_EXP, O.fq12exp_inputs, O.fq12exp_trace, gpu.Fq12ExpStark, 13),
+        "fq": (O.AIR_FQ_EXP, O.fqexp_inputs, O.fqexp_trace, gpu.FqExpStark, 16)}[table]
+    ios, _ = inputs(num_io, seed)
+    trace, pi = gen(ios)
+    stark = cls(num_io)
+    cfg = stark.config()
+    prover = gpu.Prover(stark, cfg, bits)
+    try:
+        assert np.array_equal(prover.generate_trace(ios), pi)
+        got = prover.prove()
+    finally:
+        prover.close()
+    want, _ = O.prove(kind, num_io, trace, pi)
+    assert np.array_equal(got.words, want)
+    gpu.verify_stark_proof(stark, got, cfg)
+
+
 def test_g1exp_device_witness_generation_matches_oracle(gpu, O, g1exp_case, g1exp_gpu_proof, golden):
     """G1ExpStark::generate_trace on the device (src/curves/g1/exp.rs:255-327): trace and public inputs equal the CPU
     oracle's word for word, and proving straight from the device-resident trace gives the same proof bytes."""
