@@ -292,6 +292,29 @@ def test_device_witness_above_2pow16_rows(gpu, O, table, num_io):
         prover.close()
 
 
+def test_g1exp_2pow17_rows_full_oracle_proof_equality(gpu, O):
+    """G1ExpStark(256): 2^17 rows, where the transforms take the 512 x 256 / 512 x 512 passes instead of 256 x 256 / 512 x 256
+    and the range-check table column ends in copies of 65535.  Device witness == the oracle's trace, and every proof word
+    == the oracle's prove() of it (about half a minute on the box)."""
+    ios, _ = O.g1exp_inputs(256, 31)
+    trace, pi = O.g1exp_trace(ios)
+    stark = gpu.G1ExpStark(256)
+    cfg = stark.config()
+    prover = gpu.Prover(stark, cfg, 17)
+    try:
+        assert np.array_equal(prover.generate_trace(ios), pi)
+        dev = prover.read_trace()
+        bad = np.nonzero((dev != trace).any(axis=1))[0]
+        assert bad.size == 0, f"first differing columns: {bad[:8].tolist()}"
+        del dev
+        got = prover.prove()
+    finally:
+        prover.close()
+    want, _ = O.prove(O.AIR_G1_EXP, 256, trace, pi)
+    assert np.array_equal(got.words, want)
+    assert O.verify(O.AIR_G1_EXP, 256, got.words) == (0, "")
+
+
 def test_prover_argument_errors(gpu, g1op_case):
     stark = gpu.G1Stark()
     cfg = stark.config()
