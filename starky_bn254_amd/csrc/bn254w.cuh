@@ -29,6 +29,42 @@ GL_HD u64 sub4(u64* r, const u64* a, const u64* b) {
   for (int i = 0; i < 4; i++) { u128 t = (u128)a[i] - b[i] - br; r[i] = (u64)t; br = (u64)(t >> 64) & 1; }
   return br;
 }
+#if defined(__HIP_DEVICE_COMPILE__)
+// The same Montgomery product (R = 2^256, canonical result) on eight 32-bit limbs: every inner step is one v_mad_u64_u32
+// (a_j b_i + t_j + carry never exceeds 2^64 - 1) plus the add that forms its 64-bit addend, fully unrolled, where the
+// 64-bit-limb form below compiles to ~700 instructions of emulated 128-bit arithmetic.  The device witness kernels wait for
+// ONE chain of ~350 dependent products (the Fermat inversion of a batch), so the length of a product is their latency.
+GL_HD Fq mmul(const Fq& a, const Fq& b) {   // (host-device only so that the host functions parsed in this pass resolve it)
+  constexpr u64 PL[4] = BNW_PL;
+  const uint32_t n0 = (uint32_t)BNW_N0INV;   // -p^-1 mod 2^32
+  uint32_t al[8], bl[8], pl[8], t[10];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    al[2 * i] = (uint32_t)a.l[i]; al[2 * i + 1] = (uint32_t)(a.l[i] >> 32);
+    bl[2 * i] = (uint32_t)b.l[i]; bl[2 * i + 1] = (uint32_t)(b.l[i] >> 32);
+    pl[2 * i] = (uint32_t)PL[i]; pl[2 * i + 1] = (uint32_t)(PL[i] >> 32);
+  }
+#pragma unroll
+  for (int i = 0; i < 10; i++) t[i] = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    u64 c = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) { const u64 cs = (u64)al[j] * bl[i] + ((u64)t[j] + c); t[j] = (uint32_t)cs; c = cs >> 32; }
+    u64 cs = (u64)t[8] + c; t[8] = (uint32_t)cs; t[9] = (uint32_t)(cs >> 32);
+    const uint32_t mq = t[0] * n0;
+    c = ((u64)mq * pl[0] + t[0]) >> 32;
+#pragma unroll
+    for (int j = 1; j < 8; j++) { cs = (u64)mq * pl[j] + ((u64)t[j] + c); t[j - 1] = (uint32_t)cs; c = cs >> 32; }
+    cs = (u64)t[8] + c; t[7] = (uint32_t)cs; t[8] = t[9] + (uint32_t)(cs >> 32);
+  }
+  Fq r;
+#pragma unroll
+  for (int i = 0; i < 4; i++) r.l[i] = (u64)t[2 * i] | ((u64)t[2 * i + 1] << 32);
+  if (t[8] || geq_p(r.l)) sub4(r.l, r.l, PL);
+  return r;
+}
+#else
 GL_HD Fq mmul(const Fq& a, const Fq& b) {
   constexpr u64 PL[4] = BNW_PL;
   const u64 n0 = BNW_N0INV;
@@ -46,6 +82,7 @@ GL_HD Fq mmul(const Fq& a, const Fq& b) {
   if (t[4] || geq_p(r.l)) sub4(r.l, r.l, PL);
   return r;
 }
+#endif
 GL_HD Fq to_m(const u64* x) { Fq a; for (int i = 0; i < 4; i++) a.l[i] = x[i]; Fq r2 = BNW_R2; return mmul(a, r2); }
 GL_HD void from_m(const Fq& a, u64* out) { Fq o = {{1, 0, 0, 0}}; Fq r = mmul(a, o); for (int i = 0; i < 4; i++) out[i] = r.l[i]; }
 GL_HD Fq fq_one() { Fq r = BNW_R1; return r; }
