@@ -83,19 +83,26 @@ typedef struct sbn_config {
   uint32_t fri_arity_bits;     /* 4   (FriReductionStrategy::ConstantArityBits(4, 5)) */
   uint32_t fri_final_poly_bits;/* 5   */
   uint32_t num_query_rounds;   /* 84  */
-  /* Not a StarkConfig field: which plonky2 FRI this library speaks.  1 (default) = the 0.1.x line the reference pins
-   * (plonky2 0.1.3 @ 541e127, Cargo.lock:529-531): fri/oracle.rs `prove_openings` multiplies the final polynomial by X
-   * (`final_poly.coeffs.insert(0, ZERO)`, mir-protocol/plonky2 PR #436) and fri/verifier.rs `fri_combine_initial` returns
-   * `sum * subgroup_x`.  0 = later upstream versions, which dropped the step (the quotients are zero-padded at the end).
-   * The dependency is un-vendored, so the default is recalled ([DEP-RECALL]); both forms are tested. */
-  uint32_t fri_final_poly_times_x;
+  /* Not a StarkConfig field: which plonky2 FRI this library speaks (sbn_fri_variant).  SBN_FRI_TIMES_X = the 0.1.x line
+   * the reference pins (plonky2 0.1.3 @ 541e127, Cargo.lock:529-531): fri/oracle.rs `prove_openings` multiplies the final
+   * polynomial by X (`final_poly.coeffs.insert(0, ZERO)`, mir-protocol/plonky2 PR #436) and fri/verifier.rs
+   * `fri_combine_initial` returns `sum * subgroup_x`.  SBN_FRI_PLAIN = later upstream versions, which dropped the step
+   * (the quotients are zero-padded at the end).  0 = SBN_FRI_DEFAULT (= SBN_FRI_TIMES_X), so a zero-initialised field
+   * selects the default and not the other protocol.  The dependency is un-vendored, so the default is recalled
+   * ([DEP-RECALL]); both forms are tested. */
+  uint32_t fri_variant;
 } sbn_config;
+typedef enum sbn_fri_variant { SBN_FRI_DEFAULT = 0, SBN_FRI_TIMES_X = 1, SBN_FRI_PLAIN = 2 } sbn_fri_variant;
 
 typedef struct sbn_prover sbn_prover; /* device context: buffers sized for one (air, degree_bits) */
 typedef struct sbn_proof sbn_proof;   /* host-side proof object (canonical words) */
 
 /* Library / device ------------------------------------------------------------------------------ */
 const char* sbn_version(void);
+/* Bumped whenever a struct or a function signature of this header changes (3: sbn_config.fri_variant replaces
+ * fri_final_poly_times_x, sbn_comm carries struct_size and stream-ordered callbacks).  Callers compare with SBN_ABI_VERSION. */
+#define SBN_ABI_VERSION 3
+int sbn_abi_version(void);
 const char* sbn_last_error(void);                    /* thread-local message of the last failure */
 int sbn_device_count(void);
 int sbn_set_device(int device);                      /* device used by subsequently created provers */
@@ -176,27 +183,36 @@ int sbn_batch_prover_prove_ios(sbn_batch_prover* b, const uint32_t* ios, size_t 
 void sbn_batch_prover_destroy(sbn_batch_prover* b);
 
 /* One oversized trace split over the GPUs of a node (BASELINE config "Single Fq12 exponentiation proof, trace height
- * 2^18, 8xMI355X with RCCL FRI fold"; reference workload src/fields/fq12/exp.rs:638-696).  One process per GPU; every
- * rank calls the same functions with the same arguments and receives the same proof.  Work and the derived matrices
- * (coefficients, LDE, Z, Merkle trees) are sharded: columns for iNTT / LDE / Z / openings / the FRI batch combination,
- * LDE ROWS for leaf hashing, Merkle subtrees, constraint evaluation and query answers (rank s owns the rows whose Merkle
- * leaf index has top log2(world) bits = s: complete cap subtrees).  The trace VALUES are resident on every rank
- * (generated there by sbn_split_prover_generate_trace, or loaded).  Exchange steps: one all-to-all per commitment
- * (columns -> rows), and small all-gathers (caps, quotient values, openings, FRI partial sums, query rows).
- * The library does no communication itself: the caller supplies the collectives (torch.distributed / RCCL in
- * starky_bn254_amd/split.py; a host-staged backend for tests) and the device staging memory they work on.
+ * 2^18, 8xMI355X with RCCL FRI fold"; reference workload src/fields/fq12/exp.rs:638-696).  One rank per GPU (one process
+ * each, or the threads of one process with sbn_local_comm_create); every rank calls the same functions with the same
+ * arguments and receives the same proof.  Work and the derived matrices (coefficients, LDE, Z, Merkle trees) are sharded:
+ * COLUMNS for iNTT / LDE / Z / openings / the FRI batch combination, dealt round-robin in blocks of 64 (rank r owns the
+ * column blocks r, r + world, ...); LDE ROWS for leaf hashing, Merkle subtrees, constraint evaluation and query answers
+ * (rank s owns the rows whose Merkle leaf index has top log2(world) bits = s: complete cap subtrees).  The trace VALUES
+ * are resident on every rank (generated there by sbn_split_prover_generate_trace, or loaded).  Exchange steps: one
+ * all-to-all per column block and plane (columns -> rows), pipelined -- while block k travels, block k + 1 is transformed
+ * and the blocks k - 1 of all ranks are absorbed by the leaf sponge -- and small all-gathers (caps, quotient values,
+ * openings, FRI partial sums, query rows).  The collectives come with the sbn_comm: the transports of this library
+ * (sbn_rccl_comm_create: RCCL send / recv over xGMI; sbn_local_comm_create: the ranks are threads of one process), or the
+ * caller's own (torch.distributed in starky_bn254_amd/split.py; a host-staged backend for tests).
  * world must be 1, 2, 4, 8 or 16 (<= 2^cap_height). */
 typedef struct sbn_comm {
+  uint32_t struct_size;      /* sizeof(sbn_comm) of the caller's header (ABI check) */
+  uint32_t reserved;
   void* ctx;                 /* passed back to the callbacks */
   uint32_t rank, world;
   void* send_buf;            /* device memory, >= send_bytes of sbn_split_exchange_bytes */
   void* recv_buf;            /* device memory, >= recv_bytes; holds this rank's row-sharded LDE matrices during a proof */
   uint64_t send_bytes, recv_bytes;
   /* Block d = send_buf[send_off[d] .. +send_len[d]) goes to rank d; the block from rank s lands at
-   * recv_buf[recv_off[s] .. +recv_len[s]).  Arrays of `world` entries, bytes.  Blocks sent to different ranks may be the
-   * same region (an all-gather).  Returns 0 when the received data is complete and visible to the device. */
-  int (*all_to_all)(void* ctx, const uint64_t* send_off, const uint64_t* send_len, const uint64_t* recv_off, const uint64_t* recv_len);
-  /* Host memory: every rank contributes `bytes` at send; recv = [world][bytes] in rank order. */
+   * recv_buf[recv_off[s] .. +recv_len[s]).  Arrays of `world` entries, bytes; zero-length blocks are skipped (rank d's
+   * recv_len[s] equals rank s's send_len[d]); blocks sent to different ranks may be the same region (an all-gather); a
+   * rank may send a block to itself.  STREAM-ORDERED: `stream` is a hipStream_t of the device that owns the buffers; the
+   * send blocks are read after everything enqueued on it before the call, and work enqueued on it after the call sees
+   * the received blocks complete and may overwrite the send blocks.  The call itself may return early (RCCL) or block
+   * (a host-staged transport synchronises the stream itself).  The arrays are only valid during the call.  0 = ok. */
+  int (*all_to_all)(void* ctx, void* stream, const uint64_t* send_off, const uint64_t* send_len, const uint64_t* recv_off, const uint64_t* recv_len);
+  /* Host memory, blocking: every rank contributes `bytes` at send; recv = [world][bytes] in rank order. */
   int (*all_gather_host)(void* ctx, const void* send, void* recv, uint64_t bytes);
 } sbn_comm;
 typedef struct sbn_split_prover sbn_split_prover;
@@ -210,6 +226,28 @@ int sbn_split_prover_load_trace(sbn_split_prover* p, const uint64_t* trace_col_m
 /* The proof of the whole trace, on every rank, word for word the proof sbn_prover_prove gives on one GPU. */
 int sbn_split_prover_prove(sbn_split_prover* p, sbn_proof** out);
 int sbn_split_prover_stage_times(const sbn_split_prover* p, float* ms_out, int cap);
+
+/* Transports that fill an sbn_comm: starky_bn254_amd/csrc/transport.hip ---------------------- */
+/* RCCL over xGMI, one process per GPU, no Python: librccl is loaded at run time (SBN_RCCL_LIB overrides the name), so the
+ * library itself has no link-time dependency on it.  Rank 0 calls sbn_rccl_unique_id and hands the 128 bytes to the other
+ * ranks by whatever means the caller has (a file, a socket, MPI); then every rank calls sbn_rccl_comm_create with the
+ * staging sizes of sbn_split_exchange_bytes (the transport allocates send_buf / recv_buf on the current device).
+ * all_to_all = ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd on the given stream; all_gather_host = ncclAllGather on
+ * a small device buffer + copies. */
+int sbn_rccl_unique_id(uint8_t id_out[128]);
+int sbn_rccl_comm_create(const uint8_t id[128], uint32_t rank, uint32_t world, uint64_t send_bytes, uint64_t recv_bytes, sbn_comm* out);
+void sbn_rccl_comm_destroy(sbn_comm* comm);
+/* The ranks are threads of ONE process: rank r on devices[r] (null: all ranks on the current device -- how the parity tests
+ * run 8 and 16 ranks on a one-GPU box).  Blocks are pulled with stream-ordered device-to-device copies (peer copies over
+ * xGMI between different devices); the ranks meet at host barriers, so every rank must be inside the same library call
+ * on its own thread.  A failing rank calls sbn_local_comm_abort, which releases the others with an error. */
+typedef struct sbn_local_group sbn_local_group;
+int sbn_local_comm_create(uint32_t world, const int* devices, uint64_t send_bytes, uint64_t recv_bytes, sbn_comm* comms_out, sbn_local_group** out);
+void sbn_local_comm_abort(sbn_local_group* g);
+void sbn_local_comm_destroy(sbn_local_group* g);
+/* A pattern exchange through `comm` (uneven blocks, self blocks, an all-gather, the host all-gather), checked on the
+ * device: every rank calls it; 0 = the transport moved every byte where it belongs. */
+int sbn_comm_selftest(const sbn_comm* comm);
 
 /* Proof object ---------------------------------------------------------------------------------- */
 size_t sbn_proof_num_words(const sbn_proof* proof);

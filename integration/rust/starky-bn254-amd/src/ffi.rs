@@ -20,8 +20,8 @@ pub struct sbn_config {
     pub fri_arity_bits: u32,
     pub fri_final_poly_bits: u32,
     pub num_query_rounds: u32,
-    /// 1 = plonky2 0.1.x FRI (final polynomial multiplied by X, PR #436), 0 = later upstream; see include/sbn.h
-    pub fri_final_poly_times_x: u32,
+    /// sbn_fri_variant: 0 = default (= 1), 1 = plonky2 0.1.x FRI (final polynomial multiplied by X, PR #436), 2 = later upstream
+    pub fri_variant: u32,
 }
 
 #[repr(C)]
@@ -48,6 +48,7 @@ pub const SBN_AIR_MODULAR: i32 = 7;
 pub const SBN_AIR_FQ12_MUL: i32 = 8;
 
 extern "C" {
+    pub fn sbn_abi_version() -> i32;
     pub fn sbn_last_error() -> *const c_char;
     pub fn sbn_set_device(device: i32) -> i32;
     pub fn sbn_device_count() -> i32;
@@ -59,6 +60,8 @@ extern "C" {
     pub fn sbn_prover_load_trace(p: *mut sbn_prover, trace_col_major: *const u64, public_inputs: *const u64, n_pi: usize) -> i32;
     pub fn sbn_prover_generate_trace(p: *mut sbn_prover, ios: *const u32, num_io: usize, pi_out: *mut u64) -> i32;
     pub fn sbn_prover_prove(p: *mut sbn_prover, out: *mut *mut sbn_proof) -> i32;
+    pub fn sbn_prover_stage_times(p: *const sbn_prover, ms_out: *mut f32, cap: i32) -> i32;
+    pub fn sbn_prover_stage_name(i: i32) -> *const c_char;
 
     pub fn sbn_batch_prover_create(air: *const sbn_air_desc, cfg: *const sbn_config, degree_bits: u32, inflight: u32, out: *mut *mut sbn_batch_prover) -> i32;
     pub fn sbn_batch_prover_prove_ios(b: *mut sbn_batch_prover, ios: *const u32, ios_words_per_unit: usize, num_io: usize, count: usize, proofs_out: *mut *mut sbn_proof) -> i32;

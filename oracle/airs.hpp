@@ -623,8 +623,8 @@ struct AirBase : Air {
 
 // G1Stark: src/curves/g1/muladd.rs:462-624 (single add rows, split range check).
 struct G1OpAir : AirBase<G1OpAir> {
-  static const int MAIN_COLS = 24 * N_LIMBS + 2;
-  static const int START_RC = 4 * N_LIMBS, NUM_RC = 20 * N_LIMBS - 4, END_RC = START_RC + NUM_RC;
+  static constexpr int MAIN_COLS = 24 * N_LIMBS + 2;
+  static constexpr int START_RC = 4 * N_LIMBS, NUM_RC = 20 * N_LIMBS - 4, END_RC = START_RC + NUM_RC;
   size_t num_columns() const override { return MAIN_COLS + 1 + 6 * NUM_RC; }
   size_t num_public_inputs() const override { return 0; }
   std::vector<std::pair<size_t, size_t>> permutation_pairs() const override {  // range_check.rs:228-246
@@ -984,7 +984,7 @@ struct Fq12ExpAir : AirBase<Fq12ExpAir> {
   int start_flags_col, num_main_cols, start_periodic_pulse_col, start_io_pulses_col, start_lookups_col, start_range_check_col, num_range_check_cols;  // :6-34
   size_t ncols, npi;
   std::vector<size_t> pulse_positions;
-  static const int IO_LEN = 36 * N_LIMBS + NUM_INPUT_LIMBS;  // :93
+  static constexpr int IO_LEN = 36 * N_LIMBS + NUM_INPUT_LIMBS;  // :93
   explicit Fq12ExpAir(size_t n) : num_io(n) {
     start_flags_col = 108 * N_LIMBS;
     num_main_cols = start_flags_col + NUM_FLAGS_COLS;
@@ -1136,8 +1136,8 @@ struct Fq12ExpU64Air : AirBase<Fq12ExpU64Air> {
   int start_flags_col, num_main_cols, start_io_pulses_col, start_lookups_col, start_range_check_col, num_range_check_cols;  // exp_u64.rs:19-45
   size_t ncols, npi;
   std::vector<size_t> pulse_positions;
-  static const int IO_LEN = 36 * N_LIMBS + 1;  // :98
-  static const size_t RPB = 2 * 64;
+  static constexpr int IO_LEN = 36 * N_LIMBS + 1;  // :98
+  static constexpr size_t RPB = 2 * 64;
   explicit Fq12ExpU64Air(size_t n) : num_io(n) {
     start_flags_col = 108 * N_LIMBS;
     num_main_cols = start_flags_col + NUM_FLAGS_U64_COLS;
@@ -1282,7 +1282,7 @@ struct FqExpAir : AirBase<FqExpAir> {
   int start_flags_col, num_main_cols, start_periodic_pulse_col, start_io_pulses_col, start_lookups_col, num_range_check_cols;  // exp.rs:6-34
   size_t ncols, npi;
   std::vector<size_t> pulse_positions;
-  static const int IO_LEN = 4 * NUM_INPUT_LIMBS;  // exp.rs:96
+  static constexpr int IO_LEN = 4 * NUM_INPUT_LIMBS;  // exp.rs:96
   explicit FqExpAir(size_t n) : num_io(n) {
     start_flags_col = 9 * N_LIMBS;
     num_main_cols = start_flags_col + NUM_FLAGS_COLS;
@@ -1407,8 +1407,8 @@ static inline std::vector<std::pair<size_t, size_t>> split_range_check_pairs(siz
 // ModularStark: src/modular/modular.rs:361-537.  Row: input0[16] input1[16] output[16] ModulusAux(95) quot_sign filter;
 // output and aux are range-checked; constraints: the split range check, then eval_modular_op on input0 * input1.
 struct ModularAir : AirBase<ModularAir> {
-  static const int MAIN_COLS = 9 * N_LIMBS + 1;                                                 // :361
-  static const int START_RC = 2 * N_LIMBS, NUM_RC = 7 * N_LIMBS - 1, END_RC = START_RC + NUM_RC;  // :364-366
+  static constexpr int MAIN_COLS = 9 * N_LIMBS + 1;                                                 // :361
+  static constexpr int START_RC = 2 * N_LIMBS, NUM_RC = 7 * N_LIMBS - 1, END_RC = START_RC + NUM_RC;  // :364-366
   size_t num_columns() const override { return MAIN_COLS + 1 + 6 * NUM_RC; }                    // :368
   size_t num_public_inputs() const override { return 0; }
   std::vector<std::pair<size_t, size_t>> permutation_pairs() const override { return split_range_check_pairs(MAIN_COLS, NUM_RC); }  // :533-535
@@ -1441,8 +1441,8 @@ struct ModularAir : AirBase<ModularAir> {
 };
 // Fq12Stark: src/fields/fq12/mul.rs:355-517.  Row: x[12][16] y[12][16] Fq12Output(1344) filter.
 struct Fq12MulAir : AirBase<Fq12MulAir> {
-  static const int MAIN_COLS = 108 * N_LIMBS + 1;                                                   // :355
-  static const int START_RC = 24 * N_LIMBS, NUM_RC = 84 * N_LIMBS - 12, END_RC = START_RC + NUM_RC;  // :356-358
+  static constexpr int MAIN_COLS = 108 * N_LIMBS + 1;                                                   // :355
+  static constexpr int START_RC = 24 * N_LIMBS, NUM_RC = 84 * N_LIMBS - 12, END_RC = START_RC + NUM_RC;  // :356-358
   size_t num_columns() const override { return MAIN_COLS + 1 + 6 * NUM_RC; }
   size_t num_public_inputs() const override { return 0; }
   std::vector<std::pair<size_t, size_t>> permutation_pairs() const override { return split_range_check_pairs(MAIN_COLS, NUM_RC); }

@@ -36,6 +36,8 @@ EXPORTS = [
     "sbn_proof_free", "sbn_verify", "sbn_commit_values", "sbn_poseidon_permute_batch", "sbn_poseidon_permute_host",
     "sbn_eval_constraints_host", "sbn_split_exchange_bytes", "sbn_split_prover_create", "sbn_split_prover_destroy", "sbn_split_prover_generate_trace",
     "sbn_split_prover_load_trace", "sbn_split_prover_prove", "sbn_split_prover_stage_times",
+    "sbn_abi_version", "sbn_rccl_unique_id", "sbn_rccl_comm_create", "sbn_rccl_comm_destroy",
+    "sbn_local_comm_create", "sbn_local_comm_abort", "sbn_local_comm_destroy", "sbn_comm_selftest",
 ]
 
 
@@ -52,7 +54,10 @@ class _AirDesc(C.Structure):
 class _Config(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("security_bits", "num_challenges", "rate_bits", "cap_height",
                                             "proof_of_work_bits", "fri_arity_bits", "fri_final_poly_bits", "num_query_rounds",
-                                            "fri_final_poly_times_x")]
+                                            "fri_variant")]
+
+
+FRI_DEFAULT, FRI_TIMES_X, FRI_PLAIN = 0, 1, 2   # sbn_fri_variant (include/sbn.h)
 
 
 def lib_path():

@@ -10,7 +10,8 @@ using namespace sbn;
 
 extern "C" {
 
-const char* sbn_version(void) { return "starky-bn254-amd 0.1 (gfx950)"; }
+const char* sbn_version(void) { return "starky-bn254-amd 0.3 (gfx950)"; }
+int sbn_abi_version(void) { return SBN_ABI_VERSION; }
 const char* sbn_last_error(void) { return g_last_error.c_str(); }
 
 // starky config.rs `StarkConfig::standard_fast_config` (the reference passes the column / public-input
@@ -19,7 +20,7 @@ void sbn_standard_fast_config(sbn_config* c) {
   if (!c) return;
   c->security_bits = 100; c->num_challenges = 2; c->rate_bits = 1; c->cap_height = 4; c->proof_of_work_bits = 16;
   c->fri_arity_bits = 4; c->fri_final_poly_bits = 5; c->num_query_rounds = 84;
-  c->fri_final_poly_times_x = 1;
+  c->fri_variant = SBN_FRI_TIMES_X;
 }
 
 size_t sbn_air_num_columns(const sbn_air_desc* air) { AirShape s; return air_shape(air, nullptr, s) ? s.ncols : 0; }

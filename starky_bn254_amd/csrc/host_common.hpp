@@ -93,8 +93,10 @@ static inline ExpShape exp_shape(const AirShape& a) { return ExpShape(exp_e(a.ki
 static inline bool config_supported(const sbn_config* c) {
   return c && c->num_challenges == SBN_NCH && c->rate_bits == 1 && c->cap_height >= 1 && c->cap_height <= 8 &&
          c->fri_arity_bits >= 1 && c->fri_arity_bits <= 4 && c->num_query_rounds >= 1 && c->num_query_rounds <= 512 &&
-         c->proof_of_work_bits <= 32 && c->fri_final_poly_times_x <= 1;
+         c->proof_of_work_bits <= 32 && c->fri_variant <= SBN_FRI_PLAIN;
 }
+// sbn_config.fri_variant: 0 selects the default (the 0.1.x line: final polynomial times X)
+static inline u32 fri_times_x(const sbn_config& c) { return c.fri_variant == SBN_FRI_PLAIN ? 0u : 1u; }
 
 // tracegen.hip: Jacobian curve chains of every G1ExpStark instance on host threads (layout: bn254w.cuh g1_chains)
 int tracegen_host_chains(int E, const uint32_t* ios, size_t K, u64* ja, u64* jb);

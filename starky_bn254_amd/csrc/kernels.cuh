@@ -994,23 +994,27 @@ __global__ __launch_bounds__(256) void pow_kernel(PowParams p) {
 // rows: out[q*qstride + off + c] = mat[c*m + bitrev(idx[q])]
 // ---- oversized-trace split (BASELINE config[4]: one trace over R GPUs) ---------------------------------------------
 // Rank s owns the LDE rows whose Merkle leaf index bitrev(i) has top log R bits = s, i.e. i = j * R + rho(s) with
-// rho = bit reversal on log R bits: complete cap subtrees, so hashing needs no exchange.  split_pack_kernel scatters a
-// column chunk of a rank's LDE block [nc][m] into the all-to-all send buffer: plane L [dest][ncols_own][m/R] (row i
-// goes to its owner at local row i >> log R) and, from 4 ranks up, plane N (row i is the NEXT row of point i - 2, whose
-// owner gets it at the local row of that point); with 2 ranks the next row of local row j is local row j + 1.
-__global__ __launch_bounds__(256) void split_pack_kernel(const u64* __restrict__ lde, size_t m, u32 nc, u32 c0, u32 ncols_own, u32 log_r,
-                                                         u64* __restrict__ send_l, u64* __restrict__ send_n) {
+// rho = bit reversal on log R bits: complete cap subtrees, so hashing needs no exchange.  split_pack_kernel scatters one
+// column block [nc][m] of a rank's LDE by destination: plane L (row i goes to its owner at local row i >> log R) and, from
+// 4 ranks up, plane N (row i is the NEXT row of point i - 2, whose owner gets it at the local row of that point; with 2
+// ranks the next row of local row j is local row j + 1).  Rows for another rank go to the send slot [dest][ob][m/R]; the
+// rank's OWN rows go straight into its receive matrix (self_l / self_n = the block's columns there), so no self block
+// ever passes through the transport.
+__global__ __launch_bounds__(256) void split_pack_kernel(const u64* __restrict__ lde, size_t m, u32 nc, u32 ob, u32 log_r, u32 me,
+                                                         u64* __restrict__ send_l, u64* __restrict__ send_n, u64* __restrict__ self_l, u64* __restrict__ self_n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const u32 c = blockIdx.y;
   if (i >= m || c >= nc) return;
   const u64 v = lde[(size_t)c * m + i];
   const size_t ml = m >> log_r, rmask = ((size_t)1 << log_r) - 1;
   const u32 s = bitrev32((u32)(i & rmask), log_r);
-  send_l[((size_t)s * ncols_own + c0 + c) * ml + (i >> log_r)] = v;
+  if (s == me) self_l[(size_t)c * ml + (i >> log_r)] = v;
+  else send_l[((size_t)s * ob + c) * ml + (i >> log_r)] = v;
   if (send_n) {
     const size_t p = (i + m - 2) & (m - 1);   // the point whose next row this is
     const u32 s2 = bitrev32((u32)(p & rmask), log_r);
-    send_n[((size_t)s2 * ncols_own + c0 + c) * ml + (p >> log_r)] = v;
+    if (s2 == me) self_n[(size_t)c * ml + (p >> log_r)] = v;
+    else send_n[((size_t)s2 * ob + c) * ml + (p >> log_r)] = v;
   }
 }
 // gathered [rank][nplanes][m/R] -> natural order [nplanes][m]

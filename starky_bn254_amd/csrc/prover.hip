@@ -22,7 +22,12 @@ namespace sbn { thread_local std::string g_last_error; }
     if (e_ != hipSuccess) return fail(SBN_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
   } while (0)
 
-static int g_device = 0;
+// sbn_set_device: the device of the provers created afterwards by the calling thread, and the default of threads that never
+// call it (the ranks of a local split group are threads with one device each)
+static std::atomic<int> g_default_device{0};
+static thread_local int t_device = -1;
+static inline int cur_device() { return t_device >= 0 ? t_device : g_default_device.load(); }
+#define g_device (cur_device())
 
 // Stage k spans [ev[k], ev[k+1]) on the prover's main stream.  The commit stages overlap NTT (main
 // stream) with sponge absorption (hash stream); the absorption kernels are additionally timed one by
@@ -45,24 +50,39 @@ struct DevTree {  // Merkle digests, levels concatenated (leaf level first)
 };
 
 // Oversized-trace split (include/sbn.h, sbn_split_prover_*): this rank's share of one proof.
+// The columns of a matrix are dealt to the ranks in blocks of `ob` columns, round-robin: rank r owns the blocks
+// b = r, r + R, r + 2R, ... and keeps them compactly (own block k = global block k * R + r at local columns k * ob ...);
+// only the globally last block can be short, and it is the last own block of its owner.  In step k of a commitment every
+// rank transforms its own block k, the all-to-all of that step moves the blocks k * R .. k * R + R - 1 to their row
+// owners, and the leaf sponge -- sequential over the columns of a row -- absorbs exactly those blocks next.
+struct ColShare {
+  size_t total = 0, ob = 64; u32 R = 1, rank = 0;
+  size_t nblocks() const { return (total + ob - 1) / ob; }
+  size_t steps() const { return (nblocks() + R - 1) / R; }
+  size_t block_cols(size_t b) const { return b < nblocks() ? std::min(ob, total - b * ob) : 0; }
+  size_t own_cols(u32 r) const { size_t s = 0; for (size_t b = r; b < nblocks(); b += R) s += block_cols(b); return s; }
+  size_t own() const { return own_cols(rank); }
+  size_t max_own() const { size_t s = 0; for (u32 r = 0; r < R; r++) s = std::max(s, own_cols(r)); return s; }
+  size_t global_col(u32 r, size_t local) const { return ((local / ob) * R + r) * ob + local % ob; }   // of rank r's local column
+};
 struct SplitCtx {
   sbn_comm comm;
   u32 log_r = 0, rho = 0;                 // world = 2^log_r; this rank owns the LDE rows i = j * world + rho
   size_t ml = 0;                          // local LDE rows = m >> log_r
-  std::vector<size_t> ccnt, coff, zcnt, zoff;   // trace / Z columns per rank (contiguous ranges)
-  size_t c0 = 0, cr = 0, z0 = 0, zr = 0, cmax = 0, zmax = 0;   // this rank's ranges, largest shares
+  ColShare cs, zs;                        // trace / Z columns of this rank
+  size_t cr = 0, zr = 0;                  // = cs.own(), zs.own()
   u32 planes = 1;                         // 2 from four ranks up: the rows i + 2 of the local rows arrive as a second plane
   u64 *lde_l = nullptr, *lde_n = nullptr, *zlde_l = nullptr, *zlde_n = nullptr, *scratch = nullptr;   // views of comm.recv_buf
   size_t scratch_words = 0;
-  u64* d_ldechunk = nullptr;              // [ntt_chunk][m]: one column chunk of this rank's LDE before it is packed
+  size_t slot_words = 0;                  // one send slot = [plane][dest][ob][ml]; two slots, used alternately by the steps
+  u64* d_ldechunk = nullptr;              // [ntt_chunk][m]: one column block of this rank's LDE before it is packed
   u32* d_idx_local = nullptr;             // query leaf indices inside this rank's subtrees
-  double comm_s = 0;
+  PairCols* d_pairs_own = nullptr;        // permutation pairs of the own Z columns, local order
+  hipStream_t cstream = nullptr;          // the exchanges of the commit pipeline
+  hipEvent_t xchg_done[MAX_CHUNKS];       // comm stream: the blocks of step k have arrived (and send slot k & 1 is free again)
+  std::vector<hipEvent_t> tev;            // timing events around the exchanges (pairs), consumed in order
+  size_t tev_used = 0;
 };
-static void split_partition(size_t total, u32 world, std::vector<size_t>& cnt, std::vector<size_t>& off) {
-  cnt.resize(world); off.resize(world);
-  size_t o = 0;
-  for (u32 r = 0; r < world; r++) { cnt[r] = total / world + (r < total % world ? 1 : 0); off[r] = o; o += cnt[r]; }
-}
 
 struct sbn_prover {
   AirShape air; sbn_config cfg; FriShape fri;
@@ -287,25 +307,30 @@ static int commit_pipeline(sbn_prover* P, const u64* vals, u64* coef, u64* lde, 
 static inline hipError_t stream_wait(hipStream_t st) { return hipStreamSynchronize(st); }
 static inline hipError_t event_wait(hipEvent_t ev) { return hipEventSynchronize(ev); }
 // ---- oversized-trace split: exchange helpers ------------------------------------------------------------------------
-static int split_all_to_all(sbn_prover* P, const std::vector<uint64_t>& so, const std::vector<uint64_t>& sl, const std::vector<uint64_t>& ro,
-                            const std::vector<uint64_t>& rl) {
+// Every exchange is STREAM-ORDERED (include/sbn.h sbn_comm.all_to_all): it is enqueued on `st` behind the kernels that
+// packed its blocks, and the kernels that consume the received blocks are enqueued on `st` (or behind an event of `st`)
+// after it.  Timing: a pair of events around each call, summed after the proof (split_exchange_ms).
+static int split_exchange(sbn_prover* P, hipStream_t st, const std::vector<uint64_t>& so, const std::vector<uint64_t>& sl, const std::vector<uint64_t>& ro,
+                          const std::vector<uint64_t>& rl) {
   SplitCtx* S = P->sp;
-  HIPC(hipStreamSynchronize(P->stream));   // the collective runs on the caller's stream: everything packed so far must be done
-  auto t0 = std::chrono::steady_clock::now();
-  const int rc = S->comm.all_to_all(S->comm.ctx, so.data(), sl.data(), ro.data(), rl.data());
-  S->comm_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  bool any = false;
+  for (u32 r = 0; r < S->comm.world; r++) any = any || sl[r] || rl[r];
+  if (!any) return 0;   // (every rank sees the same emptiness: the block counts are functions of the shape alone)
+  const bool timed = S->tev_used + 2 <= S->tev.size();
+  if (timed) HIPC(hipEventRecord(S->tev[S->tev_used], st));
+  const int rc = S->comm.all_to_all(S->comm.ctx, (void*)st, so.data(), sl.data(), ro.data(), rl.data());
   if (rc) return fail(SBN_ERR_HIP, "sbn_comm.all_to_all failed (%d)", rc);
+  if (timed) { HIPC(hipEventRecord(S->tev[S->tev_used + 1], st)); S->tev_used += 2; }
   return 0;
 }
 static int split_all_gather_host(sbn_prover* P, const void* send, void* recv, size_t bytes) {
   SplitCtx* S = P->sp;
-  auto t0 = std::chrono::steady_clock::now();
   const int rc = S->comm.all_gather_host(S->comm.ctx, send, recv, bytes);
-  S->comm_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   if (rc) return fail(SBN_ERR_HIP, "sbn_comm.all_gather_host failed (%d)", rc);
   return 0;
 }
-// every rank contributes `words` u64 at the start of the send buffer; the result [world][words] lands in the receive scratch
+// every rank contributes `words` u64 at the start of the send buffer; the result [world][words] lands in the receive
+// scratch; ordered on the main stream
 static int split_all_gather_device(sbn_prover* P, size_t words) {
   SplitCtx* S = P->sp;
   const u32 R = S->comm.world;
@@ -313,49 +338,78 @@ static int split_all_gather_device(sbn_prover* P, size_t words) {
   const uint64_t base = (uint64_t)((const char*)S->scratch - (const char*)S->comm.recv_buf);
   std::vector<uint64_t> so(R, 0), sl(R, words * sizeof(u64)), ro(R), rl(R, words * sizeof(u64));
   for (u32 r = 0; r < R; r++) ro[r] = base + (uint64_t)r * words * sizeof(u64);
-  return split_all_to_all(P, so, sl, ro, rl);
+  return split_exchange(P, P->stream, so, sl, ro, rl);
 }
-// PolynomialBatch::from_values for this rank's share: iNTT + coset LDE of its own columns (coefficients stay here),
-// one all-to-all columns -> rows per plane, then sponge + Merkle subtrees over its LDE rows.
-static int commit_split(sbn_prover* P, const u64* vals_own, u64* coef_own, size_t ncols_own, size_t ncols_max, const std::vector<size_t>& cnt,
-                        const std::vector<size_t>& off, size_t total, u64* plane_l, u64* plane_n, DevTree& t) {
+// PolynomialBatch::from_values for this rank's share, as a three-stage pipeline over the column blocks (ColShare):
+//   main stream   step k: iNTT + coset LDE of the own block k (coefficients stay here), rows packed per destination
+//   comm stream   step k: one all-to-all per plane, columns -> rows (the own rows never travel: the pack kernel writes them
+//                 straight into the receive matrix)
+//   hash stream   step k: the leaf sponge absorbs the blocks k*R .. k*R+R-1 of its LDE rows; then the Merkle subtrees.
+// With one rank the LDE lands in the row matrix directly (local row = natural row) and nothing is exchanged.
+// `vals`: [..][n] values; block b of the matrix starts at vals + (vals_global ? b : own index k) * ob * n.
+static int commit_split(sbn_prover* P, const ColShare& sh, const u64* vals, bool vals_global, u64* coef_own, u64* plane_l, u64* plane_n, DevTree& t) {
   SplitCtx* S = P->sp;
-  const u32 R = S->comm.world;
-  const size_t m = P->m, ml = S->ml, ch = P->ntt_chunk;
-  u64* send_l = (u64*)S->comm.send_buf;
-  u64* send_n = S->planes == 2 ? send_l + ncols_own * m : nullptr;   // per plane: [dest][ncols_own][ml] = ncols_own * m words
-  (void)ncols_max;
-  for (size_t c0 = 0; c0 < ncols_own; c0 += ch) {
-    const size_t nc = std::min(ch, ncols_own - c0);
-    int rc = ntt_columns(P, vals_own + c0 * P->n, P->n, coef_own + c0 * P->n, P->n, P->d_tmp, m, nc, P->degree_bits, true, P->n, nullptr, nullptr,
-                         host_inv_pow2(P->degree_bits));
-    if (rc) return rc;
-    rc = ntt_columns(P, coef_own + c0 * P->n, P->n, S->d_ldechunk, m, P->d_tmp, m, nc, P->lde_log, false, P->n, P->d_shift, nullptr, 1);
-    if (rc) return rc;
-    hipLaunchKernelGGL(split_pack_kernel, dim3((unsigned)((m + 255) / 256), (unsigned)nc), dim3(256), 0, P->stream, S->d_ldechunk, m, (u32)nc, (u32)c0,
-                       (u32)ncols_own, S->log_r, send_l, send_n);
-  }
-  HIPC(hipGetLastError());
-  for (u32 pl = 0; pl < S->planes; pl++) {
-    const u64* dst = pl ? plane_n : plane_l;
-    std::vector<uint64_t> so(R), sl(R), ro(R), rl(R);
-    for (u32 r = 0; r < R; r++) {
-      so[r] = (uint64_t)(((size_t)pl * ncols_own * m + (size_t)r * ncols_own * ml) * sizeof(u64));
-      sl[r] = (uint64_t)(ncols_own * ml * sizeof(u64));
-      ro[r] = (uint64_t)((const char*)(dst + off[r] * ml) - (const char*)S->comm.recv_buf);
-      rl[r] = (uint64_t)(cnt[r] * ml * sizeof(u64));
+  const u32 R = S->comm.world, me = S->comm.rank;
+  const size_t n = P->n, m = P->m, ml = S->ml, ob = sh.ob;
+  const size_t steps = sh.steps();
+  if (steps > (size_t)MAX_CHUNKS) return fail(SBN_ERR_UNSUPPORTED, "too many column blocks");
+  const char* rbase = (const char*)S->comm.recv_buf;
+  const char* sbase = (const char*)S->comm.send_buf;
+  const u32 row_log = P->lde_log - S->log_r;
+  for (size_t k = 0; k < steps; k++) {
+    const size_t b = k * R + me, nc = sh.block_cols(b);
+    u64* const slot = (u64*)S->comm.send_buf + (k & 1) * S->slot_words;     // [plane][dest][ob][ml]
+    u64* const slot_n = S->planes == 2 ? slot + (size_t)R * ob * ml : nullptr;
+    if (nc) {
+      const u64* v = vals + (vals_global ? b : k) * ob * n;
+      u64* cf = coef_own + k * ob * n;
+      int rc = ntt_columns(P, v, n, cf, n, P->d_tmp, m, nc, P->degree_bits, true, n, nullptr, nullptr, host_inv_pow2(P->degree_bits));
+      if (rc) return rc;
+      u64* lde_out = R == 1 ? plane_l + b * ob * m : S->d_ldechunk;
+      rc = ntt_columns(P, cf, n, lde_out, m, P->d_tmp, m, nc, P->lde_log, false, n, P->d_shift, nullptr, 1);
+      if (rc) return rc;
+      if (R > 1 && k >= 2) HIPC(hipStreamWaitEvent(P->stream, S->xchg_done[k - 2], 0));   // send slot k & 1 has left
+      if (R > 1)
+        hipLaunchKernelGGL(split_pack_kernel, dim3((unsigned)((m + 255) / 256), (unsigned)nc), dim3(256), 0, P->stream, S->d_ldechunk, m, (u32)nc, (u32)ob, S->log_r, me,
+                           slot, slot_n, plane_l + b * ob * ml, plane_n ? plane_n + b * ob * ml : nullptr);
+      HIPC(hipGetLastError());
     }
-    int rc = split_all_to_all(P, so, sl, ro, rl);
-    if (rc) return rc;
+    HIPC(hipEventRecord(P->chunk_ready[k], P->stream));
+    hipEvent_t arrived = P->chunk_ready[k];
+    if (R > 1) {
+      HIPC(hipStreamWaitEvent(S->cstream, P->chunk_ready[k], 0));
+      for (u32 pl = 0; pl < S->planes; pl++) {
+        const u64* dst = pl ? plane_n : plane_l;
+        std::vector<uint64_t> so(R, 0), sl(R, 0), ro(R, 0), rl(R, 0);
+        for (u32 r = 0; r < R; r++) {
+          if (r == me) continue;
+          so[r] = (uint64_t)((const char*)(slot + ((size_t)pl * R + r) * ob * ml) - sbase);
+          sl[r] = (uint64_t)(nc * ml * sizeof(u64));
+          const size_t br = k * R + r;
+          ro[r] = (uint64_t)((const char*)(dst + br * ob * ml) - rbase);
+          rl[r] = (uint64_t)(sh.block_cols(br) * ml * sizeof(u64));
+        }
+        int rc = split_exchange(P, S->cstream, so, sl, ro, rl);
+        if (rc) return rc;
+      }
+      HIPC(hipEventRecord(S->xchg_done[k], S->cstream));
+      arrived = S->xchg_done[k];
+    }
+    HIPC(hipStreamWaitEvent(P->hstream, arrived, 0));
+    // the sponge over the blocks of this step, in launches of one block (64 columns: the carried state stays small in L2)
+    const size_t c_begin = k * R * ob, c_end = std::min(sh.total, (k + 1) * R * ob);
+    for (size_t c0 = c_begin; c0 < c_end; c0 += ob) {
+      const size_t ncs = std::min(ob, c_end - c0);
+      hipLaunchKernelGGL(leaf_absorb_kernel, dim3((unsigned)((ml + 255) / 256)), dim3(256), 0, P->hstream, plane_l + c0 * ml, ml, row_log, (u32)ncs,
+                         P->d_sponge, c0 == 0 ? 1 : 0, c0 + ncs == sh.total ? 1 : 0, t.d);
+    }
+    HIPC(hipGetLastError());
   }
-  const size_t nchunks = (total + ch - 1) / ch;
-  for (size_t k = 0; k < nchunks; k++) {
-    const size_t c0 = k * ch, nc = std::min(ch, total - c0);
-    hipLaunchKernelGGL(leaf_absorb_kernel, dim3((unsigned)((ml + 255) / 256)), dim3(256), 0, P->stream, plane_l + c0 * ml, ml, P->lde_log - S->log_r, (u32)nc,
-                       P->d_sponge, k == 0 ? 1 : 0, k + 1 == nchunks ? 1 : 0, t.d);
-  }
-  HIPC(hipGetLastError());
-  return tree_build_inner(P, t, P->stream);
+  int rc = tree_build_inner(P, t, P->hstream);
+  if (rc) return rc;
+  HIPC(hipEventRecord(P->hash_done, P->hstream));
+  HIPC(hipStreamWaitEvent(P->stream, P->hash_done, 0));
+  return 0;
 }
 // the Merkle cap: this rank's 2^(cap_height - log R) subtree roots, all-gathered in rank order = cap order
 static int split_cap_to_host(sbn_prover* P, const DevTree& t, std::vector<u64>& cap) {
@@ -383,15 +437,20 @@ static int tree_cap_to_host(sbn_prover* P, const DevTree& t, std::vector<u64>& c
 }
 
 // ---- create / destroy -----------------------------------------------------------------------------
-static int split_sizes(const AirShape& as, u32 degree_bits, u32 rate_bits, u32 world, size_t chunk, uint64_t* send_bytes, uint64_t* recv_bytes, size_t* scratch_words) {
+// Send side: two slots of one column block per plane, [plane][dest][ob][m/R] = planes * ob * m words each (one rank: no
+// slot, the LDE lands in the row matrix), and room for the gathered vectors (2 m/R quotient values, 2 n partial sums).
+// Receive side: the row-sharded trace and Z matrices per plane plus the gather scratch.
+static constexpr size_t SPLIT_BLOCK = 64;   // columns per ownership block = the prover's NTT chunk (create_ctx checks)
+static int split_sizes(const AirShape& as, u32 degree_bits, u32 rate_bits, u32 world, size_t ob, uint64_t* send_bytes, uint64_t* recv_bytes, size_t* scratch_words,
+                       size_t* slot_words) {
   const size_t n = (size_t)1 << degree_bits, m = n << rate_bits;
   const u32 planes = world >= 4 ? 2 : 1;
-  const size_t cmax = (as.ncols + world - 1) / world, zmax = (as.nzs + world - 1) / world;
   const size_t sw = std::max<size_t>(2 * m, 2 * n * world);   // gathered quotient values / FRI partial sums
-  (void)chunk;
-  *send_bytes = (uint64_t)(std::max(std::max(cmax, zmax) * m * planes, 2 * n) * sizeof(u64));
+  const size_t slot = world > 1 ? (size_t)planes * ob * m : 0;
+  *send_bytes = (uint64_t)(std::max(std::max(2 * slot, 2 * (m / world)), 2 * n) * sizeof(u64));
   *recv_bytes = (uint64_t)(((as.ncols + as.nzs) * (m / world) * planes + sw) * sizeof(u64));
   *scratch_words = sw;
+  if (slot_words) *slot_words = slot;
   return 0;
 }
 static int create_ctx(const sbn_air_desc* air, const sbn_config* cfg, uint32_t degree_bits, const sbn_comm* comm, sbn_prover** out);
@@ -448,18 +507,26 @@ static int create_ctx(const sbn_air_desc* air, const sbn_config* cfg, uint32_t d
     // subtrees (views of the caller's receive buffer); the trace values stay whole
     const u32 R = comm->world;
     u32 lr = 0; while ((1u << lr) < R) lr++;
-    uint64_t sb = 0, rb = 0; size_t sw = 0;
-    split_sizes(as, degree_bits, cfg->rate_bits, R, P->ntt_chunk, &sb, &rb, &sw);
+    uint64_t sb = 0, rb = 0; size_t sw = 0, slotw = 0;
+    if (comm->struct_size != sizeof(sbn_comm)) { sbn_prover_destroy(P); return fail(SBN_ERR_BAD_ARG, "sbn_comm.struct_size does not match this library (ABI %d)", SBN_ABI_VERSION); }
+    if (P->ntt_chunk != SPLIT_BLOCK) { sbn_prover_destroy(P); return fail(SBN_ERR_UNSUPPORTED, "the split prover deals columns in blocks of %zu: unset SBN_NTT_CHUNK", SPLIT_BLOCK); }
+    split_sizes(as, degree_bits, cfg->rate_bits, R, SPLIT_BLOCK, &sb, &rb, &sw, &slotw);
     if ((1u << lr) != R || lr > cfg->cap_height || comm->rank >= R || !comm->all_to_all || !comm->all_gather_host || !comm->send_buf || !comm->recv_buf ||
         comm->send_bytes < sb || comm->recv_bytes < rb) {
       sbn_prover_destroy(P);
       return fail(SBN_ERR_BAD_ARG, "bad sbn_comm (world must be a power of two <= 2^cap_height; staging buffers of sbn_split_exchange_bytes)");
     }
     SplitCtx* S = P->sp = new SplitCtx();
+    for (auto& e : S->xchg_done) e = nullptr;
     S->comm = *comm; S->log_r = lr; S->rho = bitrev32(comm->rank, lr); S->ml = m >> lr; S->planes = R >= 4 ? 2 : 1;
-    split_partition(C, R, S->ccnt, S->coff); split_partition(Z, R, S->zcnt, S->zoff);
-    S->c0 = S->coff[comm->rank]; S->cr = S->ccnt[comm->rank]; S->z0 = S->zoff[comm->rank]; S->zr = S->zcnt[comm->rank];
-    S->cmax = S->ccnt[0]; S->zmax = S->zcnt[0];
+    S->slot_words = slotw;
+    S->cs.total = C; S->cs.ob = SPLIT_BLOCK; S->cs.R = R; S->cs.rank = comm->rank;
+    S->zs = S->cs; S->zs.total = Z;
+    S->cr = S->cs.own(); S->zr = S->zs.own();
+    hipc(hipStreamCreate(&S->cstream), "hipStreamCreate");
+    for (auto& e : S->xchg_done) hipc(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
+    S->tev.assign(2 * (2 * (S->cs.steps() + S->zs.steps()) + 8), nullptr);
+    for (auto& e : S->tev) hipc(hipEventCreate(&e), "hipEventCreate");
     u64* rbuf = (u64*)comm->recv_buf;
     S->lde_l = rbuf; rbuf += C * S->ml;
     if (S->planes == 2) { S->lde_n = rbuf; rbuf += C * S->ml; }
@@ -535,6 +602,13 @@ static int create_ctx(const sbn_air_desc* air, const sbn_config* cfg, uint32_t d
     }
     hipc(hipMalloc((void**)&P->d_pairs, Z * sizeof(PairCols)), "hipMalloc");
     if (!rc) hipc(hipMemcpy(P->d_pairs, pairs.data(), Z * sizeof(PairCols), hipMemcpyHostToDevice), "hipMemcpy");
+    if (P->sp && P->sp->zr) {   // the split: the pairs of this rank's Z columns in local order
+      SplitCtx* S = P->sp;
+      std::vector<PairCols> own(S->zr);
+      for (size_t l = 0; l < S->zr; l++) own[l] = pairs[S->zs.global_col(S->zs.rank, l)];
+      hipc(hipMalloc((void**)&S->d_pairs_own, S->zr * sizeof(PairCols)), "hipMalloc");
+      if (!rc) hipc(hipMemcpy(S->d_pairs_own, own.data(), S->zr * sizeof(PairCols), hipMemcpyHostToDevice), "hipMemcpy");
+    }
   }
   hipc(hipStreamSynchronize(P->stream), "hipStreamSynchronize");
   hipc(hipGetLastError(), "table kernels");
@@ -555,6 +629,10 @@ extern "C" void sbn_prover_destroy(sbn_prover* P) {
   if (P->sp) {
     if (P->sp->d_ldechunk) (void)hipFree(P->sp->d_ldechunk);
     if (P->sp->d_idx_local) (void)hipFree(P->sp->d_idx_local);
+    if (P->sp->d_pairs_own) (void)hipFree(P->sp->d_pairs_own);
+    for (auto& e : P->sp->xchg_done) if (e) (void)hipEventDestroy(e);
+    for (auto& e : P->sp->tev) if (e) (void)hipEventDestroy(e);
+    if (P->sp->cstream) (void)hipStreamDestroy(P->sp->cstream);
     delete P->sp;
   }
   if (P->d_pic) (void)hipFree(P->d_pic);
@@ -952,8 +1030,8 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
   HIPC(hipEventRecord(P->ev[ST_TRACE_COMMIT], st));
   SplitCtx* const S = P->sp;   // non-null: this rank's share of one trace split over S->comm.world GPUs
   if (S) {
-    S->comm_s = 0;
-    if ((rc = commit_split(P, P->d_trace + S->c0 * n, P->d_coef, S->cr, S->cmax, S->ccnt, S->coff, C, S->lde_l, S->lde_n, P->tree_t))) return rc;
+    S->tev_used = 0;
+    if ((rc = commit_split(P, S->cs, P->d_trace, true, P->d_coef, S->lde_l, S->lde_n, P->tree_t))) return rc;
   } else if ((rc = commit_pipeline(P, P->d_trace, P->d_coef, P->d_lde, C, P->tree_t, EX_TRACE_ABSORB_MS, EX_TRACE_ABSORB_LAUNCHES))) return rc;
   HIPC(hipEventRecord(P->ev[ST_PERM_Z], st));
   if ((rc = S ? split_cap_to_host(P, P->tree_t, trace_cap) : tree_cap_to_host(P, P->tree_t, trace_cap))) return rc;
@@ -966,7 +1044,7 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
   const F gamma0 = gam[0][0], gamma1 = gam[1][1];  // instance i of a batch uses sets[i].challenges[chal]
   {
     const size_t zn = S ? S->zr : Z;                       // Z columns computed here (the split: this rank's range)
-    const PairCols* pairs = P->d_pairs + (S ? S->z0 : 0);
+    const PairCols* pairs = S ? S->d_pairs_own : P->d_pairs;
     if (zn == 0) {}
     else if (n % 2048 == 0) hipLaunchKernelGGL(permutation_z_kernel<8>, dim3((unsigned)zn), dim3(256), 0, st, P->d_trace, n, pairs, gamma0.v, gamma1.v, P->d_zval);
     else if (n % 1024 == 0) hipLaunchKernelGGL(permutation_z_kernel<4>, dim3((unsigned)zn), dim3(256), 0, st, P->d_trace, n, pairs, gamma0.v, gamma1.v, P->d_zval);
@@ -975,7 +1053,7 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
   HIPC(hipGetLastError());
   HIPC(hipEventRecord(P->ev[ST_Z_COMMIT], st));
   if (S) {
-    if ((rc = commit_split(P, P->d_zval, P->d_zcoef, S->zr, S->zmax, S->zcnt, S->zoff, Z, S->zlde_l, S->zlde_n, P->tree_z))) return rc;
+    if ((rc = commit_split(P, S->zs, P->d_zval, false, P->d_zcoef, S->zlde_l, S->zlde_n, P->tree_z))) return rc;
   } else {
     if ((rc = absorb_times(P, C, EX_TRACE_ABSORB_MS))) return rc;   // (27 event queries: behind the Z kernel, not in front of it)
     if ((rc = commit_pipeline(P, P->d_zval, P->d_zcoef, P->d_zlde, Z, P->tree_z, EX_Z_ABSORB_MS, EX_Z_ABSORB_LAUNCHES))) return rc;
@@ -1038,8 +1116,11 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
       for (int sgm = 0; sgm < 4; sgm++) for (int j = 0; j < SBN_NCH; j++) qp.seg_shift[sgm][j] = f_pow(alphas[j], after[sgm]).v;
     }
     const size_t qblocks = (qp.m + 255) / 256;
-    { const char* e = getenv("SBN_DIAG_QUOTIENT_SEGMASK"); qp.seg_mask = e ? (u32)atoi(e) : 0xfu; }   // diagnostic only: the proof is invalid unless 15
+    qp.seg_mask = 0xfu;
+#ifdef SBN_DIAG   // diagnostic builds only (make CXXFLAGS+=-DSBN_DIAG): time single segments; the proof is invalid unless the mask is 15
+    { const char* e = getenv("SBN_DIAG_QUOTIENT_SEGMASK"); if (e) qp.seg_mask = (u32)atoi(e) & 0xfu; }
     if (qp.seg_mask != 0xfu) HIPC(hipMemsetAsync(qp.part, 0, (size_t)QSEG * SBN_NCH * qp.m * sizeof(u64), st));
+#endif
     // AIR head and tail on the main stream, the permutation checks beside them on the second stream (idle here)
     HIPC(hipEventRecord(P->chunk_ready[3], st));
     HIPC(hipStreamWaitEvent(P->hstream, P->chunk_ready[3], 0));
@@ -1080,27 +1161,29 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
   // device would otherwise spend waiting for the host.
   const u64* open = P->h_open;
   const u64* open2 = P->h_open2;
-  if (S) {
-    // this rank evaluates its own trace / Z columns at both points (the quotient columns everywhere), the values are
-    // all-gathered on the host and observed in transcript order
+  if (S && S->comm.world > 1) {
+    // this rank evaluates its own trace / Z columns at both points (the quotient columns everywhere; own columns sit
+    // compactly in local order at the start of the trace / Z sections of d_open), the values are all-gathered on the host,
+    // scattered to their global positions and observed in transcript order
     const u64 *zp0 = P->d_zpow, *zp1 = P->d_zpow + n, *zp2 = P->d_zpow + 2 * n, *zp3 = P->d_zpow + 3 * n;
     auto open_k = n % 1024 == 0 ? openings_kernel<4> : openings_kernel<1>;
-    if (S->cr) hipLaunchKernelGGL(open_k, dim3((unsigned)S->cr), dim3(256), 0, st, P->d_coef, n, zp0, zp1, zp2, zp3, P->d_open + S->c0 * 4);
-    if (S->zr) hipLaunchKernelGGL(open_k, dim3((unsigned)S->zr), dim3(256), 0, st, P->d_zcoef, n, zp0, zp1, zp2, zp3, P->d_open + (C + S->z0) * 4);
+    if (S->cr) hipLaunchKernelGGL(open_k, dim3((unsigned)S->cr), dim3(256), 0, st, P->d_coef, n, zp0, zp1, zp2, zp3, P->d_open);
+    if (S->zr) hipLaunchKernelGGL(open_k, dim3((unsigned)S->zr), dim3(256), 0, st, P->d_zcoef, n, zp0, zp1, zp2, zp3, P->d_open + C * 4);
     hipLaunchKernelGGL(open_k, dim3(4), dim3(256), 0, st, P->d_q, n, zp0, zp1, zp2, zp3, P->d_open + (C + Z) * 4);
     HIPC(hipGetLastError());
     HIPC(hipMemcpyAsync(P->h_open, P->d_open, (C + Z + 4) * 4 * sizeof(u64), hipMemcpyDeviceToHost, st));
     HIPC(hipEventRecord(P->ev[ST_FRI_COMBINE], st));
     HIPC(stream_wait(st));
     const u32 R = S->comm.world;
-    const size_t per = (S->cmax + S->zmax) * 4;
+    const size_t cmax = S->cs.max_own(), zmax = S->zs.max_own(), per = (cmax + zmax) * 4;
     std::vector<u64> mine(per, 0), all((size_t)R * per);
-    memcpy(mine.data(), P->h_open + S->c0 * 4, S->cr * 4 * sizeof(u64));
-    memcpy(mine.data() + S->cmax * 4, P->h_open + (C + S->z0) * 4, S->zr * 4 * sizeof(u64));
+    memcpy(mine.data(), P->h_open, S->cr * 4 * sizeof(u64));
+    memcpy(mine.data() + cmax * 4, P->h_open + C * 4, S->zr * 4 * sizeof(u64));
     if ((rc = split_all_gather_host(P, mine.data(), all.data(), per * sizeof(u64)))) return rc;
     for (u32 r = 0; r < R; r++) {
-      memcpy(P->h_open + S->coff[r] * 4, all.data() + (size_t)r * per, S->ccnt[r] * 4 * sizeof(u64));
-      memcpy(P->h_open + (C + S->zoff[r]) * 4, all.data() + (size_t)r * per + S->cmax * 4, S->zcnt[r] * 4 * sizeof(u64));
+      const u64* src = all.data() + (size_t)r * per;
+      for (size_t l = 0, cnt = S->cs.own_cols(r); l < cnt; l++) memcpy(P->h_open + S->cs.global_col(r, l) * 4, src + l * 4, 4 * sizeof(u64));
+      for (size_t l = 0, cnt = S->zs.own_cols(r); l < cnt; l++) memcpy(P->h_open + (C + S->zs.global_col(r, l)) * 4, src + (cmax + l) * 4, 4 * sizeof(u64));
     }
     open2 = open;
     for (size_t p = 0; p < C + Z + 4; p++) { ch.observe(F(open[4 * p])); ch.observe(F(open[4 * p + 1])); }
@@ -1159,17 +1242,19 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
   E2 fri_alpha = ch.ext_challenge();
   {
     // F1 = sum_{j < C+Z} alpha^j f_j ; F0 = F1 + alpha^(C+Z) * sum_{j<4} alpha^j q_j
-    const u32 GS = 128;  // polys per group; groups run on grid.y, <= 32 per launch
-    // all group weights alpha^(offset + g*GS) are known up front: one upload, no host sync in the loop
+    // polys per group; groups run on grid.y, <= 32 per launch.  The split: a group = one own column block (ColShare), whose
+    // weight is alpha^(global position of the block); consecutive own blocks are `world` blocks apart.
+    const u32 RW = S ? S->comm.world : 1;
+    const u32 GS = RW > 1 ? (u32)SPLIT_BLOCK : 128;
+    // all group weights alpha^(offset + g*stride) are known up front: one upload, no host sync in the loop
     std::vector<u64> wall;
-    auto plan = [&](u32 npoly, E2 weight0) { size_t off = wall.size(); u32 ng = (npoly + GS - 1) / GS; E2 ag = e2_pow(fri_alpha, GS), cur = weight0;
-                                             for (u32 k = 0; k < ng; k++) { wall.push_back(cur.a.v); wall.push_back(cur.b.v); cur = cur * ag; } return off; };
-    E2 one{F(1), F(0)};
+    auto plan = [&](u32 npoly, E2 weight0, u64 stride) { size_t off = wall.size(); u32 ng = (npoly + GS - 1) / GS; E2 ag = e2_pow(fri_alpha, stride), cur = weight0;
+                                                         for (u32 k = 0; k < ng; k++) { wall.push_back(cur.a.v); wall.push_back(cur.b.v); cur = cur * ag; } return off; };
     // the split: this rank's columns only, with the weights of their global positions
-    const size_t tc0 = S ? S->c0 : 0, tcn = S ? S->cr : C, tz0 = S ? S->z0 : 0, tzn = S ? S->zr : Z;
-    size_t w_t = tcn ? plan((u32)tcn, e2_pow(fri_alpha, tc0)) : 0, w_z = tzn ? plan((u32)tzn, e2_pow(fri_alpha, C + tz0)) : 0,
-           w_q = plan(4, e2_pow(fri_alpha, C + Z));
-    (void)one;
+    const size_t tc0 = S ? (size_t)S->comm.rank * GS : 0, tcn = S ? S->cr : C, tzn = S ? S->zr : Z;
+    const u64 gstride = (u64)GS * RW;
+    size_t w_t = tcn ? plan((u32)tcn, e2_pow(fri_alpha, RW > 1 ? tc0 : 0), gstride) : 0, w_z = tzn ? plan((u32)tzn, e2_pow(fri_alpha, C + (RW > 1 ? tc0 : 0)), gstride) : 0,
+           w_q = plan(4, e2_pow(fri_alpha, C + Z), GS);
     if (wall.size() > 4096) return fail(SBN_ERR_UNSUPPORTED, "too many FRI combine groups");
     HIPC(hipMemcpyAsync(P->d_w, wall.data(), wall.size() * sizeof(u64), hipMemcpyHostToDevice, st));
     // alpha^k, k < GS, as two planes in the quotient's alpha-power buffer (idle now; it holds at least 1,025 words per plane)
@@ -1193,8 +1278,7 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
     if (S) {
       // F1 = sum over ranks of the partial sums: all-gather + a mod-p add kernel (RCCL has no mod-p reduction); 16 N bytes per rank
       HIPC(hipMemcpyAsync(S->comm.send_buf, f1a, 2 * n * sizeof(u64), hipMemcpyDeviceToDevice, st));
-      HIPC(stream_wait(st));  // `wall` (pageable host memory) must outlive its upload; the copy must precede the collective
-      if ((rc = split_all_gather_device(P, 2 * n))) return rc;
+      if ((rc = split_all_gather_device(P, 2 * n))) return rc;   // stream-ordered behind the copy
       hipLaunchKernelGGL(split_modadd_kernel, blocks(2 * n), dim3(256), 0, st, S->scratch, 2 * n, S->comm.world, f1a);
       HIPC(hipGetLastError());
     }
@@ -1202,7 +1286,7 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
     if ((rc = combine(P->d_q, 4, w_q, f0a, f0b, 1))) return rc;
     HIPC(stream_wait(st));  // `wall` (pageable host memory) must outlive its upload
     // final_poly = alpha^(C+Z) * (F0 / (X - zeta)) + F1 / (X - g zeta), n-1 coefficients each; times X (a zero in front, plonky2
-    // 0.1.x, sbn_config.fri_final_poly_times_x) or zero-padded at the end; then lde -> m
+    // 0.1.x, sbn_config.fri_variant) or zero-padded at the end; then lde -> m
     HIPC(hipMemsetAsync(P->d_fcoef, 0, 2 * m * sizeof(u64), st));
     E2 shift2 = e2_pow(fri_alpha, C + Z);
     auto divide = [&](const u64* ca, const u64* cb, E2 z, E2 mul, int accumulate) {
@@ -1210,7 +1294,7 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
       u64 *ha = P->d_part, *hb = P->d_part + nch;
       hipLaunchKernelGGL(divide_by_linear_pass1, blocks(nch), dim3(256), 0, st, ca, cb, nch, z.a.v, z.b.v, ha, hb);
       hipLaunchKernelGGL(divide_by_linear_pass2, dim3(1), dim3(256), 0, st, ha, hb, nch, z.a.v, z.b.v);
-      hipLaunchKernelGGL(divide_by_linear_pass3, blocks(nch), dim3(256), 0, st, ca, cb, nch, z.a.v, z.b.v, ha, hb, mul.a.v, mul.b.v, P->d_fcoef, P->d_fcoef + m, accumulate, cfg.fri_final_poly_times_x);
+      hipLaunchKernelGGL(divide_by_linear_pass3, blocks(nch), dim3(256), 0, st, ca, cb, nch, z.a.v, z.b.v, ha, hb, mul.a.v, mul.b.v, P->d_fcoef, P->d_fcoef + m, accumulate, fri_times_x(cfg));
     };
     divide(f0a, f0b, zeta, E2{F(0), F(0)}, 0);
     divide(f1a, f1b, zeta_next, shift2, 1);
@@ -1343,7 +1427,9 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
       const u32 owner = idx[q] >> (P->lde_log - S->log_r);
       memcpy(qwords.data() + (size_t)q * P->qstride, all.data() + ((size_t)owner * nq + q) * split_section, split_section * sizeof(u64));
     }
-    P->stage_ms[ST_COUNT + EX_COMM_MS] = (float)(S->comm_s * 1e3);
+    float xms = 0;   // device time inside the exchanges (waiting for the peers' blocks included)
+    for (size_t i = 0; i + 1 < S->tev_used; i += 2) { float t = 0; HIPC(hipEventElapsedTime(&t, S->tev[i], S->tev[i + 1])); xms += t; }
+    P->stage_ms[ST_COUNT + EX_COMM_MS] = xms;
   }
 
   // assemble canonical proof words (layout: include/sbn.h) -----------------------------------------
@@ -1453,7 +1539,7 @@ extern "C" int sbn_poseidon_permute_host(uint64_t* states, size_t count, int use
 extern "C" int sbn_set_device(int device) {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return fail(SBN_ERR_NO_DEVICE, "device %d not available", device);
-  g_device = device;
+  t_device = device; g_default_device.store(device);
   return SBN_OK;
 }
 extern "C" int sbn_device_count(void) { int n = 0; return hipGetDeviceCount(&n) == hipSuccess ? n : 0; }
@@ -1466,7 +1552,7 @@ extern "C" int sbn_split_exchange_bytes(const sbn_air_desc* air, const sbn_confi
   AirShape as;
   if (!air_shape(air, cfg, as)) return fail(SBN_ERR_BAD_ARG, "unknown air kind / num_io");
   size_t sw;
-  return split_sizes(as, degree_bits, cfg->rate_bits, world, 64, send_bytes, recv_bytes, &sw);
+  return split_sizes(as, degree_bits, cfg->rate_bits, world, SPLIT_BLOCK, send_bytes, recv_bytes, &sw, nullptr);
 }
 extern "C" int sbn_split_prover_create(const sbn_air_desc* air, const sbn_config* cfg, uint32_t degree_bits, const sbn_comm* comm, sbn_split_prover** out) {
   if (!out || !comm) return fail(SBN_ERR_BAD_ARG, "null argument");

@@ -225,7 +225,7 @@ extern "C" int sbn_verify(const sbn_air_desc* air, const sbn_config* cfg, const 
     E2 sum = (e0 - red0) * e2_inv(E2(subgroup_x) - zeta);
     sum = sum * shift1 + (e1 - red1) * e2_inv(E2(subgroup_x) - zeta_next);
     // plonky2 0.1.x fri_combine_initial: "Multiply the final polynomial by `X`" (PR #436): `sum * subgroup_x`
-    E2 old_eval = cfg->fri_final_poly_times_x ? sum * subgroup_x : sum;
+    E2 old_eval = fri_times_x(*cfg) ? sum * subgroup_x : sum;
     for (size_t i = 0; i < fs.arity_bits.size(); i++) {
       u32 ab = fs.arity_bits[i];
       size_t arity = (size_t)1 << ab, coset_index = x_index >> ab, within = x_index & (arity - 1);

@@ -1,0 +1,67 @@
+// AddressSanitizer / UBSan run of the PRODUCT's host-side code (host witness generators of tracegen.hip, the verifier and
+// the host constraint evaluator of verifier.hip), built host-instrumented by `make -C starky_bn254_amd/csrc san`
+// (hipcc -fsanitize=address,undefined -fno-gpu-sanitize; no GPU is touched: nothing here launches a kernel).  The C ABI
+// takes raw pointers and sizes, so this is where an off-by-one in a column map or a proof reader would show.
+//   san_host <dir>: inputs and the oracle's traces / proofs as written by tests/test_sanitizers.py and san_oracle.
+#include "../../include/sbn.h"
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace sbn { thread_local std::string g_last_error; }   // defined in prover.hip in the library proper
+
+template <class T> static std::vector<T> read_all(const std::string& path) {
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) { fprintf(stderr, "cannot open %s\n", path.c_str()); exit(2); }
+  fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET);
+  std::vector<T> v((size_t)n / sizeof(T));
+  if (fread(v.data(), sizeof(T), v.size(), f) != v.size()) exit(2);
+  fclose(f);
+  return v;
+}
+
+static int run(const std::string& dir, const char* name, int kind, size_t words_per_row, int (*gen)(const uint32_t*, size_t, uint64_t*)) {
+  const std::vector<uint32_t> in = read_all<uint32_t>(dir + "/" + (kind == SBN_AIR_MODULAR ? "modular_ops.bin" : "g1op_pts.bin"));
+  const std::vector<uint64_t> want = read_all<uint64_t>(dir + "/" + name + "_trace.bin");
+  std::vector<uint64_t> proof = read_all<uint64_t>(dir + "/" + name + "_proof.bin");
+  sbn_air_desc air{kind, 0};
+  sbn_config cfg; memset(&cfg, 0, sizeof cfg);
+  // (sbn_standard_fast_config lives in capi.hip; the values are StarkConfig::standard_fast_config's)
+  cfg.security_bits = 100; cfg.num_challenges = 2; cfg.rate_bits = 1; cfg.cap_height = 4; cfg.proof_of_work_bits = 16;
+  cfg.fri_arity_bits = 4; cfg.fri_final_poly_bits = 5; cfg.num_query_rounds = 84; cfg.fri_variant = SBN_FRI_DEFAULT;
+  const size_t rows = in.size() / words_per_row, ncols = want.size() / rows;
+  std::vector<uint64_t> trace(ncols * rows);
+  if (gen(in.data(), rows, trace.data())) { fprintf(stderr, "%s: generate_trace failed\n", name); return 1; }
+  if (trace != want) { fprintf(stderr, "%s: host witness differs from the oracle's\n", name); return 1; }
+  if (sbn_verify(&air, &cfg, (const uint8_t*)proof.data(), proof.size() * 8)) { fprintf(stderr, "%s: oracle proof rejected\n", name); return 1; }
+  // every truncation point of the header and the first sections, and a flipped word in each region, must be REJECTED
+  // cleanly (no read past the buffer)
+  for (size_t cut : {(size_t)0, (size_t)1, (size_t)11, (size_t)12, (size_t)75, proof.size() / 3, proof.size() - 1})
+    if (!sbn_verify(&air, &cfg, (const uint8_t*)proof.data(), cut * 8)) { fprintf(stderr, "%s: truncated proof (%zu words) accepted\n", name, cut); return 1; }
+  if (!sbn_verify(&air, &cfg, (const uint8_t*)proof.data(), proof.size() * 8 - 3)) { fprintf(stderr, "%s: ragged length accepted\n", name); return 1; }
+  for (size_t at : {(size_t)1, (size_t)2, (size_t)8, (size_t)10, (size_t)11, (size_t)20, proof.size() / 2, proof.size() - 2}) {
+    std::vector<uint64_t> bad = proof;
+    bad[at] ^= 5;
+    if (!sbn_verify(&air, &cfg, (const uint8_t*)bad.data(), bad.size() * 8)) { fprintf(stderr, "%s: tampered word %zu accepted\n", name, at); return 1; }
+  }
+  // the regrouped constraint evaluator on consecutive rows of the trace: vanishes on the trace domain
+  std::vector<uint64_t> lv(ncols), nv(ncols);
+  uint64_t alphas[2] = {0x123456789abcdefULL, 0xfedcba987654321ULL}, acc[2];
+  for (size_t r : {(size_t)0, (size_t)1, rows / 2}) {
+    for (size_t c = 0; c < ncols; c++) { lv[c] = trace[c * rows + r]; nv[c] = trace[c * rows + (r + 1) % rows]; }
+    if (sbn_eval_constraints_host(&air, lv.data(), nv.data(), nullptr, 0, alphas, 1, r == 0, 0, acc)) { fprintf(stderr, "%s: eval failed\n", name); return 1; }
+    if (acc[0] || acc[1]) { fprintf(stderr, "%s: constraints do not vanish on row %zu\n", name, r); return 1; }
+  }
+  printf("%s: host witness == oracle, verifier accepts / rejects as it must, constraints vanish\n", name);
+  return 0;
+}
+
+int main(int argc, char** argv) {
+  if (argc < 2) { fprintf(stderr, "usage: san_host <dir>\n"); return 2; }
+  int rc = run(argv[1], "modular", SBN_AIR_MODULAR, 16, sbn_generate_trace_modular);
+  rc |= run(argv[1], "g1op", SBN_AIR_G1_OP, 32, sbn_generate_trace_g1_op);
+  return rc;
+}

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""One rank of a split proof (test infrastructure; started by tests/test_split_gpu.py and tools/run_split.sh).
+"""One rank of a split proof (test infrastructure; started by tests/test_split_gpu.py).
 
 usage: split_worker.py <g1|fq12> <num_io> <seed> <outdir> <staged 0|1>      env: RANK WORLD_SIZE MASTER_ADDR MASTER_PORT
 Every rank generates the witness on its device, proves its share and writes the proof words (rank<r>.npy) and its stage
@@ -28,7 +28,8 @@ def main():
     dev = 0 if staged else int(os.environ.get("LOCAL_RANK", rank))
     torch.cuda.set_device(dev)
     S.lib().sbn_set_device(dev)
-    dist.init_process_group("gloo" if staged else "nccl", rank=rank, world_size=world)
+    import datetime
+    dist.init_process_group("gloo" if staged else "nccl", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
     if table == "g1":
         ios, _ = O.g1exp_inputs(num_io, seed)
         stark = S.G1ExpStark(num_io)

@@ -107,13 +107,13 @@ def test_single_operation_tables_proof_bit_exact(gpu, O, golden, table, rows, se
 
 
 def test_g1stark_proof_without_the_times_x_step(gpu, O):
-    """sbn_config.fri_final_poly_times_x = 0 (later upstream plonky2: no multiply-by-X of the FRI final polynomial):
+    """sbn_config.fri_variant = SBN_FRI_PLAIN (later upstream plonky2: no multiply-by-X of the FRI final polynomial):
     GPU proof bytes == the oracle's in the same mode, and differ from the default mode's."""
     pts, _ = O.g1op_inputs(1024, 3)
     stark = gpu.G1Stark()
     trace = stark.generate_trace(pts)
     cfg = stark.config()
-    cfg.fri_final_poly_times_x = 0
+    cfg.fri_variant = gpu.api.FRI_PLAIN
     proof = gpu.prove(stark, cfg, trace, np.zeros(0, dtype=np.uint64))
     try:
         O.set_final_poly_times_x(False)

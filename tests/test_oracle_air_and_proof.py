@@ -114,8 +114,8 @@ def test_fri_final_poly_times_x_switch(O, S, g1op_case):
     kept behind a switch: each verifier (oracle and product host verifier) accepts its own form and rejects the other."""
     stark = S.G1Stark()
     cfg1, cfg0 = stark.config(), stark.config()
-    assert cfg1.fri_final_poly_times_x == 1
-    cfg0.fri_final_poly_times_x = 0
+    assert cfg1.fri_variant == S.api.FRI_TIMES_X
+    cfg0.fri_variant = S.api.FRI_PLAIN
     w1 = g1op_case["proof"]
     try:
         O.set_final_poly_times_x(False)
@@ -132,6 +132,11 @@ def test_fri_final_poly_times_x_switch(O, S, g1op_case):
     for w, cfg in ((w1, cfg0), (w0, cfg1)):
         with pytest.raises(S.SbnError):
             S.verify_stark_proof(stark, S.Proof(w, 9), cfg)
+    # a zero-initialised field selects the default protocol, not the other one (include/sbn.h sbn_fri_variant)
+    cfgz = stark.config()
+    cfgz.fri_variant = S.api.FRI_DEFAULT
+    S.verify_stark_proof(stark, S.Proof(w1, 9), cfgz)
+    assert S.lib().sbn_abi_version() == 3
 
 
 @pytest.mark.parametrize("where", ["trace_cap", "opening", "fri_cap", "query_leaf", "final_poly", "pow", "truncate", "noncanonical"])

@@ -1,0 +1,114 @@
+"""The reference-parity hand-over kit (tests/parity_kit.py, tests/golden/parity_kit/*.json).
+
+CPU: the committed kit is what the oracle produces today -- inputs, witness digests and every stage of prove() in both
+FRI variants -- and agrees with tests/golden/proof_digests.json.  GPU: the device prover's proof of the kit's inputs
+matches the kit STAGE BY STAGE (the first differing stage is named), which is what the Rust side
+(integration/rust/starky-bn254-amd/tests/parity.rs) prints for the reference's own prover.
+"""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import parity_kit as K
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KIT_DIR = os.path.join(ROOT, "tests", "golden", "parity_kit")
+CASES = ["modular_rows512_seed6", "g1op_rows512_seed0", "fq12expu64_io16_seed5", "fq12exp_io16_seed3", "g1exp_io128_seed1", "fqexp_io128_seed4",
+         "g2exp_io128_seed2"]
+# (inputs, trace) generators of the oracle per table
+GEN = {"ModularStark": ("modular_inputs", "modular_trace"), "G1Stark": ("g1op_inputs", "g1op_trace"), "G1ExpStark": ("g1exp_inputs", "g1exp_trace"),
+       "G2ExpStark": ("g2exp_inputs", "g2exp_trace"), "Fq12ExpStark": ("fq12exp_inputs", "fq12exp_trace"),
+       "Fq12ExpU64Stark": ("fq12expu64_inputs", "fq12expu64_trace"), "FqExpStark": ("fqexp_inputs", "fqexp_trace")}
+
+
+def load(case):
+    return json.load(open(os.path.join(KIT_DIR, case + ".json")))
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_kit_file_is_complete_and_matches_the_proof_digests(case, golden):
+    kit = load(case)
+    assert set(kit["stages"]) == {"times_x", "plain"}
+    for v, d in kit["stages"].items():
+        assert [k for k in K.STAGES if k not in d] == [], v
+        assert d["pow_ok"] and len(d["query_indices"]) == 84 and len(d["trace_cap"]) == 64 and len(d["final_poly"]) == 64
+        assert len(d["fri_commit_caps"]) == len(d["fri_betas"])
+    # the two FRI variants share every stage up to the FRI batch challenge and part ways at the first FRI commitment
+    a, b = kit["stages"]["times_x"], kit["stages"]["plain"]
+    assert K.first_difference(a, b) == "fri_commit_caps"
+    g = golden["proof_digests"][case]
+    assert kit["stages"]["times_x"]["proof"] == {"sha256": g["proof_sha256"], "words": g["proof_words"]}
+    assert kit["trace_sha256"] == g["trace_sha256"]
+    assert len(kit["inputs_u32"]) == int(np.prod(kit["inputs_shape"]))
+
+
+def _oracle_case(O, kit):
+    fin, ftr = GEN[kit["table"]]
+    size = kit["num_io"] or kit["rows"]
+    inputs, _ = getattr(O, fin)(size, kit["seed"])
+    assert [int(x) for x in np.asarray(inputs, dtype=np.uint32).reshape(-1)] == kit["inputs_u32"], "the committed inputs are not the seeded ones"
+    res = getattr(O, ftr)(inputs)
+    trace, pi = res if isinstance(res, tuple) else (res, np.zeros(0, dtype=np.uint64))
+    return inputs, trace, pi
+
+
+# G1ExpStark(128) is the headline workload: its default-variant stages are regenerated here too (about a minute on 8 cores)
+@pytest.mark.parametrize("case,variants", [("modular_rows512_seed6", ("times_x", "plain")), ("g1op_rows512_seed0", ("times_x", "plain")),
+                                           ("fq12expu64_io16_seed5", ("times_x",)), ("g1exp_io128_seed1", ("times_x",))])
+def test_oracle_regenerates_the_kit(O, case, variants):
+    kit = load(case)
+    inputs, trace, pi = _oracle_case(O, kit)
+    assert hashlib.sha256(trace.tobytes()).hexdigest() == kit["trace_sha256"]
+    assert hashlib.sha256(np.asarray(pi, dtype=np.uint64).tobytes()).hexdigest() == kit["public_inputs_sha256"]
+    for v in variants:
+        try:
+            O.set_final_poly_times_x(v == "times_x")
+            w, _ = O.prove(kit["air_kind"], kit["num_io"], trace, pi)
+        finally:
+            O.set_final_poly_times_x(True)
+        got = json.loads(json.dumps(K.stage_digests(w, O.poseidon_permute)))
+        assert K.first_difference(got, kit["stages"][v]) is None, (v, K.first_difference(got, kit["stages"][v]))
+
+
+def test_transcript_replay_uses_the_plain_poseidon_definition(O, golden):
+    """The kit's challenger hashes with the oracle's plain-definition permutation, which is pinned by plonky2's published
+    test vectors (tests/golden/poseidon_kat.json): the replay cannot drift with the fast forms the provers use."""
+    for v in golden["poseidon_kat"]["vectors"]:
+        assert O.poseidon_permute([int(x, 16) for x in v["input"]]) == [int(x, 16) for x in v["output"]]
+    ch = K.Challenger(O.poseidon_permute)
+    ch.observe_words(range(1, 20))
+    a = [ch.challenge() for _ in range(10)]
+    probe = O.challenger_probe(list(range(1, 20)), 10)
+    assert a == [int(x) for x in probe]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES)
+def test_gpu_proof_matches_the_kit_stage_by_stage(S, O, case):
+    """Device witness (Exp tables) or host witness (single-operation tables) from the kit's committed inputs, proved on the
+    GPU in both FRI variants: every stage equals the kit's; a mismatch names the first stage that differs."""
+    if S.lib().sbn_device_count() < 1:
+        pytest.fail("no HIP device")
+    kit = load(case)
+    table = kit["table"]
+    inputs = np.array(kit["inputs_u32"], dtype=np.uint32).reshape(kit["inputs_shape"])
+    stark = getattr(S, table)(kit["num_io"]) if kit["num_io"] else getattr(S, table)()
+    bits = kit["rows"].bit_length() - 1
+    for v in ("times_x", "plain"):
+        cfg = stark.config()
+        cfg.fri_variant = S.api.FRI_TIMES_X if v == "times_x" else S.api.FRI_PLAIN
+        if kit["num_io"]:
+            pr = S.Prover(stark, cfg, bits)
+            pi = pr.generate_trace(inputs)
+            assert hashlib.sha256(np.asarray(pi, dtype=np.uint64).tobytes()).hexdigest() == kit["public_inputs_sha256"]
+            proof = pr.prove()
+            pr.close()
+        else:
+            trace = stark.generate_trace(inputs)
+            assert hashlib.sha256(trace.tobytes()).hexdigest() == kit["trace_sha256"]
+            proof = S.prove(stark, cfg, trace, np.zeros(0, dtype=np.uint64))
+        got = json.loads(json.dumps(K.stage_digests(proof.words, O.poseidon_permute)))
+        assert K.first_difference(got, kit["stages"][v]) is None, (case, v, K.first_difference(got, kit["stages"][v]))

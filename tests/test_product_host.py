@@ -359,6 +359,73 @@ def test_rust_shim_declarations_match_the_header():
     assert 'from_le_bytes(*b"SNBPROV1")' in conv and int.from_bytes(b"SNBPROV1", "little") == 0x31564F5250424E53
 
 
+def _split_top_level(args):
+    out, depth, cur = [], 0, ""
+    for ch in args:
+        if ch in "(<[{":
+            depth += 1
+        elif ch in ")>]}":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur.strip())
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur.strip())
+    return out
+
+
+def _call_args(src, opener):
+    """argument text of every call `opener ... )` in src (balanced parentheses)"""
+    out, at = [], 0
+    while True:
+        i = src.find(opener, at)
+        if i < 0:
+            return out
+        j, depth = i + len(opener), 1
+        while depth:
+            depth += {"(": 1, ")": -1}.get(src[j], 0)
+            j += 1
+        out.append(src[i + len(opener):j - 1])
+        at = j
+
+
+def test_rust_shim_prove_and_verify_have_the_reference_call_shape():
+    """The shim's `prove` / `verify_stark_proof` take exactly the arguments the reference's call sites pass
+    (prove::<F, C, _, D>(stark, &inner_config, trace, pi.try_into().unwrap(), &mut TimingTree::default()) and
+    verify_stark_proof(stark, inner_proof.clone(), &inner_config): src/curves/g1/exp.rs:818-826,
+    src/curves/g1/circuit.rs:192-200), with starky's generic parameter list <F, C, S, const D: usize>, so that those call
+    expressions compile against the shim unchanged.  The reference files are read when present (this container)."""
+    lib_rs = open(os.path.join(ROOT, "integration", "rust", "starky-bn254-amd", "src", "lib.rs")).read()
+    m = re.search(r"^pub fn prove<([^>]*)>\((.*?)\)\s*->\s*Result<StarkProofWithPublicInputs<F, C, D>>\s*where(.*?)\{", lib_rs, re.S | re.M)
+    assert m, "prove"
+    assert [g.strip() for g in m.group(1).split(",")] == ["F", "C", "S", "const D: usize"]
+    params = _split_top_level(m.group(2))
+    assert [p.split(":")[0].strip() for p in params] == ["stark", "config", "trace_poly_values", "public_inputs", "timing"]
+    assert [p.split(":", 1)[1].strip() for p in params] == ["S", "&StarkConfig", "Vec<PolynomialValues<F>>", "Vec<F>", "&mut TimingTree"]
+    assert "S: Stark<F, D> + SbnTable" in m.group(3)
+    v = re.search(r"^pub fn verify_stark_proof<([^>]*)>\((.*?)\)\s*->\s*Result<\(\)>", lib_rs, re.S | re.M)
+    assert v, "verify_stark_proof"
+    assert [g.strip() for g in v.group(1).split(",")] == ["F", "C", "S", "const D: usize"]
+    vparams = _split_top_level(v.group(2))
+    assert [p.split(":", 1)[1].strip() for p in vparams] == ["S", "StarkProofWithPublicInputs<F, C, D>", "&StarkConfig"]
+    assert "words_from_proof" in open(os.path.join(ROOT, "integration", "rust", "starky-bn254-amd", "src", "convert.rs")).read()
+    for rel in ("src/curves/g1/exp.rs", "src/curves/g1/circuit.rs", "src/curves/g2/circuit.rs", "src/fields/fq12/circuit.rs"):
+        path = os.path.join("/root/reference", rel)
+        if not os.path.exists(path):
+            continue
+        src = open(path).read()
+        calls = _call_args(src, "prove::<F, C, _, D>(")
+        assert calls, rel
+        for c in calls:
+            assert len(_split_top_level(c)) == len(params), (rel, c)
+        vcalls = _call_args(src, " verify_stark_proof(")
+        assert vcalls, rel
+        for c in vcalls:
+            assert len(_split_top_level(c)) == len(vparams), (rel, c)
+
+
 @pytest.mark.parametrize("table,num_io", [("G1Stark", 0), ("G1ExpStark", 128), ("G2ExpStark", 128), ("Fq12ExpStark", 16), ("FqExpStark", 128),
                                            ("Fq12ExpU64Stark", 16), ("ModularStark", 0), ("Fq12Stark", 0)])
 def test_regrouped_constraints_equal_the_oracle_on_random_rows(S, O, table, num_io):
@@ -389,22 +456,22 @@ def test_regrouped_constraints_equal_the_oracle_on_random_rows(S, O, table, num_
 
 
 def test_split_exchange_sizes_and_argument_errors(S):
-    """sbn_split_exchange_bytes (the staging memory a rank of the oversized-trace split needs): the send side holds the rank's
-    own LDE columns once per plane (two planes from four ranks up: the rows i + 2 travel as a second plane), the receive
-    side the row-sharded trace and Z matrices plus the gather scratch; a world that is not a power of two <= 16 is refused
-    when the prover is created (here: no device, so creation fails earlier with NO_DEVICE)."""
+    """sbn_split_exchange_bytes (the staging memory a rank of the oversized-trace split needs): the send side holds two slots
+    of one 64-column block per plane (two planes from four ranks up: the rows i + 2 travel as a second plane; one rank: no
+    slot), the receive side the row-sharded trace and Z matrices plus the gather scratch; a world that is not a power of two
+    <= 16 is refused when the prover is created (here: no device, so creation fails earlier with NO_DEVICE)."""
     from starky_bn254_amd import split
     stark = S.G1ExpStark(128)
     cfg = stark.config()
     C, Z, n, m = 1676, 762, 1 << 16, 1 << 17
     for world, planes in ((1, 1), (2, 1), (4, 2), (8, 2)):
         sb, rb = split.exchange_bytes(stark, cfg, 16, world)
-        cmax = -(-C // world)
-        assert sb == max(cmax * m * planes, 2 * n) * 8
+        slot = planes * 64 * m if world > 1 else 0
+        assert sb == max(2 * slot, 2 * (m // world), 2 * n) * 8
         assert rb == ((C + Z) * (m // world) * planes + max(2 * m, 2 * n * world)) * 8
     import ctypes as C_
     L = S.lib()
-    comm = split._Comm(None, 0, 3, None, None, 0, 0, split._A2A(lambda *a: 0), split._AGH(lambda *a: 0))
+    comm = split._Comm(C_.sizeof(split._Comm), 0, None, 0, 3, None, None, 0, 0, split._A2A(lambda *a: 0), split._AGH(lambda *a: 0))
     h = C_.c_void_p()
     L.sbn_split_prover_create.argtypes = [C_.POINTER(S.api._AirDesc), C_.POINTER(S.api._Config), C_.c_uint32, C_.POINTER(split._Comm), C_.POINTER(C_.c_void_p)]
     rc = L.sbn_split_prover_create(C_.byref(stark._d), C_.byref(cfg._c), 16, C_.byref(comm), C_.byref(h))

@@ -63,9 +63,94 @@ def test_split_proof_equals_single_gpu_proof(S, golden, tmp_path, table, num_io,
     for r in range(world):
         assert len(words[r]) == g["proof_words"]
         assert hashlib.sha256(words[r].astype("<u8").tobytes()).hexdigest() == g["proof_sha256"], f"rank {r}"
-        assert info[r]["stage_ms"]["split_exchange_ms"] > 0
+        assert info[r]["stage_ms"]["split_exchange_ms"] > 0        # world 1: the quotient / FRI gathers still pass through the transport
     stark = S.G1ExpStark(num_io) if table == "g1" else S.Fq12ExpStark(num_io)
     S.verify_stark_proof(stark, S.Proof(words[0], (512 * num_io).bit_length() - 1), stark.config())
     print(f"{table} world {world}: second prove {[round(i['second_prove_s'], 3) for i in info]} s, "
           f"exchange {[round(i['stage_ms']['split_exchange_ms'], 1) for i in info]} ms, "
           f"sent per rank {[i['exchange_bytes_sent_per_proof'] >> 20 for i in info]} MiB")
+
+
+def _digest(words):
+    return hashlib.sha256(np.asarray(words).astype("<u8").tobytes()).hexdigest()
+
+
+@pytest.mark.parametrize("table,num_io,seed,key,world", [
+    ("fq12", 16, 3, "fq12exp_io16_seed3", 8),      # BASELINE config[4]'s world size: two cap subtrees per rank, two planes
+    ("g1", 128, 1, "g1exp_io128_seed1", 8),
+    ("fq12", 16, 3, "fq12exp_io16_seed3", 16),     # the largest world sbn.h admits: one cap subtree per rank
+    ("g1", 128, 1, "g1exp_io128_seed1", 16),
+    ("g1", 128, 1, "g1exp_io128_seed1", 2),        # (the local transport at the sizes the multi-process test covers too)
+])
+def test_split_proof_local_ranks(S, O, golden, table, num_io, seed, key, world):
+    """8 and 16 ranks -- config[4]'s world size and the maximum -- as threads of ONE process on device 0 (sbn_local_comm_create;
+    the box allows at most 6 GPU processes, and RCCL one rank per device): every rank's proof is word for word the
+    single-GPU proof = the committed digest of the oracle's proof; the exchanges are real device-to-device copies ordered by
+    events, with the pipeline (transform k+1 | exchange k | sponge k-1) running on three streams per rank."""
+    from starky_bn254_amd import split
+    if S.lib().sbn_device_count() < 1:
+        pytest.fail("no HIP device")
+    S.lib().sbn_set_device(0)
+    ios, _ = (O.g1exp_inputs if table == "g1" else O.fq12exp_inputs)(num_io, seed)
+    stark = S.G1ExpStark(num_io) if table == "g1" else S.Fq12ExpStark(num_io)
+    bits = (512 * num_io).bit_length() - 1
+    proofs, times = split.prove_local(stark, stark.config(), bits, world, ios=ios, proofs=2)
+    g = golden["proof_digests"][key]
+    for r in range(world):
+        assert len(proofs[r].words) == g["proof_words"]
+        assert _digest(proofs[r].words) == g["proof_sha256"], f"rank {r} of {world}"
+        assert times[r]["split_exchange_ms"] > 0
+    S.verify_stark_proof(stark, proofs[0], stark.config())
+    print(f"{table} world {world} (local ranks): exchange {[round(t['split_exchange_ms'], 1) for t in times]} ms")
+
+
+def test_transport_selftests(S):
+    """sbn_comm_selftest through both native transports: uneven blocks, self blocks, the all-gather form, the host all-gather.
+    RCCL at world 1 (one rank per device is all a one-GPU box allows): ncclSend / ncclRecv to itself inside a group, and
+    ncclAllGather; local at world 4 on device 0."""
+    import ctypes as C
+    import threading
+    from starky_bn254_amd import split
+    if S.lib().sbn_device_count() < 1:
+        pytest.fail("no HIP device")
+    S.lib().sbn_set_device(0)
+    rc = split.RcclComm(1 << 22, 1 << 22, 0, 1)
+    rc.selftest()
+    rc.close()
+    world = 4
+    grp = split.LocalGroup(world, 1 << 22, 1 << 22)
+    res = [None] * world
+
+    def go(r):
+        res[r] = S.lib().sbn_comm_selftest(C.byref(grp.comms[r]))
+        if res[r] != 0:
+            grp.abort()
+    th = [threading.Thread(target=go, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    grp.close()
+    assert res == [0] * world, S.lib().sbn_last_error()
+
+
+def test_split_proof_over_the_native_rccl_transport_world_1(S, O, golden):
+    """sbn_rccl_comm_create + sbn_split_prover_* with no torch.distributed anywhere: the gathers of the quotient values and
+    of the FRI partial sums run as grouped ncclSend / ncclRecv on the prover's stream, the caps / openings / query rows
+    through ncclAllGather.  World 1 is what a one-GPU box can run; the proof must be the committed one."""
+    from starky_bn254_amd import split
+    if S.lib().sbn_device_count() < 1:
+        pytest.fail("no HIP device")
+    S.lib().sbn_set_device(0)
+    ios, _ = O.fq12exp_inputs(16, 3)
+    stark = S.Fq12ExpStark(16)
+    cfg = stark.config()
+    sb, rb = split.exchange_bytes(stark, cfg, 13, 1)
+    comm = split.RcclComm(sb, rb, 0, 1)
+    sp = split.SplitProver(stark, cfg, 13, transport=comm)
+    sp.generate_trace(ios)
+    proof = sp.prove()
+    t = sp.stage_times()
+    sp.close()
+    comm.close()
+    g = golden["proof_digests"]["fq12exp_io16_seed3"]
+    assert _digest(proof.words) == g["proof_sha256"]
+    assert t["split_exchange_ms"] > 0
