@@ -1476,4 +1476,22 @@ struct Fq12MulAir : AirBase<Fq12MulAir> {
   }
 };
 
+// MyStark, the lookup unit-test table: src/utils/lookup.rs:136-213.  Four columns: inputs, table, permuted inputs, permuted
+// table; constraints = eval_lookups on columns 2 / 3; pairs (0, 2), (1, 3).  The reference's test (lookup.rs:215-229) proves it
+// on the crate's ONLY fixed input, inputs [6, 3, 1, 1, 0, 0, 0, 0] against table 0..7 (lookup.rs:154-161): 8 rows -- the one
+// workload whose trace a Rust run reproduces without any seeded generator, hence the first entry of the parity kit.  Oracle
+// only: 8 rows are far below anything the device kernels are built for (the product returns SBN_ERR_UNSUPPORTED).
+struct LookupAir : AirBase<LookupAir> {
+  size_t num_columns() const override { return 4; }
+  size_t num_public_inputs() const override { return 0; }
+  std::vector<std::pair<size_t, size_t>> permutation_pairs() const override { return {{0, 2}, {1, 3}}; }   // :199-204
+  template <class P> void eval_t(const P* lv, const P* nv, const P*, Consumer<P>& yc) const { eval_lookups(yc, lv, nv, 2, 3); }   // :168-180
+  std::vector<std::vector<GF>> generate_trace(const std::vector<GF>& inputs, const std::vector<GF>& table) const {   // :151-166
+    std::vector<std::vector<GF>> cols(4);
+    cols[0] = inputs; cols[1] = table;
+    permuted_cols(inputs, table, cols[2], cols[3]);
+    return cols;
+  }
+};
+
 }  // namespace orc

@@ -1,6 +1,7 @@
 // ORACLE (test infrastructure, NOT product code): C entry points for the ctypes test harness.
 // Built by oracle/Makefile into oracle/_build/liboracle.so.  Nothing under starky_bn254_amd/ may
 // load this library.
+#include <omp.h>
 #include "airs.hpp"
 #include <cstdlib>
 #include <cstdio>
@@ -17,6 +18,7 @@ static std::unique_ptr<Air> make_air(int kind, size_t num_io) {
   if (kind == 6) return std::unique_ptr<Air>(new Fq12ExpU64Air(num_io));
   if (kind == 7) return std::unique_ptr<Air>(new ModularAir());
   if (kind == 8) return std::unique_ptr<Air>(new Fq12MulAir());
+  if (kind == 9) return std::unique_ptr<Air>(new LookupAir());
   return nullptr;
 }
 static U256 u256_from_u32(const uint32_t* w) {
@@ -245,6 +247,16 @@ int orc_fq12mul_generate_trace(const uint32_t* ops, size_t rows, uint64_t* trace
   return 0;
 }
 
+// MyStark (lookup.rs:136-213): inputs / table of `rows` values each -> the 4-column trace
+int orc_lookup_generate_trace(const uint64_t* inputs, const uint64_t* table, size_t rows, uint64_t* trace_out) {
+  LookupAir air;
+  std::vector<GF> in(rows), tab(rows);
+  for (size_t i = 0; i < rows; i++) { in[i] = GF(inputs[i]); tab[i] = GF(table[i]); }
+  auto cols = air.generate_trace(in, tab);
+  for (size_t c = 0; c < 4; c++) for (size_t i = 0; i < rows; i++) trace_out[c * rows + i] = cols[c][i].v;
+  return 0;
+}
+
 // Switch of this restatement (oracle/fri.hpp FriConfig::final_poly_times_x): 1 = plonky2 0.1.x "multiply the final
 // polynomial by X" step (default), 0 = the later upstream form without it.
 static int g_final_poly_times_x = 1;
@@ -273,9 +285,12 @@ int orc_prove(int kind, size_t num_io, const uint64_t* trace, unsigned degree_bi
   return 0;
 }
 void orc_free(void* p) { free(p); }
+// OpenMP threads of the following calls (tools/oracle_scaling.py); 0 = leave as is.  Returns the maximum available.
+int orc_set_threads(int n) { if (n > 0) omp_set_num_threads(n); return omp_get_max_threads(); }
 // Stage k of the last orc_prove: name (static storage until the next prove) and wall seconds; returns the stage count.
 int orc_last_stage_seconds(int k, const char** name, double* seconds) {
-  auto& v = stage_log();
+  static std::vector<std::pair<std::string, double>> v;   // stages, then the phases inside the commitments ("commit: ...")
+  if (k < 0) { v = stage_log(); v.insert(v.end(), phase_log().begin(), phase_log().end()); }
   if (k >= 0 && (size_t)k < v.size()) { if (name) *name = v[k].first.c_str(); if (seconds) *seconds = v[k].second; }
   return (int)v.size();
 }

@@ -8,6 +8,8 @@
 #pragma once
 #include "poseidon.hpp"
 #include <algorithm>
+#include <chrono>
+#include <string>
 
 namespace orc {
 
@@ -150,6 +152,21 @@ static inline bool verify_merkle_proof_to_cap(const std::vector<GF>& leaf, size_
   return cur == cap[idx];
 }
 
+// Wall time of the phases inside from_values / from_coeffs, accumulated over the commitments of one prove() (cleared by
+// the StageTimer of prove(), read back through orc_last_stage_seconds as "commit: ..." entries): what the CPU baseline's
+// commitment time is made of, and which phases stop scaling with the thread count (tools/oracle_scaling.py).
+static inline std::vector<std::pair<std::string, double>>& phase_log() { static std::vector<std::pair<std::string, double>> v; return v; }
+struct PhaseTimer {
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  void lap(const char* name) {
+    auto n = std::chrono::steady_clock::now();
+    const double s = std::chrono::duration<double>(n - t).count();
+    t = n;
+    for (auto& e : phase_log()) if (e.first == name) { e.second += s; return; }
+    phase_log().emplace_back(name, s);
+  }
+};
+
 // fri/oracle.rs `PolynomialBatch` (blinding = false).
 struct PolynomialBatch {
   std::vector<std::vector<GF>> polynomials;  // coefficient form, length N each
@@ -164,14 +181,17 @@ struct PolynomialBatch {
     b.rate_bits = rate_bits;
     size_t m = n << rate_bits;
     unsigned lgm = b.degree_log + rate_bits;
+    PhaseTimer pt;
     std::vector<std::vector<GF>> lde(ncols);
 #pragma omp parallel for schedule(dynamic, 4)
     for (size_t c = 0; c < ncols; c++) lde[c] = coset_lde(polys[c], rate_bits, GF(GL_GENERATOR));
+    pt.lap("commit: coset LDE (per column)");
     // transpose + reverse_index_bits_in_place
     // (blocks of 64 natural-order points: every column is read in contiguous runs and the 64 destination rows stay in cache)
     b.tree.leaves.assign(m, std::vector<GF>());
 #pragma omp parallel for schedule(static)
     for (size_t i = 0; i < m; i++) b.tree.leaves[i].resize(ncols);
+    pt.lap("commit: leaf allocation");
     const size_t TB = m < 64 ? m : 64;
 #pragma omp parallel for schedule(static)
     for (size_t s0 = 0; s0 < m; s0 += TB) {
@@ -182,14 +202,20 @@ struct PolynomialBatch {
         for (size_t k = 0; k < TB; k++) dst[k][c] = col[k];
       }
     }
+    pt.lap("commit: transpose + bit reversal");
+    { std::vector<std::vector<GF>>().swap(lde); }
+    pt.lap("commit: free LDE columns");
     b.tree.build(cap_height);
+    pt.lap("commit: leaf hashes + Merkle levels");
     b.polynomials = std::move(polys);
     return b;
   }
   static PolynomialBatch from_values(const std::vector<std::vector<GF>>& values, unsigned rate_bits, unsigned cap_height) {
+    PhaseTimer pt;
     std::vector<std::vector<GF>> coeffs(values.size());
 #pragma omp parallel for schedule(dynamic, 4)
     for (size_t c = 0; c < values.size(); c++) coeffs[c] = ifft(values[c]);
+    pt.lap("commit: iFFT (per column)");
     return from_coeffs(std::move(coeffs), rate_bits, cap_height);
   }
   // get_lde_values(index, step): LDE row at natural index `index*step`.

@@ -149,7 +149,7 @@ static inline FriOpenings to_fri_openings(const StarkOpeningSet& o) {
 static inline std::vector<std::pair<std::string, double>>& stage_log() { static std::vector<std::pair<std::string, double>> v; return v; }
 struct StageTimer {
   bool on; std::chrono::steady_clock::time_point t;
-  StageTimer() : on(getenv("ORC_TIMING") != nullptr), t(std::chrono::steady_clock::now()) { stage_log().clear(); }
+  StageTimer() : on(getenv("ORC_TIMING") != nullptr), t(std::chrono::steady_clock::now()) { stage_log().clear(); phase_log().clear(); }
   void lap(const char* name) {
     auto n = std::chrono::steady_clock::now();
     const double s = std::chrono::duration<double>(n - t).count();

@@ -30,6 +30,14 @@ struct NttPassParams {
   const u64* pre;   // optional per-index input scale (coset shift powers), indexed by input index
   const u64* post;  // optional per-index output scale, indexed by output index
   u64 scale;        // scalar output scale (1/n for inverse); 1 = none
+  // fast pass only.  split = 1: this launch is one 1,024-point pass over an input whose rows 512.. are zero (the coset LDE
+  // of a 2^18-row table: 2^19 = 1,024 x 512), run as TWO 512-point passes on grid.z: DFT_1024(x)[2j + v] = DFT_512(x_r
+  // w_1024^(v r))[j].  Half v reads the same 512 rows, scaled by pre (v = 0) or pre2 (v = 1: pre2[i] = pre[i] w_1024^(row of
+  // i)), and writes the output rows of parity v.  The 64-values-per-lane form of a register-resident 1,024-point pass needs
+  // twice the registers of the 512-point one and loses its place beside the sponge waves; this form keeps
+  // the 512-point kernel's footprint and reads the (cache-resident) input twice.
+  const u64* pre2;
+  u32 split;
 };
 
 GL_HD F tw_lookup(const u64* tw, u32 tw_log, u64 e_of_order, u32 order_log) {
@@ -206,6 +214,8 @@ __global__ __launch_bounds__(256) void ntt_fast_pass_kernel(NttPassParams p, u32
   constexpr u32 R = 256u << LOG_B;
   const size_t col = blockIdx.y;
   const size_t t0 = (size_t)blockIdx.x << 4;
+  const u32 half = p.split ? blockIdx.z : 0u;            // split: which parity of the 1,024-point pass's outputs
+  const u64* __restrict__ pre = half ? p.pre2 : p.pre;
   const u64* in = p.in + col * p.in_col_stride;
   u64* out = p.out + col * p.out_col_stride;
   // work item = (g, t): g = residue of r mod 16 within a 256-block, t = tile column.  For pass B (r contiguous in
@@ -230,7 +240,7 @@ __global__ __launch_bounds__(256) void ntt_fast_pass_kernel(NttPassParams p, u32
       u64 v = 0;
       if (gi < p.n_in) {
         v = in[gi];
-        if (p.pre) v = nw::mul(v, p.pre[gi]);
+        if (pre) v = nw::mul(v, pre[gi]);
       }
       x[b][q] = v;
     }
@@ -274,6 +284,7 @@ __global__ __launch_bounds__(256) void ntt_fast_pass_kernel(NttPassParams p, u32
       u32 k2 = (kperm * m) & 15;
       u32 k256 = k1 + 16 * k2;                       // frequency inside the 256-point block
       u32 k = LOG_B == 0 ? k256 : (k256 * NB + b);   // DIF: block b holds outputs k = 2 k256 + b
+      if (LOG_B == 1) k = (k << p.split) + half;      // split: this 512-point pass yields the outputs 2 k + half of the 1,024-point one
       u64 v = x[b][pidx];
       if (p.twiddle) v = nw::mul(v, tw_lookup(p.tw, p.tw_log, (u64)k * tg, p.log_n).v);
       if (p.scale != 1) v = nw::mul(v, p.scale);
@@ -289,6 +300,12 @@ __global__ __launch_bounds__(256) void ntt_fast_pass_kernel(NttPassParams p, u32
 __global__ void pow_table_kernel(u64* out, size_t n, u64 base) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = f_pow(F(base), i).v;
+}
+// out[i] = shift[i] * w_m^((i >> log_s) << log_s), i < n = m/2: the input scale of the odd half of a split first pass
+// (NttPassParams::pre2; tw = the forward table w_m^e, e < m/2).
+__global__ void shift_odd_table_kernel(u64* out, size_t n, const u64* __restrict__ shift, const u64* __restrict__ tw, u32 log_s) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (F(shift[i]) * F(tw[(i >> log_s) << log_s])).v;
 }
 // v[i] *= base^i, for the small FRI layers.
 __global__ void scale_pow_kernel(u64* v, size_t n, u64 base) {

@@ -98,6 +98,7 @@ struct sbn_prover {
   std::vector<DevTree> fri_trees;
   // tables
   u64 *d_tw_f = nullptr, *d_tw_i = nullptr, *d_shift = nullptr, *d_shift_inv = nullptr;
+  u64 *d_shift_odd = nullptr;   // 2^19-point LDE (1,024 x 512): 7^i w_1024^(i >> 9), the input scale of the odd half of its split first pass
   u64 *d_xs = nullptr, *d_lag_first = nullptr, *d_lag_last = nullptr;
   u64 *d_apow = nullptr;  // [2][apow_n]
   size_t apow_n = 0;
@@ -177,7 +178,11 @@ static int ntt_columns(sbn_prover* P, const u64* in, size_t in_cs, u64* out, siz
     };
     if (P->fast_ntt && pa.log_r == 9 && log_n2 >= 4) pa.log_t = 4;  // the fast kernel always uses 16-wide tiles
     if (P->fast_ntt && pb.log_r == 9 && log_n1 >= 4) pb.log_t = 4;
-    ga = dim3((unsigned)(n2 >> pa.log_t), (unsigned)nc); gb = dim3((unsigned)(n1 >> pb.log_t), (unsigned)nc);
+    // 1,024-point first pass over an input whose rows 512.. are zero (the 2^19-point coset LDE): two 512-point fast passes
+    // on grid.z (kernels.cuh NttPassParams::split) instead of the generic radix-2 pass
+    const bool split_a = P->fast_ntt && !inverse && pa.log_r == 10 && log_n2 >= 4 && pa.in_st == 1 && n_in <= (size_t)512 * pa.in_sr && pre == P->d_shift && P->d_shift_odd;
+    if (split_a) { pa.log_r = 9; pa.log_t = 4; pa.split = 1; pa.pre2 = P->d_shift_odd; }
+    ga = dim3((unsigned)(n2 >> pa.log_t), (unsigned)nc, split_a ? 2u : 1u); gb = dim3((unsigned)(n1 >> pb.log_t), (unsigned)nc);
     la = ((size_t)1 << pa.log_r) * ((1u << pa.log_t) + 1) * 8; lb = ((size_t)1 << pb.log_r) * ((1u << pb.log_t) + 1) * 8;
     launch(pa, ga, la);
     launch(pb, gb, lb);
@@ -549,6 +554,7 @@ static int create_ctx(const sbn_air_desc* air, const sbn_config* cfg, uint32_t d
   acc(dmalloc(&P->d_q, 2 * m)); acc(dmalloc(&P->d_qlde, 4 * m));
   acc(tree_alloc(P->tree_q, m, cfg->cap_height));
   acc(dmalloc(&P->d_tw_f, m / 2)); acc(dmalloc(&P->d_tw_i, m / 2)); acc(dmalloc(&P->d_shift, m)); acc(dmalloc(&P->d_shift_inv, m));
+  { const char* se = getenv("SBN_NTT_SPLIT1024"); if (P->lde_log == 19 && !(se && se[0] == '0')) acc(dmalloc(&P->d_shift_odd, n)); }   // =0: generic first pass (A/B)
   acc(dmalloc(&P->d_xs, m)); acc(dmalloc(&P->d_lag_first, m)); acc(dmalloc(&P->d_lag_last, m));
   P->apow_n = apow_len(as.nconstraints, as.nzs);
   acc(dmalloc(&P->d_apow, (size_t)SBN_NCH * P->apow_n));
@@ -590,6 +596,7 @@ static int create_ctx(const sbn_air_desc* air, const sbn_config* cfg, uint32_t d
   hipLaunchKernelGGL(pow_table_kernel, blocks(m), dim3(256), 0, P->stream, P->d_shift, m, (u64)GL_GEN);
   hipLaunchKernelGGL(pow_table_kernel, blocks(m), dim3(256), 0, P->stream, P->d_shift_inv, m, f_inv(F(GL_GEN)).v);
   hipLaunchKernelGGL(domain_tables_kernel, blocks(m), dim3(256), 0, P->stream, P->d_xs, P->d_lag_first, P->d_lag_last, m, P->lde_log, degree_bits);
+  if (P->d_shift_odd) hipLaunchKernelGGL(shift_odd_table_kernel, blocks(n), dim3(256), 0, P->stream, P->d_shift_odd, n, P->d_shift, P->d_tw_f, 9u);
   // permutation pairs
   {
     std::vector<PairCols> pairs(Z);
@@ -622,7 +629,7 @@ extern "C" void sbn_prover_destroy(sbn_prover* P) {
   (void)hipSetDevice(P->device);
   u64* bufs[] = {P->d_trace, P->d_coef, P->d_lde, P->d_tmp, P->d_zval, P->d_zcoef, P->d_zlde, P->d_q, P->d_qlde, P->tree_t.d, P->tree_z.d,
                  P->tree_q.d, P->d_tw_f, P->d_tw_i, P->d_shift, P->d_shift_inv, P->d_xs, P->d_lag_first, P->d_lag_last, P->d_apow, P->d_zpow,
-                 P->d_open, P->d_part, P->d_w, P->d_fa, P->d_fcoef, P->d_fcoef2, P->d_pow, P->d_qbuf};
+                 P->d_open, P->d_part, P->d_w, P->d_fa, P->d_fcoef, P->d_fcoef2, P->d_pow, P->d_qbuf, P->d_shift_odd};
   for (u64* b : bufs) if (b) (void)hipFree(b);
   for (u64* b : P->fri_vals) if (b) (void)hipFree(b);
   for (auto& t : P->fri_trees) if (t.d) (void)hipFree(t.d);

@@ -38,3 +38,32 @@ def gather_digests(local, dist):
     for d in out:
         merged.update(d)
     return merged
+
+
+def effective_cpus():
+    """CPUs this process may really use: the smaller of the affinity mask and the cgroup CPU quota (a GPU box hands a
+    container all 256 hardware threads in /proc but only a share of them -- 16 per GPU on the pool this was built on; 256
+    worker threads on such a share run slower than 32).  Falls back to os.cpu_count()."""
+    import math
+    import os
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    quota = None
+    try:                                                      # cgroup v2
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = int(q) / int(period)
+    except (OSError, ValueError):
+        try:                                                  # cgroup v1
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and period > 0:
+                quota = q / period
+        except (OSError, ValueError):
+            pass
+    if quota:
+        n = max(1, min(n, int(math.ceil(quota))))
+    return n

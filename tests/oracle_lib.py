@@ -544,6 +544,21 @@ def fq12expu64_trace(ios):
 # ---- the reference's single-operation test tables: ModularStark (src/modular/modular.rs:361-537), Fq12Stark (src/fields/fq12/mul.rs:355-517)
 AIR_MODULAR = 7
 AIR_FQ12_MUL = 8
+AIR_LOOKUP = 9      # oracle only: MyStark, the lookup unit-test table (src/utils/lookup.rs:136-213), 8 rows in the reference's test
+
+
+def lookup_fixed_inputs():
+    """The crate's only fixed test input (src/utils/lookup.rs:154-161): inputs and table of MyStark::generate_trace."""
+    return np.array([6, 3, 1, 1, 0, 0, 0, 0], dtype=np.uint64), np.arange(8, dtype=np.uint64)
+
+
+def lookup_trace(inputs, table):
+    """MyStark::generate_trace (lookup.rs:151-166): columns inputs, table, permuted inputs, permuted table."""
+    inputs = np.ascontiguousarray(inputs, dtype=np.uint64)
+    table = np.ascontiguousarray(table, dtype=np.uint64)
+    trace = np.zeros((4, len(inputs)), dtype=np.uint64)
+    lib().orc_lookup_generate_trace(ptr(inputs), ptr(table), len(inputs), ptr(trace))
+    return trace
 
 
 def modular_inputs(rows, seed):

@@ -35,7 +35,7 @@ def test_poseidon_permutation_batch(gpu, O, golden):
     assert e.value.code == -2
 
 
-@pytest.mark.parametrize("ncols,n", [(1, 512), (3, 512), (4, 1024), (5, 512), (8, 2048), (9, 4096), (20, 1024), (17, 65536), (130, 16384)])
+@pytest.mark.parametrize("ncols,n", [(1, 512), (3, 512), (4, 1024), (5, 512), (8, 2048), (9, 4096), (20, 1024), (17, 65536), (130, 16384), (3, 262144), (66, 262144)])
 def test_commit_matches_oracle(gpu, O, ncols, n):
     """PolynomialBatch::from_values: iNTT, coset LDE (shift 7, blow-up 2), Poseidon leaves, Merkle cap.
     Covers <=4 columns (hash_or_noop copies the row), a ragged last sponge block, and NTT sizes that
