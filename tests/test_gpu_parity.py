@@ -255,7 +255,7 @@ def test_g1exp_device_witness_generation_matches_oracle(gpu, O, g1exp_case, g1ex
         prover.close()
 
 
-@pytest.mark.parametrize("table,num_io", [("g1", 256), ("fq", 512)])
+@pytest.mark.parametrize("table,num_io", [("g1", 256), ("fq", 512), ("g2", 256)])
 def test_device_witness_above_2pow16_rows(gpu, O, table, num_io):
     """The reference pads the instance list to any power of two >= 128 (src/curves/g1/circuit.rs:273-277), i.e. tables of
     2^17, 2^18 ... rows, where the multiplicities of the u16 range check no longer fit 16-bit counters (the table column then
@@ -265,6 +265,10 @@ def test_device_witness_above_2pow16_rows(gpu, O, table, num_io):
         ios, _ = O.g1exp_inputs(num_io, 21)
         stark = gpu.G1ExpStark(num_io)
         e0 = 32
+    elif table == "g2":                                      # include/sbn.h: G2_EXP device witness covers 2^16 .. 2^18 rows
+        ios, _ = O.g2exp_inputs(num_io, 23)
+        stark = gpu.G2ExpStark(num_io)
+        e0 = 64
     else:
         ios, _ = O.fqexp_inputs(num_io, 22)
         stark = gpu.FqExpStark(num_io)
@@ -290,6 +294,38 @@ def test_device_witness_above_2pow16_rows(gpu, O, table, num_io):
         assert proof.recover_degree_bits(cfg) == bits
     finally:
         prover.close()
+
+
+def test_load_trace_device_and_trace_device_ptr(gpu, O, g1exp_case):
+    """sbn_prover_trace_device_ptr / sbn_prover_load_trace_device (include/sbn.h): a trace that is already resident in HBM --
+    here the witness one prover generated on the device -- is handed to a second prover by device pointer (device-to-device
+    copy, nothing crosses PCIe); a caller may also fill the prover's own trace buffer in place and declare it loaded.  Both
+    give the proof of the host-loaded trace."""
+    stark = gpu.G1ExpStark(128)
+    cfg = stark.config()
+    a = gpu.Prover(stark, cfg, 16)
+    b = gpu.Prover(stark, cfg, 16)
+    try:
+        pi = a.generate_trace(g1exp_case["ios"])
+        assert np.array_equal(pi, g1exp_case["pi"])
+        ref = a.prove()
+        ptr = a.trace_device_ptr()
+        assert ptr
+        b.load_trace_device(ptr, pi)                         # another prover's buffer: copied device to device
+        assert np.array_equal(b.read_trace(), g1exp_case["trace"])
+        assert np.array_equal(b.prove().words, ref.words)
+        b.load_trace_device(b.trace_device_ptr(), pi)        # the prover's own buffer, filled in place: no copy at all
+        assert np.array_equal(b.prove().words, ref.words)
+        with pytest.raises(gpu.SbnError):
+            b.load_trace_device(ptr, pi[:-1])                # wrong number of public inputs
+        bad = pi.copy()
+        bad[0] = P                                           # not canonical
+        with pytest.raises(gpu.SbnError) as e:
+            b.load_trace_device(ptr, bad)
+        assert e.value.code == -2
+    finally:
+        a.close()
+        b.close()
 
 
 def test_g1exp_2pow17_rows_full_oracle_proof_equality(gpu, O):
