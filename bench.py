@@ -570,26 +570,25 @@ def synthetic_ios_g2(num_io, rng, P):
 def cpu_baseline(trace, pi, table="g1"):
     """The CPU oracle's prove() (a restatement "port", OpenMP) on the SAME trace, on the host cores this process really has.
     Sample: one full proof -- the smallest unit of this workload (the table cannot be smaller than 2^16 rows).
-    Thread count: the box shows every hardware thread of the host (256) but gives a container a share of them, and the
-    oracle is SLOWER with 256 threads than with 32 on such a share (profiles/r3_oracle_scaling.jsonl).  So the count is the
-    cgroup / affinity limit when there is one, and otherwise the fastest of a one-second calibration (a 2^11-row G1Stark
-    proof at 16, 32, 64, ... threads); every calibration point is reported."""
+    Thread count: the box shows every hardware thread of the host (256) but gives a container a share of them (cgroup
+    cpu.max = 16 CPUs on the pool this was built on), and the oracle is SLOWER with 256 threads than with 32 on such a share
+    (profiles/r3_oracle_scaling.jsonl).  So the count is the fastest of a short calibration (a 2^11-row G1Stark proof) over
+    the cgroup / affinity limit and twice that limit, or, when no limit is visible, over 16, 32, 64, ... threads; every
+    calibration point is reported, `cores` is the winner."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
     import oracle_lib as O
     from starky_bn254_amd.sharding import effective_cpus
     visible, eff = os.cpu_count() or 1, effective_cpus()
     calib = {}
-    threads = eff
-    if eff >= visible and visible > 16:          # no quota visible: measure which thread count this container can really use
-        pts, _ = O.g1op_inputs(2048, 3)
-        tr = O.g1op_trace(pts)
-        cands = sorted({t for t in (16, 32, 64, 128, visible) if t <= visible})
-        for t in cands:
-            O.lib().orc_set_threads(t)
-            O.prove(O.AIR_G1_OP, 0, tr, np.zeros(0, dtype=np.uint64))                      # warm the allocator at this width
-            calib[t] = min(O.prove(O.AIR_G1_OP, 0, tr, np.zeros(0, dtype=np.uint64))[1] for _ in range(2))
-        threads = min(calib, key=calib.get)
+    pts, _ = O.g1op_inputs(2048, 3)
+    tr = O.g1op_trace(pts)
+    cands = sorted({t for t in ((eff, 2 * eff) if eff < visible else (16, 32, 64, 128, visible)) if 1 <= t <= visible})
+    for t in cands:
+        O.lib().orc_set_threads(t)
+        O.prove(O.AIR_G1_OP, 0, tr, np.zeros(0, dtype=np.uint64))                      # warm the allocator at this width
+        calib[t] = min(O.prove(O.AIR_G1_OP, 0, tr, np.zeros(0, dtype=np.uint64))[1] for _ in range(2))
+    threads = min(calib, key=calib.get)
     O.lib().orc_set_threads(threads)
     words, secs = O.prove(O.AIR_G1_EXP if table == "g1" else O.AIR_G2_EXP, NUM_IO, trace, pi)
     return {"value": 1.0 / secs, "unit": "proofs/s", "cores": threads, "kind": "port",

@@ -476,3 +476,30 @@ def test_split_exchange_sizes_and_argument_errors(S):
     L.sbn_split_prover_create.argtypes = [C_.POINTER(S.api._AirDesc), C_.POINTER(S.api._Config), C_.c_uint32, C_.POINTER(split._Comm), C_.POINTER(C_.c_void_p)]
     rc = L.sbn_split_prover_create(C_.byref(stark._d), C_.byref(cfg._c), 16, C_.byref(comm), C_.byref(h))
     assert rc in (-1, -3) and not h.value          # BAD_ARG on a GPU box, NO_DEVICE here
+
+
+def test_committed_profiles_json_parse():
+    """Every profiles/*.json is one JSON document and every *.jsonl one document per line (collection scripts keep stderr --
+    RCCL / gloo banners -- in a sibling .err file)."""
+    import glob
+    import json
+    for f in glob.glob(os.path.join(ROOT, "profiles", "*.json")):
+        json.load(open(f))
+    for f in glob.glob(os.path.join(ROOT, "profiles", "*.jsonl")):
+        for line in open(f):
+            json.loads(line)
+
+
+def test_production_library_ignores_the_quotient_diagnostic_switch():
+    """SBN_DIAG_QUOTIENT_SEGMASK (skip constraint segments, invalid proof) is compiled in only with -DSBN_DIAG."""
+    src = open(os.path.join(ROOT, "starky_bn254_amd", "csrc", "prover.hip")).read()
+    at = src.index('getenv("SBN_DIAG_QUOTIENT_SEGMASK")')
+    assert src.rfind("#ifdef SBN_DIAG", 0, at) > src.rfind("#endif", 0, at)
+    assert "SBN_DIAG" not in open(os.path.join(ROOT, "starky_bn254_amd", "csrc", "Makefile")).read().replace("SBN_DIAG_", "")
+    lib = open(S_lib_path(), "rb").read()
+    assert b"SBN_DIAG_QUOTIENT_SEGMASK" not in lib
+
+
+def S_lib_path():
+    import starky_bn254_amd as pkg
+    return pkg.lib_path()

@@ -154,3 +154,31 @@ def test_split_proof_over_the_native_rccl_transport_world_1(S, O, golden):
     g = golden["proof_digests"]["fq12exp_io16_seed3"]
     assert _digest(proof.words) == g["proof_sha256"]
     assert t["split_exchange_ms"] > 0
+
+
+def test_split_proof_at_config4_size_two_local_ranks(S, O):
+    """BASELINE config[4]'s table at full size -- Fq12ExpStark(512): 2^18 rows x 11,786 columns, 185 + 84 column blocks, send
+    slots of 0.27 GB, a 36 GB row matrix per rank -- split over two ranks (threads, one GPU; four and more ranks of this size
+    do not fit one card's HBM beside each other): the offsets and counts that only get large here (block * 64 * M words, the
+    FRI group weights of 93 own blocks, the 2^19-point split first LDE pass) must give, on both ranks, word for word the
+    single-GPU proof of the same instances, which the product verifier accepts."""
+    from starky_bn254_amd import split
+    if S.lib().sbn_device_count() < 1:
+        pytest.fail("no HIP device")
+    S.lib().sbn_set_device(0)
+    ios, _ = O.fq12exp_inputs(512, 3)
+    stark = S.Fq12ExpStark(512)
+    cfg = stark.config()
+    proofs, times = split.prove_local(stark, cfg, 18, 2, ios=ios, proofs=1)
+    assert np.array_equal(proofs[0].words, proofs[1].words)
+    split_words = proofs[0].words.copy()
+    del proofs
+    single = S.Prover(stark, cfg, 18)
+    try:
+        single.generate_trace(ios)
+        ref = single.prove()
+    finally:
+        single.close()
+    assert np.array_equal(split_words, ref.words)
+    S.verify_stark_proof(stark, ref, cfg)
+    print(f"config[4] size, 2 local ranks: exchange {[round(t['split_exchange_ms'], 1) for t in times]} ms")

@@ -1,6 +1,9 @@
 #!/bin/bash
 # Per-segment HBM traffic of the quotient kernel (run on the GPU box): one FETCH_SIZE pass per segment mask.
 #   tools/pmc_quotient_segments.sh [table] -> gpurun_out/pmc_quotient_segments.txt
+# Needs a DIAGNOSTIC build of the library: SBN_DIAG_QUOTIENT_SEGMASK is compiled in only with -DSBN_DIAG
+#   (make -C starky_bn254_amd/csrc clean && make -C starky_bn254_amd/csrc CXXFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -DSBN_DIAG");
+# a production library ignores the variable (an invalid proof must never come out of a stale export).
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out
 TABLE=${1:-g1}

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic driver for counter passes over the quotient kernel: proves G1ExpStark(128) (device witness) a few times
 WITHOUT verifying, so that SBN_DIAG_QUOTIENT_SEGMASK (run only some of the four constraint segments; the proof is then
-invalid) can be used under rocprofv3 --pmc.  usage: quotient_diag.py [table g1|g2] [proofs]"""
+invalid; compiled in only with -DSBN_DIAG, see tools/pmc_quotient_segments.sh) can be used under rocprofv3 --pmc.  usage: quotient_diag.py [table g1|g2] [proofs]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
