@@ -54,7 +54,7 @@ typedef enum sbn_status {
 /* Table kinds.  G1_OP = reference `G1Stark` (src/curves/g1/muladd.rs:462-624);
  * G1_EXP = reference `G1ExpStark` (src/curves/g1/exp.rs:232-742). */
 typedef enum sbn_air_kind { SBN_AIR_G1_OP = 1, SBN_AIR_G1_EXP = 2, SBN_AIR_G2_EXP = 3, SBN_AIR_FQ12_EXP = 4, SBN_AIR_FQ_EXP = 5, SBN_AIR_FQ12_EXP_U64 = 6,
-                              SBN_AIR_MODULAR = 7, SBN_AIR_FQ12_MUL = 8 } sbn_air_kind;
+                              SBN_AIR_MODULAR = 7, SBN_AIR_FQ12_MUL = 8, SBN_AIR_LOOKUP = 9, SBN_AIR_FLAGS = 10 } sbn_air_kind;
 /* G2_EXP = reference `G2ExpStark` (src/curves/g2/exp.rs:248-807): the same machine over Fq2 coordinates.
  * FQ12_EXP = reference `Fq12ExpStark` (src/fields/fq12/exp.rs:223-605): offset * x^e in Fq12 (flat basis of
  * plonky2-bn254 `MyFq12`: coefficient of w^k is c[k] + c[k+6]*i, w^6 = 9 + i), 512 rows per instance, num_io a
@@ -65,7 +65,13 @@ typedef enum sbn_air_kind { SBN_AIR_G1_OP = 1, SBN_AIR_G1_EXP = 2, SBN_AIR_G2_EX
  * exponent, 128 rows per instance, 6-column flags (flags_u64.rs), the exponent is ONE public input (< p).
  * MODULAR = reference `ModularStark` (src/modular/modular.rs:361-537) and FQ12_MUL = reference `Fq12Stark`
  * (src/fields/fq12/mul.rs:355-517): its single-operation test tables for the modular gadget (a * b mod p per row, 812
- * columns) and the Fq12 product (9722 columns); no public inputs, num_io ignored, any power-of-two height >= 256. */
+ * columns) and the Fq12 product (9722 columns); no public inputs, num_io ignored, any power-of-two height >= 256.
+ * LOOKUP = reference `MyStark` (src/utils/lookup.rs:136-213), its unit-test table of the lookup argument: 4 columns (inputs,
+ * table, permuted inputs, permuted table), two permutation pairs, Merkle leaves are the rows themselves (hash_or_noop); any
+ * power-of-two height >= 512, num_io ignored (the reference's own 8-row instance is below the device prover's minimum).
+ * FLAGS = reference `FlagStark` (src/utils/flags.rs:379-547), the unit-test table of the exponent-bit flags: num_io inputs
+ * of 8 u32 limbs, 512 rows each (the reference uses 16), 17 + 4 * num_io columns, NO permutation pairs -- the one table
+ * whose proof carries no permutation-Z commitment (header n_perm_zs = 0). */
 
 typedef struct sbn_air_desc {
   int32_t kind;    /* sbn_air_kind */
@@ -140,6 +146,13 @@ int sbn_generate_trace_g1_op(const uint32_t* pts, size_t rows, uint64_t* trace_o
 int sbn_generate_trace_modular(const uint32_t* ops, size_t rows, uint64_t* trace_out);
 /* Fq12Stark::generate_trace (fq12/mul.rs:375-419): ops: rows x 192 u32 = x[12] y[12] (flat-basis coefficients < p, 8 u32 limbs each). */
 int sbn_generate_trace_fq12_mul(const uint32_t* ops, size_t rows, uint64_t* trace_out);
+
+/* MyStark::generate_trace (lookup.rs:151-166) on caller-given columns: inputs[rows], table[rows] (canonical field elements;
+ * every input value must occur in the table) -> [4][rows] = inputs, table, permuted inputs, permuted table (permuted_cols,
+ * lookup.rs:60-111). */
+int sbn_generate_trace_lookup(const uint64_t* inputs, const uint64_t* table, size_t rows, uint64_t* trace_out);
+/* FlagStark::generate_trace (flags.rs:392-440): limbs: num_io x 8 u32; trace_out: [17 + 4 * num_io][512 * num_io]. */
+int sbn_generate_trace_flags(const uint32_t* limbs, size_t num_io, uint64_t* trace_out);
 
 /* Prover ---------------------------------------------------------------------------------------- */
 int sbn_prover_create(const sbn_air_desc* air, const sbn_config* cfg, uint32_t degree_bits, sbn_prover** out);

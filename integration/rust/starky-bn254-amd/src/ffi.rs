@@ -46,6 +46,9 @@ pub const SBN_AIR_FQ12_EXP_U64: i32 = 6;
 /// the reference's single-operation test tables (`ModularStark`, `Fq12Stark`)
 pub const SBN_AIR_MODULAR: i32 = 7;
 pub const SBN_AIR_FQ12_MUL: i32 = 8;
+/// the reference's unit-test tables `MyStark` (lookup.rs) and `FlagStark` (flags.rs)
+pub const SBN_AIR_LOOKUP: i32 = 9;
+pub const SBN_AIR_FLAGS: i32 = 10;
 
 extern "C" {
     pub fn sbn_abi_version() -> i32;

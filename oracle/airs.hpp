@@ -1494,4 +1494,50 @@ struct LookupAir : AirBase<LookupAir> {
   }
 };
 
+// FlagStark, the flags unit-test table: src/utils/flags.rs:379-547.  MAIN_COLS = 6 + 8 flag columns, then the rotation pulse
+// (counter, witness), the io-pulse counter and (witness, pulse) for the first and last row of every 512-row block (:372-377);
+// constraints :449-492: is_final - sum(output pulses), eval_flags, eval_periodic_pulse, eval_pulse; NO permutation pairs.
+// The reference's test proves NUM_INPUTS = 16 random inputs (:549-565); here num_io is a parameter.
+struct FlagAir : AirBase<FlagAir> {
+  size_t num_io;
+  std::vector<size_t> pulse_positions;
+  static constexpr int MAIN_COLS = 6 + NUM_INPUT_LIMBS;
+  explicit FlagAir(size_t n) : num_io(n) {
+    const size_t rpb = 2 * INPUT_LIMB_BITS * NUM_INPUT_LIMBS;
+    for (size_t i = 0; i < n; i++) { pulse_positions.push_back(i * rpb); pulse_positions.push_back(i * rpb + rpb - 1); }   // :411-417
+  }
+  size_t num_columns() const override { return MAIN_COLS + 2 + 1 + 4 * num_io; }   // :376
+  size_t num_public_inputs() const override { return 0; }
+  std::vector<std::pair<size_t, size_t>> permutation_pairs() const override { return {}; }
+  template <class P> void eval_t(const P* lv, const P* nv, const P*, Consumer<P>& yc) const {   // :449-492
+    P output = cst<P>(0);
+    for (size_t i = 1; i < 2 * num_io; i += 2) output = output + lv[get_pulse_col(MAIN_COLS + 2, (int)i)];
+    yc.constraint(lv[0] - output);
+    eval_flags(yc, lv, nv, 0);
+    eval_periodic_pulse(yc, lv, nv, 1, MAIN_COLS, 2 * INPUT_LIMB_BITS, 2 * INPUT_LIMB_BITS - 2);
+    eval_pulse(yc, lv, nv, MAIN_COLS + 2, pulse_positions);
+  }
+  // generate_trace :392-440; limbs[k] = the 8 u32 limbs of input k
+  std::vector<std::vector<GF>> generate_trace(const std::vector<std::array<uint32_t, NUM_INPUT_LIMBS>>& inputs) const {
+    assert(inputs.size() == num_io);
+    const size_t rpb = 2 * INPUT_LIMB_BITS * NUM_INPUT_LIMBS, rows = rpb * num_io;
+    std::vector<std::vector<GF>> cols(MAIN_COLS, std::vector<GF>(rows));
+    for (size_t k = 0; k < num_io; k++) {
+      std::vector<GF> lv(MAIN_COLS, GF()), nvv(MAIN_COLS, GF());
+      generate_flags_first_row(lv.data(), 0, inputs[k].data());
+      for (int c = 0; c < MAIN_COLS; c++) cols[c][k * rpb] = lv[c];
+      for (size_t i = 0; i + 1 < rpb; i++) {
+        std::fill(nvv.begin(), nvv.end(), GF());
+        generate_flags_next_row(lv.data(), nvv.data(), i, 0);
+        for (int c = 0; c < MAIN_COLS; c++) cols[c][k * rpb + i + 1] = nvv[c];
+        lv.swap(nvv);
+      }
+    }
+    generate_periodic_pulse_witness(cols, 1, 2 * INPUT_LIMB_BITS, 2 * INPUT_LIMB_BITS - 2);
+    generate_pulse(cols, pulse_positions);
+    assert(cols.size() == num_columns());
+    return cols;
+  }
+};
+
 }  // namespace orc

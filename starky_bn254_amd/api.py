@@ -13,6 +13,8 @@ import numpy as np
 AIR_G1_OP = 1
 AIR_MODULAR = 7
 AIR_FQ12_MUL = 8
+AIR_LOOKUP = 9
+AIR_FLAGS = 10
 AIR_G1_EXP = 2
 AIR_G2_EXP = 3
 AIR_FQ12_EXP = 4
@@ -27,7 +29,7 @@ EXPORTS = [
     "sbn_version", "sbn_last_error", "sbn_device_count", "sbn_set_device", "sbn_standard_fast_config",
     "sbn_air_num_columns", "sbn_air_num_public_inputs", "sbn_air_num_permutation_zs", "sbn_air_num_constraints",
     "sbn_generate_trace_g1_exp", "sbn_generate_trace_g2_exp", "sbn_generate_trace_fq12_exp", "sbn_generate_trace_fq_exp", "sbn_generate_trace_fq12_exp_u64",
-    "sbn_generate_trace_g1_op", "sbn_generate_trace_modular", "sbn_generate_trace_fq12_mul",
+    "sbn_generate_trace_g1_op", "sbn_generate_trace_modular", "sbn_generate_trace_fq12_mul", "sbn_generate_trace_lookup", "sbn_generate_trace_flags",
     "sbn_prover_create", "sbn_prover_destroy", "sbn_prover_load_trace", "sbn_prover_load_trace_device",
     "sbn_prover_prove", "sbn_prover_stage_times", "sbn_prover_stage_name", "sbn_prover_trace_device_ptr",
     "sbn_prover_generate_trace", "sbn_prover_read_trace",
@@ -92,6 +94,8 @@ def lib():
         L.sbn_generate_trace_g1_op.argtypes = [vp, sz, vp]
         L.sbn_generate_trace_modular.argtypes = [vp, sz, vp]
         L.sbn_generate_trace_fq12_mul.argtypes = [vp, sz, vp]
+        L.sbn_generate_trace_lookup.argtypes = [vp, vp, sz, vp]
+        L.sbn_generate_trace_flags.argtypes = [vp, sz, vp]
         L.sbn_prover_create.argtypes = [C.POINTER(_AirDesc), C.POINTER(_Config), u32, C.POINTER(vp)]
         L.sbn_prover_destroy.argtypes = [vp]
         L.sbn_prover_load_trace.argtypes = [vp, vp, vp, sz]
@@ -214,6 +218,41 @@ class ModularStark(_Stark):
         assert ops.shape == (rows, 16)
         trace = np.zeros((self.num_columns, rows), dtype=np.uint64)
         _check(lib().sbn_generate_trace_modular(_ptr(ops), rows, _ptr(trace)))
+        return trace
+
+
+class LookupStark(_Stark):
+    """Reference `MyStark` (src/utils/lookup.rs:136-213), the unit-test table of the lookup argument: inputs, table, permuted
+    inputs, permuted table; any power-of-two height >= 512 on the device (the reference's own 8-row instance: oracle only)."""
+    kind = AIR_LOOKUP
+
+    def __init__(self):
+        super().__init__(0)
+
+    def generate_trace(self, inputs, table):
+        """inputs, table: (rows,) uint64 canonical field elements, every input value present in the table -> (4, rows) uint64."""
+        inputs = np.ascontiguousarray(inputs, dtype=np.uint64)
+        table = np.ascontiguousarray(table, dtype=np.uint64)
+        assert inputs.shape == table.shape and inputs.ndim == 1
+        trace = np.zeros((4, inputs.shape[0]), dtype=np.uint64)
+        _check(lib().sbn_generate_trace_lookup(_ptr(inputs), _ptr(table), inputs.shape[0], _ptr(trace)))
+        return trace
+
+
+MyStark = LookupStark   # the reference's name for it (a test-module local)
+
+
+class FlagStark(_Stark):
+    """Reference `FlagStark` (src/utils/flags.rs:379-547), the unit-test table of the exponent-bit flags: num_io inputs of 8 u32
+    limbs, 512 rows each; no permutation pairs, so its proofs carry no permutation-Z commitment."""
+    kind = AIR_FLAGS
+
+    def generate_trace(self, limbs):
+        """limbs: (num_io, 8) uint32 -> (17 + 4 num_io, 512 num_io) uint64."""
+        limbs = np.ascontiguousarray(limbs, dtype=np.uint32)
+        assert limbs.shape == (self.num_io, 8)
+        trace = np.zeros((self.num_columns, 512 * self.num_io), dtype=np.uint64)
+        _check(lib().sbn_generate_trace_flags(_ptr(limbs), self.num_io, _ptr(trace)))
         return trace
 
 

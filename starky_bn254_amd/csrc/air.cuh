@@ -617,6 +617,64 @@ GL_HD void op_eval(Cons<P>& cs, const Row& row, const OpShape& S) {
   cs.merge(h_mul, row.l(S.main_cols - 1), S.gadget_cons);
 }
 
+// ---- MyStark (src/utils/lookup.rs:136-213) and FlagStark (src/utils/flags.rs:379-547): the reference's unit-test tables -------
+// MyStark: columns inputs, table, permuted inputs, permuted table; constraints = eval_lookups(2, 3); pairs (0, 2), (1, 3).
+// The smallest table of the reference (4 columns: Merkle leaves are copied rows, hash_or_noop) -- here at any power-of-two
+// height >= 512 (the reference's own 8-row instance lives in the oracle only, tests/golden/parity_kit).
+struct LookupShape {
+  static constexpr int NUM_COLS = 4, NUM_PAIRS = 2, NUM_CONSTRAINTS = 2;
+  GL_HD void pair(int z, int& lhs, int& rhs) const { lhs = z; rhs = z + 2; }   // lookup.rs:199-204
+};
+template <class P, class Row>
+GL_HD void lookup_eval(Cons<P>& cs, const Row& row) { lookup_pair(cs, row, 2, 3); }   // lookup.rs:168-180
+// FlagStark(num_io): the bit-peeling flags of the Exp tables on their own -- 14 flag columns, the rotation pulse (counter,
+// witness), the io-pulse counter and (witness, pulse) per block boundary; 512 rows per input; NO permutation pairs, so the
+// proof has no permutation-Z commitment at all (starky: uses_permutation_args() == false).
+struct FlagShape {
+  int num_io;
+  GL_HD explicit FlagShape(int n) : num_io(n) {}
+  static constexpr int MAIN_COLS = 14, START_PERIODIC = 14, START_IO_PULSES = 16;   // flags.rs:372-377: 6 + NUM_INPUT_LIMBS, + 2, + 1 + 4 inputs
+  GL_HD int num_cols() const { return MAIN_COLS + 2 + 1 + 4 * num_io; }
+  GL_HD int num_constraints() const { return 1 + FLAGS_CONSTRAINTS + 5 + 2 + 4 * num_io; }
+  GL_HD int witness_col(int i) const { return START_IO_PULSES + 1 + 2 * i; }   // pulse.rs:14
+  GL_HD int pulse_col(int i) const { return START_IO_PULSES + 2 + 2 * i; }     // pulse.rs:10
+};
+template <class P, class Row>
+GL_HD void flag_eval(Cons<P>& cs, const Row& row, const FlagShape& sh) {   // flags.rs:449-492, in its emission order
+  const P one = lift<P>(1);
+  P sum_out = lift<P>(0);
+  for (int i = 0; i < sh.num_io; i++) sum_out = sum_out + row.l(sh.pulse_col(2 * i + 1));
+  cs.c(row.l(0) - sum_out);                                  // is_final - sum of the output pulses
+  Horner2<P> hf(FLAGS_CONSTRAINTS);
+  flags_block(cs, row, 0, hf);
+  P hfv[SBN_NCH];
+  hf.value(hfv);
+  cs.merge(hfv, one, FLAGS_CONSTRAINTS);
+  {   // eval_periodic_pulse(pulse_col = is_rotate, period 64, first_pulse 62)   pulse.rs:146-170
+    const int st = FlagShape::START_PERIODIC;
+    P counter = row.l(st), witness = row.l(st + 1), is_reset = row.l(1), next_counter = row.n(st);
+    cs.cf(counter - lift<P>(1));
+    cs.ct((one - is_reset) * (next_counter - counter - one));
+    cs.ct(is_reset * next_counter);
+    P delta = counter - lift<P>(63);
+    cs.c(delta * witness + is_reset - one);
+    cs.c(delta * is_reset);
+  }
+  {   // eval_pulse over the first and last row of every block   pulse.rs:45-63
+    const int st = FlagShape::START_IO_PULSES;
+    P counter = row.l(st);
+    cs.cf(counter);
+    cs.ct(row.n(st) - counter - one);
+    for (int i = 0; i < 2 * sh.num_io; i++) {
+      u64 pos = (u64)(i >> 1) * 512 + ((i & 1) ? 511 : 0);
+      P cmp = counter - lift<P>(pos);
+      P pulse = row.l(sh.pulse_col(i));
+      cs.c(cmp * row.l(sh.witness_col(i)) + pulse - one);
+      cs.c(cmp * pulse);
+    }
+  }
+}
+
 // ---- G1ExpStark / G2ExpStark (src/curves/g1/exp.rs, src/curves/g2/exp.rs) --------------------------------
 // Both tables are the same double-and-add machine; E = 1 (Fq coordinates) or 2 (Fq2 coordinates) scales
 // the point columns (32E per point), the gadget (320E columns, 165E constraints) and the public inputs.

@@ -722,6 +722,14 @@ __global__ __launch_bounds__(256, 2) void quotient_kernel(QuotientParams p, cons
       if (seg == 2) permutation_checks(cs, row, zrow, G1OpShape(), p.num_zs, F(p.gamma0), F(p.gamma1), 0, p.zsplit);
       else permutation_checks(cs, row, zrow, G1OpShape(), p.num_zs, F(p.gamma0), F(p.gamma1), p.zsplit, p.num_zs);
     }
+  } else if (KIND == 9) {   // MyStark: two lookup constraints, two permutation pairs
+    if (PART == 0) lookup_eval(cs, row);
+    else if (PART == 2) {
+      if (seg == 2) permutation_checks(cs, row, zrow, LookupShape(), p.num_zs, F(p.gamma0), F(p.gamma1), 0, p.zsplit);
+      else permutation_checks(cs, row, zrow, LookupShape(), p.num_zs, F(p.gamma0), F(p.gamma1), p.zsplit, p.num_zs);
+    }
+  } else if (KIND == 10) {  // FlagStark: no permutation pairs, segments 1-3 are empty
+    if (PART == 0) flag_eval(cs, row, FlagShape(p.num_io));
   } else if (KIND == 7 || KIND == 8) {   // ModularStark / Fq12Stark: everything but the permutation checks is the head segment
     const OpShape sh(KIND);
     if (PART == 0) op_eval<KIND>(cs, row, sh);

@@ -284,6 +284,12 @@ static int commit_pipeline(sbn_prover* P, const u64* vals, u64* coef, u64* lde, 
   size_t ch = P->ntt_chunk;
   size_t nchunks = (ncols + ch - 1) / ch;
   if (nchunks > (size_t)MAX_CHUNKS) return fail(SBN_ERR_UNSUPPORTED, "too many column chunks");
+  if (ncols <= 4) {   // hash_or_noop: a leaf of at most 4 elements is its own digest (MyStark's 4 columns and its 2 Z columns)
+    int rc = intt_then_lde(P, vals, coef, lde, ncols);
+    if (rc) return rc;
+    P->stage_ms[ST_COUNT + ex_launches] = 0;
+    return tree_from_matrix(P, t, lde, ncols);
+  }
   // Two streams: iNTT + coset LDE of chunk k on the main stream, the sponge over the chunk's LDE on the hash stream.
   // MEASURED and dropped (profiles/r2_bench_3stream.json): a third stream for the LDE, so that the iNTT of chunk k+1 hides
   // behind the LDE of chunk k -- 28.3 -> 29.6 ms per proof: the stage is bound by the VALU work of sponge + transforms
@@ -469,6 +475,7 @@ static int create_ctx(const sbn_air_desc* air, const sbn_config* cfg, uint32_t d
   AirShape as;
   if (!air_shape(air, cfg, as)) return fail(SBN_ERR_BAD_ARG, "unknown air kind / num_io");
   if (degree_bits < 9 || degree_bits > 22) return fail(SBN_ERR_UNSUPPORTED, "degree_bits out of range");
+  if (as.kind == SBN_AIR_FLAGS && (512 * (size_t)as.num_io) != ((size_t)1 << degree_bits)) return fail(SBN_ERR_BAD_ARG, "FlagStark needs 512*num_io rows");
   if (is_exp_air(as.kind)) {
     if ((exp_rows_per_instance(as.kind) * as.num_io) != ((size_t)1 << degree_bits)) return fail(SBN_ERR_BAD_ARG, "the Exp tables need 512*num_io rows (FQ12_EXP_U64: 128*num_io)");
     if (as.kind != SBN_AIR_FQ12_EXP && as.kind != SBN_AIR_FQ12_EXP_U64 && degree_bits < 16)
@@ -507,6 +514,7 @@ static int create_ctx(const sbn_air_desc* air, const sbn_config* cfg, uint32_t d
   for (auto& v : P->stage_ms) v = 0;
   if (rc) { sbn_prover_destroy(P); return rc; }
   const size_t n = P->n, m = P->m, C = as.ncols, Z = as.nzs;
+  if (comm && (C <= 4 || Z == 0)) { sbn_prover_destroy(P); return fail(SBN_ERR_UNSUPPORTED, "the split prover covers the wide tables (this one has %zu columns and %zu permutation Zs)", C, Z); }
   if (comm) {
     // one trace over comm->world GPUs: this rank keeps the coefficients of its own columns and the LDE ROWS of its Merkle
     // subtrees (views of the caller's receive buffer); the trace values stay whole
@@ -547,7 +555,7 @@ static int create_ctx(const sbn_air_desc* air, const sbn_config* cfg, uint32_t d
   } else {
     P->lde_scratch_words = C * m;
     acc(dmalloc(&P->d_trace, C * n)); acc(dmalloc(&P->d_coef, C * n)); acc(dmalloc(&P->d_lde, C * m));
-    acc(dmalloc(&P->d_zval, Z * n)); acc(dmalloc(&P->d_zcoef, Z * n)); acc(dmalloc(&P->d_zlde, Z * m));
+    acc(dmalloc(&P->d_zval, std::max<size_t>(Z, 1) * n)); acc(dmalloc(&P->d_zcoef, std::max<size_t>(Z, 1) * n)); acc(dmalloc(&P->d_zlde, std::max<size_t>(Z, 1) * m));
     acc(tree_alloc(P->tree_t, m, cfg->cap_height)); acc(tree_alloc(P->tree_z, m, cfg->cap_height));
   }
   acc(dmalloc(&P->d_tmp, std::max(P->ntt_chunk, (size_t)4) * m));
@@ -603,12 +611,13 @@ static int create_ctx(const sbn_air_desc* air, const sbn_config* cfg, uint32_t d
     for (size_t z = 0; z < Z; z++) {
       int l, r;
       if (as.kind == SBN_AIR_G1_OP) G1OpShape::pair((int)z, l, r);
+      else if (as.kind == SBN_AIR_LOOKUP) LookupShape().pair((int)z, l, r);
       else if (is_op_air(as.kind)) OpShape(as.kind).pair((int)z, l, r);
       else exp_shape(as).pair((int)z, l, r);
       pairs[z].lhs = l; pairs[z].rhs = r;
     }
-    hipc(hipMalloc((void**)&P->d_pairs, Z * sizeof(PairCols)), "hipMalloc");
-    if (!rc) hipc(hipMemcpy(P->d_pairs, pairs.data(), Z * sizeof(PairCols), hipMemcpyHostToDevice), "hipMemcpy");
+    hipc(hipMalloc((void**)&P->d_pairs, std::max<size_t>(Z, 1) * sizeof(PairCols)), "hipMalloc");
+    if (!rc && Z) hipc(hipMemcpy(P->d_pairs, pairs.data(), Z * sizeof(PairCols), hipMemcpyHostToDevice), "hipMemcpy");
     if (P->sp && P->sp->zr) {   // the split: the pairs of this rank's Z columns in local order
       SplitCtx* S = P->sp;
       std::vector<PairCols> own(S->zr);
@@ -1013,6 +1022,8 @@ static int launch_quotient_parts(sbn_prover* P, const QuotientParams& qp, size_t
     case SBN_AIR_FQ12_EXP_U64: launch_quotient_kind<6>(P, qp, qblocks); break;
     case SBN_AIR_MODULAR: launch_quotient_kind<7>(P, qp, qblocks); break;
     case SBN_AIR_FQ12_MUL: launch_quotient_kind<8>(P, qp, qblocks); break;
+    case SBN_AIR_LOOKUP: launch_quotient_kind<9>(P, qp, qblocks); break;
+    case SBN_AIR_FLAGS: launch_quotient_kind<10>(P, qp, qblocks); break;
     default: launch_quotient_kind<4>(P, qp, qblocks); break;
   }
   HIPC(hipGetLastError());
@@ -1046,8 +1057,10 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
 
   // P2 permutation argument -------------------------------------------------------------------------
   // get_n_permutation_challenge_sets(num_challenges, batch_size=2): sets[s].challenges[c] = (beta, gamma)
-  F gam[2][2];
-  for (int s = 0; s < 2; s++) for (int c = 0; c < (int)cfg.num_challenges; c++) { (void)ch.challenge(); gam[s][c] = ch.challenge(); }
+  // (a table without permutation pairs -- FlagStark -- draws no permutation challenges and commits no Z: starky prover.rs
+  //  `stark.uses_permutation_args()`)
+  F gam[2][2] = {};
+  if (Z) for (int s = 0; s < 2; s++) for (int c = 0; c < (int)cfg.num_challenges; c++) { (void)ch.challenge(); gam[s][c] = ch.challenge(); }
   const F gamma0 = gam[0][0], gamma1 = gam[1][1];  // instance i of a batch uses sets[i].challenges[chal]
   {
     const size_t zn = S ? S->zr : Z;                       // Z columns computed here (the split: this rank's range)
@@ -1062,12 +1075,14 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
   if (S) {
     if ((rc = commit_split(P, S->zs, P->d_zval, false, P->d_zcoef, S->zlde_l, S->zlde_n, P->tree_z))) return rc;
   } else {
-    if ((rc = absorb_times(P, C, EX_TRACE_ABSORB_MS))) return rc;   // (27 event queries: behind the Z kernel, not in front of it)
-    if ((rc = commit_pipeline(P, P->d_zval, P->d_zcoef, P->d_zlde, Z, P->tree_z, EX_Z_ABSORB_MS, EX_Z_ABSORB_LAUNCHES))) return rc;
+    if (C > 4) if ((rc = absorb_times(P, C, EX_TRACE_ABSORB_MS))) return rc;   // (27 event queries: behind the Z kernel, not in front of it)
+    if (Z) if ((rc = commit_pipeline(P, P->d_zval, P->d_zcoef, P->d_zlde, Z, P->tree_z, EX_Z_ABSORB_MS, EX_Z_ABSORB_LAUNCHES))) return rc;
   }
   HIPC(hipEventRecord(P->ev[ST_QUOTIENT_EVAL], st));
-  if ((rc = S ? split_cap_to_host(P, P->tree_z, z_cap) : tree_cap_to_host(P, P->tree_z, z_cap))) return rc;
-  ch.observe_words(z_cap.data(), capw);
+  if (Z) {
+    if ((rc = S ? split_cap_to_host(P, P->tree_z, z_cap) : tree_cap_to_host(P, P->tree_z, z_cap))) return rc;
+    ch.observe_words(z_cap.data(), capw);
+  }
 
   // P3 quotient -------------------------------------------------------------------------------------
   F alphas[SBN_NCH];
@@ -1142,7 +1157,7 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
       if ((rc = split_all_gather_device(P, 2 * S->ml))) return rc;
       hipLaunchKernelGGL(split_unpack_rows_kernel, blocks(m), dim3(256), 0, st, S->scratch, m, 2u, S->log_r, P->d_q);
       HIPC(hipGetLastError());
-    } else if ((rc = absorb_times(P, Z, EX_Z_ABSORB_MS))) return rc;   // behind the quotient kernel
+    } else if (Z > 4) { if ((rc = absorb_times(P, Z, EX_Z_ABSORB_MS))) return rc; }   // behind the quotient kernel
   }
   HIPC(hipEventRecord(P->ev[ST_QUOTIENT_COMMIT], st));
   // coset_ifft(7) of the 2 quotient value vectors (size m), in place via tmp; the result viewed as
@@ -1213,7 +1228,7 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
     // Z and quotient at zeta, then everything at g*zeta, again in slices: the host (0.86 us per permutation, 4 columns each)
     // is the slower side, and it must never find the next values missing -- with the trace at g*zeta evaluated last in one
     // kernel it idled 0.3 ms before it.
-    hipLaunchKernelGGL(open1_k, dim3((unsigned)Z), dim3(256), 0, st, P->d_zcoef, n, zp0, zp1, P->d_open + C * 4, 0u);
+    if (Z) hipLaunchKernelGGL(open1_k, dim3((unsigned)Z), dim3(256), 0, st, P->d_zcoef, n, zp0, zp1, P->d_open + C * 4, 0u);
     hipLaunchKernelGGL(open1_k, dim3(4), dim3(256), 0, st, P->d_q, n, zp0, zp1, P->d_open + (C + Z) * 4, 0u);
     HIPC(hipMemcpyAsync(P->h_open + C * 4, P->d_open + C * 4, (Z + 4) * 4 * sizeof(u64), hipMemcpyDeviceToHost, st));
     HIPC(hipEventRecord(P->chunk_ready[1], st));
@@ -1226,7 +1241,7 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
       }
       HIPC(hipEventRecord(P->chunk_ready[12 + k], st));
     }
-    hipLaunchKernelGGL(open1_k, dim3((unsigned)Z), dim3(256), 0, st, P->d_zcoef, n, zp2, zp3, P->d_open + C * 4, 2u);
+    if (Z) hipLaunchKernelGGL(open1_k, dim3((unsigned)Z), dim3(256), 0, st, P->d_zcoef, n, zp2, zp3, P->d_open + C * 4, 2u);
     HIPC(hipGetLastError());
     HIPC(hipMemcpyAsync(P->h_open2 + C * 4, P->d_open + C * 4, Z * 4 * sizeof(u64), hipMemcpyDeviceToHost, st));
     HIPC(hipEventRecord(P->ev[ST_FRI_COMBINE], st));

@@ -12,6 +12,7 @@
 //  * range-check columns use a counting sort (values < 2^16) and the reference's merge
 //    (src/utils/lookup.rs:60-111) to place unused table values.
 #include "host_common.hpp"
+#include <algorithm>
 #include "bn254w.cuh"
 #include <thread>
 #include <atomic>
@@ -167,23 +168,25 @@ static void fill_flags(uint64_t* trace, size_t n, int sf, size_t num_io, const s
 }
 // periodic pulse (pulse.rs:100-144: counter starts at 1, period 64, witness 1/(counter-63); absent in the u64 table) and
 // io pulses (pulse.rs:20-43) at the first and last row of every instance
-static void fill_pulses(uint64_t* trace, size_t n, const ExpShape& sh) {
+static void fill_pulses_at(uint64_t* trace, size_t n, int start_periodic, int start_io_pulses, size_t num_io, size_t RPB) {
   auto col = [&](int c) { return trace + (size_t)c * n; };
-  const size_t RPB = (size_t)sh.rpb;
   std::vector<u64> inv = small_inverses(n);
-  if (sh.start_periodic >= 0) {
-    u64* cnt = col(sh.start_periodic); u64* wit = col(sh.start_periodic + 1);
+  if (start_periodic >= 0) {
+    u64* cnt = col(start_periodic); u64* wit = col(start_periodic + 1);
     for (size_t i = 0; i < n; i++) { u64 c = (i + 1) % 64; cnt[i] = c; wit[i] = c == 63 ? 0 : (-F(inv[63 - c])).v; }
   }
-  u64* cnt2 = col(sh.start_io_pulses);
+  u64* cnt2 = col(start_io_pulses);
   for (size_t i = 0; i < n; i++) cnt2[i] = i;
-  parallel_for(2 * (size_t)sh.num_io, [&](size_t q) {
+  parallel_for(2 * num_io, [&](size_t q) {
     size_t pos = (q >> 1) * RPB + ((q & 1) ? RPB - 1 : 0);
-    u64* w = col(sh.witness_col((int)q)); u64* pul = col(sh.pulse_col((int)q));
+    u64* w = col(start_io_pulses + 1 + 2 * (int)q); u64* pul = col(start_io_pulses + 2 + 2 * (int)q);   // pulse.rs:10-16
     for (size_t i = 0; i < n; i++) w[i] = i > pos ? inv[i - pos] : (i < pos ? (-F(inv[pos - i])).v : 0);
     memset(pul, 0, n * sizeof(u64));
     pul[pos] = 1;
   });
+}
+static void fill_pulses(uint64_t* trace, size_t n, const ExpShape& sh) {
+  fill_pulses_at(trace, n, sh.start_periodic, sh.start_io_pulses, (size_t)sh.num_io, (size_t)sh.rpb);
 }
 // split range check (range_check.rs:116-160): table 0..255 then 255; per target: lo, perm(lo), table', hi, perm(hi), table'
 static bool fill_split_range_check(uint64_t* trace, size_t n, int table_col, int first_target, int num_targets) {
@@ -322,6 +325,48 @@ static int generate_exp_trace(const uint32_t* ios, size_t num_io, uint64_t* trac
     if (bad) return fail(SBN_ERR_WITNESS, "range-checked column holds a value >= 2^16");
   }
   tm.lap("range check");
+  return SBN_OK;
+}
+
+// permuted_cols (lookup.rs:60-111) on arbitrary columns: sorted inputs, and the table permuted so that every looked-up value
+// sits beside its first occurrence and unused table values fill the gaps (a LIFO pool while the merge runs, the rest in order).
+static bool permuted_cols_any(const u64* inputs, const u64* table, size_t n, u64* sorted_out, u64* perm_table_out) {
+  std::vector<u64> si(inputs, inputs + n), st(table, table + n);
+  std::sort(si.begin(), si.end());
+  std::sort(st.begin(), st.end());
+  std::vector<size_t> unused_inds; std::vector<u64> unused_vals;
+  size_t i = 0, j = 0;
+  while (j < n && i < n) {
+    if (si[i] > st[j]) { unused_vals.push_back(st[j]); j++; }
+    else if (si[i] < st[j]) { if (!unused_vals.empty()) { perm_table_out[i] = unused_vals.back(); unused_vals.pop_back(); } else unused_inds.push_back(i); i++; }
+    else { perm_table_out[i] = st[j]; i++; j++; }
+  }
+  for (; j < n; j++) unused_vals.push_back(st[j]);
+  for (; i < n; i++) unused_inds.push_back(i);
+  if (unused_inds.size() != unused_vals.size()) return false;
+  for (size_t k = 0; k < unused_inds.size(); k++) perm_table_out[unused_inds[k]] = unused_vals[k];
+  memcpy(sorted_out, si.data(), n * sizeof(u64));
+  return true;
+}
+// MyStark::generate_trace (src/utils/lookup.rs:151-166)
+extern "C" int sbn_generate_trace_lookup(const uint64_t* inputs, const uint64_t* table, size_t rows, uint64_t* trace) {
+  if (!inputs || !table || !trace) return fail(SBN_ERR_BAD_ARG, "null argument");
+  if (rows < 2 || (rows & (rows - 1))) return fail(SBN_ERR_BAD_ARG, "rows must be a power of two");
+  for (size_t i = 0; i < rows; i++) if (inputs[i] >= GLP || table[i] >= GLP) return fail(SBN_ERR_NON_CANONICAL, "value %zu is not canonical", i);
+  memcpy(trace, inputs, rows * sizeof(u64));
+  memcpy(trace + rows, table, rows * sizeof(u64));
+  if (!permuted_cols_any(inputs, table, rows, trace + 2 * rows, trace + 3 * rows)) return fail(SBN_ERR_WITNESS, "permuted_cols: the merge does not close");
+  return SBN_OK;
+}
+// FlagStark::generate_trace (src/utils/flags.rs:392-440): the flags of every input, the rotation pulse, the block-boundary pulses
+extern "C" int sbn_generate_trace_flags(const uint32_t* limbs, size_t num_io, uint64_t* trace) {
+  if (!limbs || !trace) return fail(SBN_ERR_BAD_ARG, "null argument");
+  if (num_io == 0 || num_io > (size_t)G1EXP_MAX_IO || (num_io & (num_io - 1))) return fail(SBN_ERR_BAD_ARG, "num_io must be a power of two <= %d", G1EXP_MAX_IO);
+  const size_t n = 512 * num_io;
+  const FlagShape sh((int)num_io);
+  memset(trace, 0, (size_t)sh.num_cols() * n * sizeof(u64));
+  fill_flags(trace, n, 0, num_io, [&](size_t k) { return limbs + 8 * k; });
+  fill_pulses_at(trace, n, FlagShape::START_PERIODIC, FlagShape::START_IO_PULSES, num_io, 512);
   return SBN_OK;
 }
 

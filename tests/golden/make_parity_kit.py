@@ -30,6 +30,8 @@ import parity_kit as K  # noqa: E402
 # name -> (table, kind, num_io or rows, seed, inputs(), trace(), slow)
 CASES = {
     "mystark_lookup_fixed": ("MyStark", "AIR_LOOKUP", 8, None, None, None, False),
+    "mystark_rows512_seed9": ("MyStark", "AIR_LOOKUP", 512, 9, "lookup_inputs", "lookup_trace", False),
+    "flagstark_io16_seed8": ("FlagStark", "AIR_FLAGS", 16, 8, "flags_inputs", "flags_trace", False),
     "modular_rows512_seed6": ("ModularStark", "AIR_MODULAR", 512, 6, "modular_inputs", "modular_trace", False),
     "g1op_rows512_seed0": ("G1Stark", "AIR_G1_OP", 512, 0, "g1op_inputs", "g1op_trace", False),
     "fq12expu64_io16_seed5": ("Fq12ExpU64Stark", "AIR_FQ12_EXP_U64", 16, 5, "fq12expu64_inputs", "fq12expu64_trace", False),
@@ -39,8 +41,10 @@ CASES = {
     "g2exp_io128_seed2": ("G2ExpStark", "AIR_G2_EXP", 128, 2, "g2exp_inputs", "g2exp_trace", True),
 }
 INPUT_LAYOUT = {
-    "MyStark": "2 x 8: row 0 = inputs [6, 3, 1, 1, 0, 0, 0, 0], row 1 = table 0..7 -- the fixed vectors of MyStark::generate_trace, src/utils/lookup.rs:154-161 (ORACLE ONLY: "
-               "8 rows are below the device prover's minimum; run the reference's test_mystark, lookup.rs:215-229, and compare)",
+    "MyStark": "2 x rows: row 0 = the inputs column, row 1 = the table column of MyStark::generate_trace (sbn_generate_trace_lookup).  mystark_lookup_fixed = the reference's own "
+               "fixed vectors [6, 3, 1, 1, 0, 0, 0, 0] / 0..7, src/utils/lookup.rs:154-161 (ORACLE ONLY: 8 rows are below the device prover's minimum; run the reference's "
+               "test_mystark, lookup.rs:215-229, and compare)",
+    "FlagStark": "num_io x 8 u32 limbs (sbn_generate_trace_flags; flags.rs:551-554 draws them at random)",
     "ModularStark": "rows x 16 u32 = a[8] b[8] (sbn_generate_trace_modular)",
     "G1Stark": "rows x 32 u32 = a.x[8] a.y[8] b.x[8] b.y[8] (sbn_generate_trace_g1_op)",
     "G1ExpStark": "num_io x 40 u32 = x.x[8] x.y[8] offset.x[8] offset.y[8] exp_val[8] (sbn_generate_trace_g1_exp)",
@@ -53,15 +57,15 @@ INPUT_LAYOUT = {
 
 def build_case(name, variants=("times_x", "plain")):
     table, kind, size, seed, fin, ftr, _ = CASES[name]
-    if table == "MyStark":        # no generator, no seed: the reference's own fixed input
-        ins, tab = O.lookup_fixed_inputs()
+    if table == "MyStark":        # seed None: no generator, the reference's own fixed input
+        ins, tab = O.lookup_fixed_inputs() if seed is None else O.lookup_inputs(size, seed)
         inputs = np.stack([ins, tab]).astype(np.uint32)
         trace, pi = O.lookup_trace(ins, tab), np.zeros(0, dtype=np.uint64)
     else:
         inputs, _ = getattr(O, fin)(size, seed)
         res = getattr(O, ftr)(inputs)
         trace, pi = res if isinstance(res, tuple) else (res, np.zeros(0, dtype=np.uint64))
-    is_exp = table.endswith("ExpStark") or table == "Fq12ExpU64Stark"
+    is_exp = table.endswith("ExpStark") or table in ("Fq12ExpU64Stark", "FlagStark")   # tables parametrised by an instance count
     out = {
         "about": "reference-parity hand-over kit: inputs + per-stage digests of the ORACLE's proof (a restatement; parity vs the Rust reference is unpinned)",
         "table": table, "air_kind": int(getattr(O, kind)), "num_io": size if is_exp else 0, "rows": int(trace.shape[1]), "seed": seed,

@@ -547,6 +547,30 @@ AIR_FQ12_MUL = 8
 AIR_LOOKUP = 9      # oracle only: MyStark, the lookup unit-test table (src/utils/lookup.rs:136-213), 8 rows in the reference's test
 
 
+AIR_FLAGS = 10      # FlagStark, the flags unit-test table (src/utils/flags.rs:379-547): no permutation pairs
+
+
+def lookup_inputs(rows, seed):
+    """A MyStark instance of `rows` rows: table 0 .. rows-1 shuffled, inputs drawn from a quarter of the table (repeats)."""
+    rng = np.random.default_rng(seed)
+    table = rng.permutation(rows).astype(np.uint64)
+    inputs = rng.choice(table[: max(rows // 4, 1)], size=rows).astype(np.uint64)
+    return inputs, table
+
+
+def flags_inputs(num_io, seed):
+    """num_io x 8 u32 limbs (flags.rs:551-554 draws them at random)."""
+    return np.random.default_rng(seed).integers(0, 1 << 32, size=(num_io, 8), dtype=np.uint64).astype(np.uint32), None
+
+
+def flags_trace(limbs):
+    limbs = np.ascontiguousarray(limbs, dtype=np.uint32)
+    k = limbs.shape[0]
+    trace = np.zeros((17 + 4 * k, 512 * k), dtype=np.uint64)
+    lib().orc_flags_generate_trace(ptr(limbs), k, ptr(trace))
+    return trace
+
+
 def lookup_fixed_inputs():
     """The crate's only fixed test input (src/utils/lookup.rs:154-161): inputs and table of MyStark::generate_trace."""
     return np.array([6, 3, 1, 1, 0, 0, 0, 0], dtype=np.uint64), np.arange(8, dtype=np.uint64)

@@ -106,6 +106,56 @@ def test_single_operation_tables_proof_bit_exact(gpu, O, golden, table, rows, se
         gpu.verify_stark_proof(stark, p2, cfg)
 
 
+@pytest.mark.parametrize("rows,seed", [(512, 9), (4096, 19)])
+def test_mystark_lookup_table_proof_bit_exact(gpu, O, rows, seed):
+    """Reference `MyStark` (src/utils/lookup.rs:136-229), the unit-test table of the lookup argument, at 512 and 4096 rows:
+    4 trace columns and 2 Z columns, so every Merkle leaf of the first two commitments is the row itself (hash_or_noop) --
+    the narrow-matrix path of the prover.  GPU proof words == the oracle's; both verifiers accept; a row whose looked-up
+    value is missing from the permuted table yields a proof both verifiers reject."""
+    stark = gpu.LookupStark()
+    cfg = stark.config()
+    ins, tab = O.lookup_inputs(rows, seed)
+    trace = stark.generate_trace(ins, tab)
+    proof = gpu.prove(stark, cfg, trace, np.zeros(0, dtype=np.uint64))
+    ref, _ = O.prove(O.AIR_LOOKUP, 0, trace, np.zeros(0, dtype=np.uint64))
+    assert np.array_equal(proof.words, ref)
+    assert [int(x) for x in proof.words[1:6]] == [rows.bit_length() - 1, 4, 2, 4, 0]
+    assert O.verify(O.AIR_LOOKUP, 0, proof.words) == (0, "")
+    gpu.verify_stark_proof(stark, proof, cfg)
+    r = next(i for i in range(1, rows) if trace[2, i] != trace[2, i - 1])
+    bad = trace.copy()
+    bad[3, r], bad[3, r + 1] = bad[3, r + 1], bad[3, r]          # still a permutation of the table, but the lookup breaks
+    if bad[3, r] != trace[3, r]:
+        p2 = gpu.prove(stark, cfg, bad, np.zeros(0, dtype=np.uint64))
+        assert O.verify(O.AIR_LOOKUP, 0, p2.words)[0] != 0
+        with pytest.raises(gpu.SbnError):
+            gpu.verify_stark_proof(stark, p2, cfg)
+
+
+@pytest.mark.parametrize("num_io,seed", [(16, 8), (1, 18)])
+def test_flagstark_proof_bit_exact(gpu, O, num_io, seed):
+    """Reference `FlagStark` (src/utils/flags.rs:379-565; 16 inputs in its test): the one table WITHOUT permutation pairs -- no
+    permutation challenges are drawn, no Z commitment is made, the proof header says n_perm_zs = 0.  GPU proof words == the
+    oracle's; both verifiers accept; a flipped bit column is rejected by both."""
+    stark = gpu.FlagStark(num_io)
+    cfg = stark.config()
+    limbs, _ = O.flags_inputs(num_io, seed)
+    trace = stark.generate_trace(limbs)
+    proof = gpu.prove(stark, cfg, trace, np.zeros(0, dtype=np.uint64))
+    ref, _ = O.prove(O.AIR_FLAGS, num_io, trace, np.zeros(0, dtype=np.uint64))
+    assert np.array_equal(proof.words, ref)
+    assert [int(x) for x in proof.words[1:6]] == [(512 * num_io).bit_length() - 1, 17 + 4 * num_io, 0, 4, 0]
+    assert O.verify(O.AIR_FLAGS, num_io, proof.words) == (0, "")
+    gpu.verify_stark_proof(stark, proof, cfg)
+    assert proof.recover_degree_bits(cfg) == (512 * num_io).bit_length() - 1
+    bad = trace.copy()
+    bad[5, 7] ^= 1                                               # the bit column of row 7
+    p2 = gpu.prove(stark, cfg, bad, np.zeros(0, dtype=np.uint64))
+    assert O.verify(O.AIR_FLAGS, num_io, p2.words)[0] != 0
+    with pytest.raises(gpu.SbnError):
+        gpu.verify_stark_proof(stark, p2, cfg)
+
+
 def test_g1stark_proof_without_the_times_x_step(gpu, O):
     """sbn_config.fri_variant = SBN_FRI_PLAIN (later upstream plonky2: no multiply-by-X of the FRI final polynomial):
     GPU proof bytes == the oracle's in the same mode, and differ from the default mode's."""
