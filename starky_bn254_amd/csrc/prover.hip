@@ -315,8 +315,30 @@ static int commit_pipeline(sbn_prover* P, const u64* vals, u64* coef, u64* lde, 
   return 0;
 }
 // Host waits inside prove().  Polling hipStreamQuery / hipEventQuery instead was measured: no gain over the runtime's waits.
-static inline hipError_t stream_wait(hipStream_t st) { return hipStreamSynchronize(st); }
-static inline hipError_t event_wait(hipEvent_t ev) { return hipEventSynchronize(ev); }
+// A rank of a split proof (world > 1) waits with a DEADLINE instead: a peer that died leaves this rank's stream behind a
+// receive that never completes, and hipStreamSynchronize would hang the whole job; polling returns hipErrorNotReady after
+// SBN_COMM_TIMEOUT_S seconds (default 600), prove() fails with SBN_ERR_HIP and the caller can tear the job down.
+static thread_local double t_wait_deadline_s = 0;   // 0: plain runtime waits
+static inline hipError_t stream_wait(hipStream_t st) {
+  if (t_wait_deadline_s <= 0) return hipStreamSynchronize(st);
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    const hipError_t e = hipStreamQuery(st);
+    if (e != hipErrorNotReady) return e;
+    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > t_wait_deadline_s) return hipErrorNotReady;
+    std::this_thread::yield();
+  }
+}
+static inline hipError_t event_wait(hipEvent_t ev) {
+  if (t_wait_deadline_s <= 0) return hipEventSynchronize(ev);
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    const hipError_t e = hipEventQuery(ev);
+    if (e != hipErrorNotReady) return e;
+    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > t_wait_deadline_s) return hipErrorNotReady;
+    std::this_thread::yield();
+  }
+}
 // ---- oversized-trace split: exchange helpers ------------------------------------------------------------------------
 // Every exchange is STREAM-ORDERED (include/sbn.h sbn_comm.all_to_all): it is enqueued on `st` behind the kernels that
 // packed its blocks, and the kernels that consume the received blocks are enqueued on `st` (or behind an event of `st`)
@@ -428,7 +450,7 @@ static int split_cap_to_host(sbn_prover* P, const DevTree& t, std::vector<u64>& 
   const size_t capn = (size_t)1 << P->cfg.cap_height, own = capn >> S->log_r;
   std::vector<u64> mine(own * 4);
   HIPC(hipMemcpyAsync(mine.data(), t.level(t.nlevels), own * 4 * sizeof(u64), hipMemcpyDeviceToHost, P->stream));
-  HIPC(hipStreamSynchronize(P->stream));
+  HIPC(stream_wait(P->stream));
   cap.resize(capn * 4);
   return split_all_gather_host(P, mine.data(), cap.data(), own * 4 * sizeof(u64));
 }
@@ -1033,7 +1055,7 @@ static int launch_quotient_parts(sbn_prover* P, const QuotientParams& qp, size_t
 extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
   if (!P || !out) return fail(SBN_ERR_BAD_ARG, "null argument");
   *out = nullptr;
-  if (!P->loaded) return fail(SBN_ERR_BAD_ARG, "no trace loaded");
+  if (!P->loaded && !(P->sp && P->sp->comm.world > 1)) return fail(SBN_ERR_BAD_ARG, "no trace loaded");   // (split: agreed with the other ranks below)
   HIPC(hipSetDevice(P->device));
   hipStream_t st = P->stream;
   const size_t n = P->n, m = P->m, C = P->air.ncols, Z = P->air.nzs;
@@ -1047,6 +1069,18 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
   // P1 trace commitment ---------------------------------------------------------------------------
   HIPC(hipEventRecord(P->ev[ST_TRACE_COMMIT], st));
   SplitCtx* const S = P->sp;   // non-null: this rank's share of one trace split over S->comm.world GPUs
+  struct DeadlineScope { ~DeadlineScope() { t_wait_deadline_s = 0; } } deadline_scope;
+  if (S && S->comm.world > 1) {
+    // every rank must have a witness before anyone walks into the first exchange (a rank whose generate_trace failed would
+    // leave the others waiting for its blocks): agree on a status word first
+    const char* te = getenv("SBN_COMM_TIMEOUT_S");
+    t_wait_deadline_s = te && atof(te) > 0 ? atof(te) : 600.0;
+    std::vector<uint32_t> st_all(S->comm.world, 0);
+    const uint32_t mine = P->loaded ? 1u : 0u;
+    if ((rc = split_all_gather_host(P, &mine, st_all.data(), sizeof(uint32_t)))) return rc;
+    for (u32 r = 0; r < S->comm.world; r++) if (!st_all[r]) return fail(SBN_ERR_BAD_ARG, "split proof abandoned: rank %u has no trace loaded", r);
+  }
+  if (!P->loaded) return fail(SBN_ERR_BAD_ARG, "no trace loaded");
   if (S) {
     S->tev_used = 0;
     if ((rc = commit_split(P, S->cs, P->d_trace, true, P->d_coef, S->lde_l, S->lde_n, P->tree_t))) return rc;

@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>   // types only: every entry point is looked up with dlsym
 #include <dlfcn.h>
+#include <sched.h>
 #include <chrono>
 #include <condition_variable>
 #include <cstdarg>
@@ -121,8 +122,18 @@ int rccl_all_gather_host(void* vctx, const void* send, void* recv, uint64_t byte
   THIP(hipMemcpyAsync(d_in, send, bytes, hipMemcpyHostToDevice, c->hstream));
   TNCCL(g_rccl.AllGather(d_in, d_out, (size_t)bytes, ncclUint8, c->comm, c->hstream));
   THIP(hipMemcpyAsync(recv, d_out, (size_t)c->world * bytes, hipMemcpyDeviceToHost, c->hstream));
-  THIP(hipStreamSynchronize(c->hstream));
-  return 0;
+  // a peer that never arrives must fail this rank, not hang it: poll with a deadline (SBN_COMM_TIMEOUT_S, default 600 s)
+  const char* te = getenv("SBN_COMM_TIMEOUT_S");
+  const double limit = te && atof(te) > 0 ? atof(te) : 600.0;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    const hipError_t e = hipStreamQuery(c->hstream);
+    if (e == hipSuccess) return 0;
+    if (e != hipErrorNotReady) return tfail(SBN_ERR_HIP, "all_gather_host: %s", hipGetErrorString(e));
+    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit)
+      return tfail(SBN_ERR_HIP, "all_gather_host: no answer from the other ranks within %.0f s", limit);
+    sched_yield();
+  }
 }
 }  // namespace
 

@@ -182,3 +182,45 @@ def test_split_proof_at_config4_size_two_local_ranks(S, O):
     assert np.array_equal(split_words, ref.words)
     S.verify_stark_proof(stark, ref, cfg)
     print(f"config[4] size, 2 local ranks: exchange {[round(t['split_exchange_ms'], 1) for t in times]} ms")
+
+
+def test_a_rank_without_a_witness_stops_all_ranks(S, O):
+    """a rank that failed before prove() (here: it never loaded a trace) must not leave the others waiting in
+    the first exchange.  sbn_split_prover_prove agrees on a status word over the host all-gather first: EVERY rank returns an
+    error, nobody hangs; after the missing witness is supplied the same provers produce the proof."""
+    import threading
+    import time
+    from starky_bn254_amd import split
+    if S.lib().sbn_device_count() < 1:
+        pytest.fail("no HIP device")
+    S.lib().sbn_set_device(0)
+    ios, _ = O.fq12exp_inputs(16, 3)
+    stark = S.Fq12ExpStark(16)
+    cfg = stark.config()
+    sb, rb = split.exchange_bytes(stark, cfg, 13, 2)
+    grp = split.LocalGroup(2, sb, rb)
+    provers = [split.SplitProver(stark, cfg, 13, transport=grp.comms[r]) for r in range(2)]
+    provers[0].generate_trace(ios)
+    res = [None, None]
+
+    def go(r):
+        try:
+            res[r] = provers[r].prove()
+        except Exception as e:  # noqa: BLE001
+            res[r] = e
+    t0 = time.time()
+    th = [threading.Thread(target=go, args=(r,)) for r in range(2)]
+    [t.start() for t in th]
+    [t.join(timeout=120) for t in th]
+    assert not any(t.is_alive() for t in th), "a rank hangs"
+    assert all(isinstance(x, S.SbnError) for x in res), res
+    assert "rank 1 has no trace" in str(res[0]) and time.time() - t0 < 60
+    provers[1].generate_trace(ios)
+    th = [threading.Thread(target=go, args=(r,)) for r in range(2)]
+    [t.start() for t in th]
+    [t.join(timeout=300) for t in th]
+    assert all(isinstance(x, S.Proof) for x in res), res
+    assert np.array_equal(res[0].words, res[1].words)
+    for p in provers:
+        p.close()
+    grp.close()
