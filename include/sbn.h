@@ -54,7 +54,7 @@ typedef enum sbn_status {
 /* Table kinds.  G1_OP = reference `G1Stark` (src/curves/g1/muladd.rs:462-624);
  * G1_EXP = reference `G1ExpStark` (src/curves/g1/exp.rs:232-742). */
 typedef enum sbn_air_kind { SBN_AIR_G1_OP = 1, SBN_AIR_G1_EXP = 2, SBN_AIR_G2_EXP = 3, SBN_AIR_FQ12_EXP = 4, SBN_AIR_FQ_EXP = 5, SBN_AIR_FQ12_EXP_U64 = 6,
-                              SBN_AIR_MODULAR = 7, SBN_AIR_FQ12_MUL = 8, SBN_AIR_LOOKUP = 9, SBN_AIR_FLAGS = 10 } sbn_air_kind;
+                              SBN_AIR_MODULAR = 7, SBN_AIR_FQ12_MUL = 8, SBN_AIR_LOOKUP = 9, SBN_AIR_FLAGS = 10, SBN_AIR_FLAGS_U64 = 11 } sbn_air_kind;
 /* G2_EXP = reference `G2ExpStark` (src/curves/g2/exp.rs:248-807): the same machine over Fq2 coordinates.
  * FQ12_EXP = reference `Fq12ExpStark` (src/fields/fq12/exp.rs:223-605): offset * x^e in Fq12 (flat basis of
  * plonky2-bn254 `MyFq12`: coefficient of w^k is c[k] + c[k+6]*i, w^6 = 9 + i), 512 rows per instance, num_io a
@@ -71,7 +71,9 @@ typedef enum sbn_air_kind { SBN_AIR_G1_OP = 1, SBN_AIR_G1_EXP = 2, SBN_AIR_G2_EX
  * power-of-two height >= 512, num_io ignored (the reference's own 8-row instance is below the device prover's minimum).
  * FLAGS = reference `FlagStark` (src/utils/flags.rs:379-547), the unit-test table of the exponent-bit flags: num_io inputs
  * of 8 u32 limbs, 512 rows each (the reference uses 16), 17 + 4 * num_io columns, NO permutation pairs -- the one table
- * whose proof carries no permutation-Z commitment (header n_perm_zs = 0). */
+ * whose proof carries no permutation-Z commitment (header n_perm_zs = 0).
+ * FLAGS_U64 = the `FlagStark` of src/fields/fq12_u64/flags_u64.rs:289-420, the same for the u64-exponent flags: num_io inputs
+ * (u64), 128 rows each, 7 + 4 * num_io columns, no rotation pulse, no permutation pairs; num_io >= 4 (512 rows). */
 
 typedef struct sbn_air_desc {
   int32_t kind;    /* sbn_air_kind */
@@ -153,6 +155,8 @@ int sbn_generate_trace_fq12_mul(const uint32_t* ops, size_t rows, uint64_t* trac
 int sbn_generate_trace_lookup(const uint64_t* inputs, const uint64_t* table, size_t rows, uint64_t* trace_out);
 /* FlagStark::generate_trace (flags.rs:392-440): limbs: num_io x 8 u32; trace_out: [17 + 4 * num_io][512 * num_io]. */
 int sbn_generate_trace_flags(const uint32_t* limbs, size_t num_io, uint64_t* trace_out);
+/* flags_u64.rs FlagStark::generate_trace (:316-337): exps: num_io x u64; trace_out: [7 + 4 * num_io][128 * num_io]. */
+int sbn_generate_trace_flags_u64(const uint64_t* exps, size_t num_io, uint64_t* trace_out);
 
 /* Prover ---------------------------------------------------------------------------------------- */
 int sbn_prover_create(const sbn_air_desc* air, const sbn_config* cfg, uint32_t degree_bits, sbn_prover** out);

@@ -49,6 +49,7 @@ pub const SBN_AIR_FQ12_MUL: i32 = 8;
 /// the reference's unit-test tables `MyStark` (lookup.rs) and `FlagStark` (flags.rs)
 pub const SBN_AIR_LOOKUP: i32 = 9;
 pub const SBN_AIR_FLAGS: i32 = 10;
+pub const SBN_AIR_FLAGS_U64: i32 = 11;
 
 extern "C" {
     pub fn sbn_abi_version() -> i32;

@@ -1540,4 +1540,42 @@ struct FlagAir : AirBase<FlagAir> {
   }
 };
 
+// The FlagStark of src/fields/fq12_u64/flags_u64.rs:282-420, the flags_u64 unit-test table: 6 flag columns, the io-pulse
+// counter and (witness, pulse) per block boundary; 128 rows per input; constraints :338-375.
+struct FlagU64Air : AirBase<FlagU64Air> {
+  size_t num_io;
+  std::vector<size_t> pulse_positions;
+  static constexpr int MAIN_COLS = 6;
+  explicit FlagU64Air(size_t n) : num_io(n) { for (size_t i = 0; i < n; i++) { pulse_positions.push_back(i * 128); pulse_positions.push_back(i * 128 + 127); } }
+  size_t num_columns() const override { return MAIN_COLS + 1 + 4 * num_io; }   // :285
+  size_t num_public_inputs() const override { return 0; }
+  std::vector<std::pair<size_t, size_t>> permutation_pairs() const override { return {}; }
+  template <class P> void eval_t(const P* lv, const P* nv, const P*, Consumer<P>& yc) const {
+    P output = cst<P>(0);
+    for (size_t i = 1; i < 2 * num_io; i += 2) output = output + lv[get_pulse_col(MAIN_COLS, (int)i)];
+    yc.constraint(lv[0] - output);
+    eval_flags_u64(yc, lv, nv, 0);
+    eval_pulse(yc, lv, nv, MAIN_COLS, pulse_positions);
+  }
+  std::vector<std::vector<GF>> generate_trace(const std::vector<uint64_t>& inputs) const {   // :316-337
+    assert(inputs.size() == num_io);
+    const size_t rows = 128 * num_io;
+    std::vector<std::vector<GF>> cols(MAIN_COLS, std::vector<GF>(rows));
+    for (size_t k = 0; k < num_io; k++) {
+      std::vector<GF> lv(MAIN_COLS, GF()), nvv(MAIN_COLS, GF());
+      generate_flags_u64_first_row(lv.data(), 0, inputs[k]);
+      for (int c = 0; c < MAIN_COLS; c++) cols[c][k * 128] = lv[c];
+      for (size_t i = 0; i + 1 < 128; i++) {
+        std::fill(nvv.begin(), nvv.end(), GF());
+        generate_flags_u64_next_row(lv.data(), nvv.data(), i, 0);
+        for (int c = 0; c < MAIN_COLS; c++) cols[c][k * 128 + i + 1] = nvv[c];
+        lv.swap(nvv);
+      }
+    }
+    generate_pulse(cols, pulse_positions);
+    assert(cols.size() == num_columns());
+    return cols;
+  }
+};
+
 }  // namespace orc

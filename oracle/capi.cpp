@@ -20,6 +20,7 @@ static std::unique_ptr<Air> make_air(int kind, size_t num_io) {
   if (kind == 8) return std::unique_ptr<Air>(new Fq12MulAir());
   if (kind == 9) return std::unique_ptr<Air>(new LookupAir());
   if (kind == 10) return std::unique_ptr<Air>(new FlagAir(num_io));
+  if (kind == 11) return std::unique_ptr<Air>(new FlagU64Air(num_io));
   return nullptr;
 }
 static U256 u256_from_u32(const uint32_t* w) {
@@ -264,6 +265,14 @@ int orc_flags_generate_trace(const uint32_t* limbs, size_t num_io, uint64_t* tra
   std::vector<std::array<uint32_t, NUM_INPUT_LIMBS>> in(num_io);
   for (size_t k = 0; k < num_io; k++) for (int i = 0; i < NUM_INPUT_LIMBS; i++) in[k][i] = limbs[8 * k + i];
   auto cols = air.generate_trace(in);
+  const size_t rows = cols[0].size();
+  for (size_t c = 0; c < cols.size(); c++) for (size_t i = 0; i < rows; i++) trace_out[c * rows + i] = cols[c][i].v;
+  return 0;
+}
+
+int orc_flags_u64_generate_trace(const uint64_t* exps, size_t num_io, uint64_t* trace_out) {
+  FlagU64Air air(num_io);
+  auto cols = air.generate_trace(std::vector<uint64_t>(exps, exps + num_io));
   const size_t rows = cols[0].size();
   for (size_t c = 0; c < cols.size(); c++) for (size_t i = 0; i < rows; i++) trace_out[c * rows + i] = cols[c][i].v;
   return 0;

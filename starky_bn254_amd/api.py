@@ -15,6 +15,7 @@ AIR_MODULAR = 7
 AIR_FQ12_MUL = 8
 AIR_LOOKUP = 9
 AIR_FLAGS = 10
+AIR_FLAGS_U64 = 11
 AIR_G1_EXP = 2
 AIR_G2_EXP = 3
 AIR_FQ12_EXP = 4
@@ -29,7 +30,7 @@ EXPORTS = [
     "sbn_version", "sbn_last_error", "sbn_device_count", "sbn_set_device", "sbn_standard_fast_config",
     "sbn_air_num_columns", "sbn_air_num_public_inputs", "sbn_air_num_permutation_zs", "sbn_air_num_constraints",
     "sbn_generate_trace_g1_exp", "sbn_generate_trace_g2_exp", "sbn_generate_trace_fq12_exp", "sbn_generate_trace_fq_exp", "sbn_generate_trace_fq12_exp_u64",
-    "sbn_generate_trace_g1_op", "sbn_generate_trace_modular", "sbn_generate_trace_fq12_mul", "sbn_generate_trace_lookup", "sbn_generate_trace_flags",
+    "sbn_generate_trace_g1_op", "sbn_generate_trace_modular", "sbn_generate_trace_fq12_mul", "sbn_generate_trace_lookup", "sbn_generate_trace_flags", "sbn_generate_trace_flags_u64",
     "sbn_prover_create", "sbn_prover_destroy", "sbn_prover_load_trace", "sbn_prover_load_trace_device",
     "sbn_prover_prove", "sbn_prover_stage_times", "sbn_prover_stage_name", "sbn_prover_trace_device_ptr",
     "sbn_prover_generate_trace", "sbn_prover_read_trace",
@@ -96,6 +97,7 @@ def lib():
         L.sbn_generate_trace_fq12_mul.argtypes = [vp, sz, vp]
         L.sbn_generate_trace_lookup.argtypes = [vp, vp, sz, vp]
         L.sbn_generate_trace_flags.argtypes = [vp, sz, vp]
+        L.sbn_generate_trace_flags_u64.argtypes = [vp, sz, vp]
         L.sbn_prover_create.argtypes = [C.POINTER(_AirDesc), C.POINTER(_Config), u32, C.POINTER(vp)]
         L.sbn_prover_destroy.argtypes = [vp]
         L.sbn_prover_load_trace.argtypes = [vp, vp, vp, sz]
@@ -253,6 +255,19 @@ class FlagStark(_Stark):
         assert limbs.shape == (self.num_io, 8)
         trace = np.zeros((self.num_columns, 512 * self.num_io), dtype=np.uint64)
         _check(lib().sbn_generate_trace_flags(_ptr(limbs), self.num_io, _ptr(trace)))
+        return trace
+
+
+class FlagU64Stark(_Stark):
+    """The `FlagStark` of src/fields/fq12_u64/flags_u64.rs:289-420 (u64 exponents, 128 rows per input, no permutation pairs)."""
+    kind = AIR_FLAGS_U64
+
+    def generate_trace(self, exps):
+        """exps: (num_io,) uint64 < p -> (7 + 4 num_io, 128 num_io) uint64."""
+        exps = np.ascontiguousarray(exps, dtype=np.uint64)
+        assert exps.shape == (self.num_io,)
+        trace = np.zeros((self.num_columns, 128 * self.num_io), dtype=np.uint64)
+        _check(lib().sbn_generate_trace_flags_u64(_ptr(exps), self.num_io, _ptr(trace)))
         return trace
 
 

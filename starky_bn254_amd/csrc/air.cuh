@@ -639,6 +639,39 @@ struct FlagShape {
   GL_HD int witness_col(int i) const { return START_IO_PULSES + 1 + 2 * i; }   // pulse.rs:14
   GL_HD int pulse_col(int i) const { return START_IO_PULSES + 2 + 2 * i; }     // pulse.rs:10
 };
+// The u64 variant (src/fields/fq12_u64/flags_u64.rs:282-377): 6 flag columns, 128 rows per input, no rotation pulse.
+struct FlagU64Shape {
+  int num_io;
+  GL_HD explicit FlagU64Shape(int n) : num_io(n) {}
+  static constexpr int MAIN_COLS = 6;
+  GL_HD int num_cols() const { return MAIN_COLS + 1 + 4 * num_io; }                              // flags_u64.rs:285
+  GL_HD int num_constraints() const { return 1 + FLAGS_U64_CONSTRAINTS + 2 + 4 * num_io; }
+  GL_HD int witness_col(int i) const { return MAIN_COLS + 1 + 2 * i; }
+  GL_HD int pulse_col(int i) const { return MAIN_COLS + 2 + 2 * i; }
+};
+template <class P, class Row>
+GL_HD void flag_u64_eval(Cons<P>& cs, const Row& row, const FlagU64Shape& sh) {   // flags_u64.rs:338-375
+  const P one = lift<P>(1);
+  P sum_out = lift<P>(0);
+  for (int i = 0; i < sh.num_io; i++) sum_out = sum_out + row.l(sh.pulse_col(2 * i + 1));
+  cs.c(row.l(0) - sum_out);
+  Horner2<P> hf(FLAGS_U64_CONSTRAINTS);
+  flags_u64_block(cs, row, 0, hf);
+  P hfv[SBN_NCH];
+  hf.value(hfv);
+  cs.merge(hfv, one, FLAGS_U64_CONSTRAINTS);
+  const int st = FlagU64Shape::MAIN_COLS;
+  P counter = row.l(st);
+  cs.cf(counter);
+  cs.ct(row.n(st) - counter - one);
+  for (int i = 0; i < 2 * sh.num_io; i++) {
+    u64 pos = (u64)(i >> 1) * 128 + ((i & 1) ? 127 : 0);
+    P cmp = counter - lift<P>(pos);
+    P pulse = row.l(sh.pulse_col(i));
+    cs.c(cmp * row.l(sh.witness_col(i)) + pulse - one);
+    cs.c(cmp * pulse);
+  }
+}
 template <class P, class Row>
 GL_HD void flag_eval(Cons<P>& cs, const Row& row, const FlagShape& sh) {   // flags.rs:449-492, in its emission order
   const P one = lift<P>(1);

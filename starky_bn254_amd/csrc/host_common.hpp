@@ -76,6 +76,10 @@ static inline bool air_shape(const sbn_air_desc* air, const sbn_config* cfg, Air
     if (air->num_io == 0 || air->num_io > (u32)G1EXP_MAX_IO || (air->num_io & (air->num_io - 1))) return false;
     FlagShape sh((int)air->num_io);
     s.ncols = sh.num_cols(); s.npi = 0; s.npairs = 0; s.nconstraints = sh.num_constraints();
+  } else if (air->kind == SBN_AIR_FLAGS_U64) {
+    if (air->num_io < 4 || air->num_io > 4 * (u32)G1EXP_MAX_IO || (air->num_io & (air->num_io - 1))) return false;
+    FlagU64Shape sh((int)air->num_io);
+    s.ncols = sh.num_cols(); s.npi = 0; s.npairs = 0; s.nconstraints = sh.num_constraints();
   } else if (air->kind == SBN_AIR_G1_EXP || air->kind == SBN_AIR_G2_EXP || air->kind == SBN_AIR_FQ12_EXP || air->kind == SBN_AIR_FQ_EXP || air->kind == SBN_AIR_FQ12_EXP_U64) {
     if (air->num_io == 0 || air->num_io > (u32)G1EXP_MAX_IO || (air->num_io & (air->num_io - 1))) return false;
     ExpShape sh(exp_e(air->kind), (int)air->num_io);
@@ -87,7 +91,7 @@ static inline bool air_shape(const sbn_air_desc* air, const sbn_config* cfg, Air
 }
 static inline bool is_op_air(int kind) { return kind == SBN_AIR_MODULAR || kind == SBN_AIR_FQ12_MUL; }   // OpShape tables (air.cuh)
 static inline bool is_exp_air(int kind) { return kind == SBN_AIR_G1_EXP || kind == SBN_AIR_G2_EXP || kind == SBN_AIR_FQ12_EXP || kind == SBN_AIR_FQ_EXP || kind == SBN_AIR_FQ12_EXP_U64; }
-static inline size_t exp_rows_per_instance(int kind) { return kind == SBN_AIR_FQ12_EXP_U64 ? 128 : 512; }   // (FLAGS: 512 too)
+static inline size_t exp_rows_per_instance(int kind) { return (kind == SBN_AIR_FQ12_EXP_U64 || kind == SBN_AIR_FLAGS_U64) ? 128 : 512; }   // (FLAGS: 512)
 // u32 words of one instance in the `ios` arrays of include/sbn.h (x, offset, exp_val)
 static inline size_t exp_io_words(int kind) {
   switch (kind) {

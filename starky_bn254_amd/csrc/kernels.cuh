@@ -730,6 +730,8 @@ __global__ __launch_bounds__(256, 2) void quotient_kernel(QuotientParams p, cons
     }
   } else if (KIND == 10) {  // FlagStark: no permutation pairs, segments 1-3 are empty
     if (PART == 0) flag_eval(cs, row, FlagShape(p.num_io));
+  } else if (KIND == 11) {  // the u64 FlagStark
+    if (PART == 0) flag_u64_eval(cs, row, FlagU64Shape(p.num_io));
   } else if (KIND == 7 || KIND == 8) {   // ModularStark / Fq12Stark: everything but the permutation checks is the head segment
     const OpShape sh(KIND);
     if (PART == 0) op_eval<KIND>(cs, row, sh);

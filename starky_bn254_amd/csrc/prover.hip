@@ -498,6 +498,7 @@ static int create_ctx(const sbn_air_desc* air, const sbn_config* cfg, uint32_t d
   if (!air_shape(air, cfg, as)) return fail(SBN_ERR_BAD_ARG, "unknown air kind / num_io");
   if (degree_bits < 9 || degree_bits > 22) return fail(SBN_ERR_UNSUPPORTED, "degree_bits out of range");
   if (as.kind == SBN_AIR_FLAGS && (512 * (size_t)as.num_io) != ((size_t)1 << degree_bits)) return fail(SBN_ERR_BAD_ARG, "FlagStark needs 512*num_io rows");
+  if (as.kind == SBN_AIR_FLAGS_U64 && (128 * (size_t)as.num_io) != ((size_t)1 << degree_bits)) return fail(SBN_ERR_BAD_ARG, "the u64 FlagStark needs 128*num_io rows");
   if (is_exp_air(as.kind)) {
     if ((exp_rows_per_instance(as.kind) * as.num_io) != ((size_t)1 << degree_bits)) return fail(SBN_ERR_BAD_ARG, "the Exp tables need 512*num_io rows (FQ12_EXP_U64: 128*num_io)");
     if (as.kind != SBN_AIR_FQ12_EXP && as.kind != SBN_AIR_FQ12_EXP_U64 && degree_bits < 16)
@@ -1046,6 +1047,7 @@ static int launch_quotient_parts(sbn_prover* P, const QuotientParams& qp, size_t
     case SBN_AIR_FQ12_MUL: launch_quotient_kind<8>(P, qp, qblocks); break;
     case SBN_AIR_LOOKUP: launch_quotient_kind<9>(P, qp, qblocks); break;
     case SBN_AIR_FLAGS: launch_quotient_kind<10>(P, qp, qblocks); break;
+    case SBN_AIR_FLAGS_U64: launch_quotient_kind<11>(P, qp, qblocks); break;
     default: launch_quotient_kind<4>(P, qp, qblocks); break;
   }
   HIPC(hipGetLastError());

@@ -370,6 +370,29 @@ extern "C" int sbn_generate_trace_flags(const uint32_t* limbs, size_t num_io, ui
   return SBN_OK;
 }
 
+// the FlagStark of src/fields/fq12_u64/flags_u64.rs:316-337: flags_u64 of every input (closed form: bit t of e is consumed on rows
+// 2t, 2t+1), then the block-boundary pulses; no rotation pulse
+extern "C" int sbn_generate_trace_flags_u64(const uint64_t* exps, size_t num_io, uint64_t* trace) {
+  if (!exps || !trace) return fail(SBN_ERR_BAD_ARG, "null argument");
+  if (num_io < 4 || num_io > 4 * (size_t)G1EXP_MAX_IO || (num_io & (num_io - 1))) return fail(SBN_ERR_BAD_ARG, "num_io must be a power of two between 4 and %d", 4 * G1EXP_MAX_IO);
+  const size_t n = 128 * num_io;
+  const FlagU64Shape sh((int)num_io);
+  auto col = [&](int c) { return trace + (size_t)c * n; };
+  memset(trace, 0, (size_t)sh.num_cols() * n * sizeof(u64));
+  for (size_t k = 0; k < num_io; k++) {
+    const u64 e = exps[k];
+    if (e >= GLP) return fail(SBN_ERR_NON_CANONICAL, "exponent %zu is not a canonical field element", k);
+    for (size_t r = 0; r < 128; r++) {
+      const size_t row = k * 128 + r;
+      const unsigned t = (unsigned)(r >> 1);
+      const u64 fa = r & 1, fb = 1 - fa, bit = (e >> t) & 1, val = t == 63 ? 0 : e >> (t + 1);
+      col(0)[row] = r == 127; col(1)[row] = fa; col(2)[row] = fb; col(3)[row] = bit * fb; col(4)[row] = bit; col(5)[row] = val;
+    }
+  }
+  fill_pulses_at(trace, n, -1, FlagU64Shape::MAIN_COLS, num_io, 128);
+  return SBN_OK;
+}
+
 extern "C" int sbn_generate_trace_g1_exp(const uint32_t* ios, size_t num_io, uint64_t* trace, uint64_t* pi_out) {
   return generate_exp_trace<1>(ios, num_io, trace, pi_out);
 }

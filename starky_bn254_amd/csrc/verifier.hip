@@ -89,7 +89,7 @@ extern "C" int sbn_verify(const sbn_air_desc* air, const sbn_config* cfg, const 
   if (ncol != as.ncols || nz != as.nzs || nq != 2 * cfg->num_challenges || npi != as.npi || cap_h != cfg->cap_height || rate_bits != cfg->rate_bits ||
       nlayers != fs.arity_bits.size() || arity_bits != cfg->fri_arity_bits || fpl != fs.final_poly_len() || nqueries != cfg->num_query_rounds)
     return fail(SBN_ERR_MALFORMED_PROOF, "proof shape does not match the table / config");
-  if ((is_exp_air(as.kind) || as.kind == SBN_AIR_FLAGS) && ((u64)exp_rows_per_instance(as.kind) * as.num_io) != ((u64)1 << degree_bits)) return fail(SBN_ERR_MALFORMED_PROOF, "degree_bits does not match num_io");
+  if ((is_exp_air(as.kind) || as.kind == SBN_AIR_FLAGS || as.kind == SBN_AIR_FLAGS_U64) && ((u64)exp_rows_per_instance(as.kind) * as.num_io) != ((u64)1 << degree_bits)) return fail(SBN_ERR_MALFORMED_PROOF, "degree_bits does not match num_io");
   const u32 lde_bits = (u32)degree_bits + cfg->rate_bits;
   if (lde_bits < cfg->cap_height + fs.total_arity()) return fail(SBN_ERR_MALFORMED_PROOF, "degree too small for the FRI parameters");
   const size_t capn = (size_t)1 << cfg->cap_height;
@@ -185,6 +185,8 @@ extern "C" int sbn_verify(const sbn_air_desc* air, const sbn_config* cfg, const 
     permutation_checks(cs, row, zrow, LookupShape(), (int)nz, g0, g1);
   } else if (as.kind == SBN_AIR_FLAGS) {
     flag_eval(cs, row, FlagShape((int)as.num_io));   // no permutation pairs: nz = 0, no Z cap, no permutation challenges
+  } else if (as.kind == SBN_AIR_FLAGS_U64) {
+    flag_u64_eval(cs, row, FlagU64Shape((int)as.num_io));
   } else {
     ExpShape sh = exp_shape(as);
     std::vector<E2> epi(npi); for (size_t i = 0; i < npi; i++) epi[i] = E2(pi[i]);
@@ -290,6 +292,8 @@ extern "C" int sbn_eval_constraints_host(const sbn_air_desc* air, const uint64_t
     lookup_eval(cs, row);
   } else if (as.kind == SBN_AIR_FLAGS) {
     flag_eval(cs, row, FlagShape((int)as.num_io));
+  } else if (as.kind == SBN_AIR_FLAGS_U64) {
+    flag_u64_eval(cs, row, FlagU64Shape((int)as.num_io));
   } else {
     ExpShape sh = exp_shape(as);
     std::vector<F> fpi(n_pi); for (size_t i = 0; i < n_pi; i++) fpi[i] = F(public_inputs[i]);

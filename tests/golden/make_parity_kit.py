@@ -32,6 +32,7 @@ CASES = {
     "mystark_lookup_fixed": ("MyStark", "AIR_LOOKUP", 8, None, None, None, False),
     "mystark_rows512_seed9": ("MyStark", "AIR_LOOKUP", 512, 9, "lookup_inputs", "lookup_trace", False),
     "flagstark_io16_seed8": ("FlagStark", "AIR_FLAGS", 16, 8, "flags_inputs", "flags_trace", False),
+    "flagu64stark_io16_seed10": ("FlagU64Stark", "AIR_FLAGS_U64", 16, 10, "flags_u64_inputs", "flags_u64_trace", False),
     "modular_rows512_seed6": ("ModularStark", "AIR_MODULAR", 512, 6, "modular_inputs", "modular_trace", False),
     "g1op_rows512_seed0": ("G1Stark", "AIR_G1_OP", 512, 0, "g1op_inputs", "g1op_trace", False),
     "fq12expu64_io16_seed5": ("Fq12ExpU64Stark", "AIR_FQ12_EXP_U64", 16, 5, "fq12expu64_inputs", "fq12expu64_trace", False),
@@ -45,6 +46,7 @@ INPUT_LAYOUT = {
                "fixed vectors [6, 3, 1, 1, 0, 0, 0, 0] / 0..7, src/utils/lookup.rs:154-161 (ORACLE ONLY: 8 rows are below the device prover's minimum; run the reference's "
                "test_mystark, lookup.rs:215-229, and compare)",
     "FlagStark": "num_io x 8 u32 limbs (sbn_generate_trace_flags; flags.rs:551-554 draws them at random)",
+    "FlagU64Stark": "num_io x 2 u32 = the u64 exponents, low word first (sbn_generate_trace_flags_u64 takes them as u64; flags_u64.rs:427)",
     "ModularStark": "rows x 16 u32 = a[8] b[8] (sbn_generate_trace_modular)",
     "G1Stark": "rows x 32 u32 = a.x[8] a.y[8] b.x[8] b.y[8] (sbn_generate_trace_g1_op)",
     "G1ExpStark": "num_io x 40 u32 = x.x[8] x.y[8] offset.x[8] offset.y[8] exp_val[8] (sbn_generate_trace_g1_exp)",
@@ -65,13 +67,13 @@ def build_case(name, variants=("times_x", "plain")):
         inputs, _ = getattr(O, fin)(size, seed)
         res = getattr(O, ftr)(inputs)
         trace, pi = res if isinstance(res, tuple) else (res, np.zeros(0, dtype=np.uint64))
-    is_exp = table.endswith("ExpStark") or table in ("Fq12ExpU64Stark", "FlagStark")   # tables parametrised by an instance count
+    is_exp = table.endswith("ExpStark") or table in ("Fq12ExpU64Stark", "FlagStark", "FlagU64Stark")   # tables parametrised by an instance count
     out = {
         "about": "reference-parity hand-over kit: inputs + per-stage digests of the ORACLE's proof (a restatement; parity vs the Rust reference is unpinned)",
         "table": table, "air_kind": int(getattr(O, kind)), "num_io": size if is_exp else 0, "rows": int(trace.shape[1]), "seed": seed,
         "config": "StarkConfig::standard_fast_config: security 100, 2 challenges, rate_bits 1, cap_height 4, pow 16, ConstantArityBits(4, 5), 84 queries",
-        "inputs_layout": INPUT_LAYOUT[table], "inputs_shape": list(np.asarray(inputs).shape),
-        "inputs_u32": [int(x) for x in np.asarray(inputs, dtype=np.uint32).reshape(-1)],
+        "inputs_layout": INPUT_LAYOUT[table], "inputs_shape": [len(inputs), 2] if table == "FlagU64Stark" else list(np.asarray(inputs).shape),
+        "inputs_u32": [int(x) for x in (np.asarray(inputs, dtype=np.uint64).view(np.uint32) if table == "FlagU64Stark" else np.asarray(inputs, dtype=np.uint32)).reshape(-1)],
         "num_columns": int(trace.shape[0]),
         "trace_sha256": hashlib.sha256(trace.tobytes()).hexdigest(),
         "public_inputs_sha256": hashlib.sha256(np.asarray(pi, dtype=np.uint64).tobytes()).hexdigest(),

@@ -550,6 +550,21 @@ AIR_LOOKUP = 9      # oracle only: MyStark, the lookup unit-test table (src/util
 AIR_FLAGS = 10      # FlagStark, the flags unit-test table (src/utils/flags.rs:379-547): no permutation pairs
 
 
+AIR_FLAGS_U64 = 11  # the FlagStark of src/fields/fq12_u64/flags_u64.rs (u64 exponents, 128 rows each)
+
+
+def flags_u64_inputs(num_io, seed):
+    return np.random.default_rng(seed).integers(0, GL_P, size=num_io, dtype=np.uint64), None
+
+
+def flags_u64_trace(exps):
+    exps = np.ascontiguousarray(exps, dtype=np.uint64)
+    k = exps.shape[0]
+    trace = np.zeros((7 + 4 * k, 128 * k), dtype=np.uint64)
+    lib().orc_flags_u64_generate_trace(ptr(exps), k, ptr(trace))
+    return trace
+
+
 def lookup_inputs(rows, seed):
     """A MyStark instance of `rows` rows: table 0 .. rows-1 shuffled, inputs drawn from a quarter of the table (repeats)."""
     rng = np.random.default_rng(seed)

@@ -156,6 +156,21 @@ def test_flagstark_proof_bit_exact(gpu, O, num_io, seed):
         gpu.verify_stark_proof(stark, p2, cfg)
 
 
+def test_flag_u64_stark_proof_bit_exact(gpu, O):
+    """The `FlagStark` of src/fields/fq12_u64/flags_u64.rs:289-447 (16 u64 exponents as in its test, :425-447): GPU proof
+    words == the oracle's, no permutation-Z commitment, both verifiers accept."""
+    stark = gpu.FlagU64Stark(16)
+    cfg = stark.config()
+    exps, _ = O.flags_u64_inputs(16, 10)
+    trace = stark.generate_trace(exps)
+    proof = gpu.prove(stark, cfg, trace, np.zeros(0, dtype=np.uint64))
+    ref, _ = O.prove(O.AIR_FLAGS_U64, 16, trace, np.zeros(0, dtype=np.uint64))
+    assert np.array_equal(proof.words, ref)
+    assert [int(x) for x in proof.words[1:6]] == [11, 71, 0, 4, 0]
+    assert O.verify(O.AIR_FLAGS_U64, 16, proof.words) == (0, "")
+    gpu.verify_stark_proof(stark, proof, cfg)
+
+
 def test_g1stark_proof_without_the_times_x_step(gpu, O):
     """sbn_config.fri_variant = SBN_FRI_PLAIN (later upstream plonky2: no multiply-by-X of the FRI final polynomial):
     GPU proof bytes == the oracle's in the same mode, and differ from the default mode's."""

@@ -17,13 +17,13 @@ import parity_kit as K
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KIT_DIR = os.path.join(ROOT, "tests", "golden", "parity_kit")
 ORACLE_ONLY = ["mystark_lookup_fixed"]      # the reference's pinned 8-row lookup table: below the device prover's minimum size
-CASES = ["mystark_rows512_seed9", "flagstark_io16_seed8", "modular_rows512_seed6", "g1op_rows512_seed0", "fq12expu64_io16_seed5", "fq12exp_io16_seed3", "g1exp_io128_seed1", "fqexp_io128_seed4",
+CASES = ["mystark_rows512_seed9", "flagstark_io16_seed8", "flagu64stark_io16_seed10", "modular_rows512_seed6", "g1op_rows512_seed0", "fq12expu64_io16_seed5", "fq12exp_io16_seed3", "g1exp_io128_seed1", "fqexp_io128_seed4",
          "g2exp_io128_seed2"]
 # (inputs, trace) generators of the oracle per table
 GEN = {"ModularStark": ("modular_inputs", "modular_trace"), "G1Stark": ("g1op_inputs", "g1op_trace"), "G1ExpStark": ("g1exp_inputs", "g1exp_trace"),
        "G2ExpStark": ("g2exp_inputs", "g2exp_trace"), "Fq12ExpStark": ("fq12exp_inputs", "fq12exp_trace"),
        "Fq12ExpU64Stark": ("fq12expu64_inputs", "fq12expu64_trace"), "FqExpStark": ("fqexp_inputs", "fqexp_trace"),
-       "FlagStark": ("flags_inputs", "flags_trace")}
+       "FlagStark": ("flags_inputs", "flags_trace"), "FlagU64Stark": ("flags_u64_inputs", "flags_u64_trace")}
 
 
 def load(case):
@@ -60,7 +60,8 @@ def _oracle_case(O, kit):
     fin, ftr = GEN[kit["table"]]
     size = kit["num_io"] or kit["rows"]
     inputs, _ = getattr(O, fin)(size, kit["seed"])
-    assert [int(x) for x in np.asarray(inputs, dtype=np.uint32).reshape(-1)] == kit["inputs_u32"], "the committed inputs are not the seeded ones"
+    flat = np.asarray(inputs, dtype=np.uint64).view(np.uint32) if kit["table"] == "FlagU64Stark" else np.asarray(inputs, dtype=np.uint32)
+    assert [int(x) for x in flat.reshape(-1)] == kit["inputs_u32"], "the committed inputs are not the seeded ones"
     res = getattr(O, ftr)(inputs)
     trace, pi = res if isinstance(res, tuple) else (res, np.zeros(0, dtype=np.uint64))
     return inputs, trace, pi
@@ -68,6 +69,7 @@ def _oracle_case(O, kit):
 
 # G1ExpStark(128) is the headline workload: its default-variant stages are regenerated here too (about a minute on 8 cores)
 @pytest.mark.parametrize("case,variants", [("mystark_rows512_seed9", ("times_x", "plain")), ("flagstark_io16_seed8", ("times_x", "plain")),
+                                           ("flagu64stark_io16_seed10", ("times_x", "plain")),
                                            ("modular_rows512_seed6", ("times_x", "plain")), ("g1op_rows512_seed0", ("times_x", "plain")),
                                            ("fq12expu64_io16_seed5", ("times_x",)), ("g1exp_io128_seed1", ("times_x",))])
 def test_oracle_regenerates_the_kit(O, case, variants):
@@ -139,7 +141,9 @@ def test_gpu_proof_matches_the_kit_stage_by_stage(S, O, case):
     table = kit["table"]
     inputs = np.array(kit["inputs_u32"], dtype=np.uint32).reshape(kit["inputs_shape"])
     stark = getattr(S, table)(kit["num_io"]) if kit["num_io"] else getattr(S, table)()
-    host_witness = not kit["num_io"] or table == "FlagStark"      # the Exp tables build their witness on the device
+    host_witness = not kit["num_io"] or table in ("FlagStark", "FlagU64Stark")      # the Exp tables build their witness on the device
+    if table == "FlagU64Stark":
+        inputs = np.ascontiguousarray(inputs).view(np.uint64).reshape(-1)            # (low, high) u32 pairs -> the u64 exponents
     bits = kit["rows"].bit_length() - 1
     for v in ("times_x", "plain"):
         cfg = stark.config()

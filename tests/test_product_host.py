@@ -427,7 +427,7 @@ def test_rust_shim_prove_and_verify_have_the_reference_call_shape():
 
 
 @pytest.mark.parametrize("table,num_io", [("G1Stark", 0), ("G1ExpStark", 128), ("G2ExpStark", 128), ("Fq12ExpStark", 16), ("FqExpStark", 128),
-                                           ("Fq12ExpU64Stark", 16), ("ModularStark", 0), ("Fq12Stark", 0), ("LookupStark", 0), ("FlagStark", 16)])
+                                           ("Fq12ExpU64Stark", 16), ("ModularStark", 0), ("Fq12Stark", 0), ("LookupStark", 0), ("FlagStark", 16), ("FlagU64Stark", 16)])
 def test_regrouped_constraints_equal_the_oracle_on_random_rows(S, O, table, num_io):
     """air.cuh folds the constraints in regrouped form (local Horner sums, shared and factored limb convolutions, collapsed
     public-input block); the result must be the SAME field element as folding them one by one in the reference's order
@@ -436,7 +436,7 @@ def test_regrouped_constraints_equal_the_oracle_on_random_rows(S, O, table, num_
     stark = getattr(S, table)(num_io) if num_io else getattr(S, table)()
     kind = {"G1Stark": O.AIR_G1_OP, "G1ExpStark": O.AIR_G1_EXP, "G2ExpStark": O.AIR_G2_EXP, "Fq12ExpStark": O.AIR_FQ12_EXP, "FqExpStark": O.AIR_FQ_EXP,
             "Fq12ExpU64Stark": O.AIR_FQ12_EXP_U64, "ModularStark": O.AIR_MODULAR, "Fq12Stark": O.AIR_FQ12_MUL, "LookupStark": O.AIR_LOOKUP,
-            "FlagStark": O.AIR_FLAGS}[table]
+            "FlagStark": O.AIR_FLAGS, "FlagU64Stark": O.AIR_FLAGS_U64}[table]
     rng = np.random.default_rng(hash(table) % 1000 + 17)
     ncol, npi = stark.num_columns, stark.num_public_inputs
     for trial in range(3):
@@ -511,7 +511,12 @@ def test_unit_test_tables_shape_and_host_witness(S, O, golden):
     and FlagStark (flags.rs:379-547; 17 + 4 num_io columns, NO pairs): shapes, host witness == the oracle's, every constraint
     vanishes on the generated trace (both evaluators), a wrong table value does not; MyStark on the reference's fixed input
     reproduces the committed lookup fixture."""
-    lk, fl = S.LookupStark(), S.FlagStark(16)
+    lk, fl, fu = S.LookupStark(), S.FlagStark(16), S.FlagU64Stark(16)
+    assert (fu.num_columns, fu.num_public_inputs, fu.num_permutation_zs(), fu.num_constraints) == (71, 0, 0, 76)   # flags_u64.rs:285: 6 + 1 + 4 * 16
+    exps, _ = O.flags_u64_inputs(16, 10)
+    tu = fu.generate_trace(exps)
+    assert np.array_equal(tu, O.flags_u64_trace(exps))
+    assert [int(tu[3, 128 * 5 + 2 * k]) for k in range(64)] == [(int(exps[5]) >> k) & 1 for k in range(64)]        # filtered bits = the exponent's bits, LSB first
     assert (lk.num_columns, lk.num_public_inputs, lk.num_permutation_zs(), lk.num_constraints) == (4, 0, 2, 2)
     assert (fl.num_columns, fl.num_public_inputs, fl.num_permutation_zs(), fl.num_constraints) == (81, 0, 0, 98)   # flags.rs:376: MAIN_COLS + 2 + 1 + 4 * 16
     assert S.MyStark is S.LookupStark
@@ -526,9 +531,9 @@ def test_unit_test_tables_shape_and_host_witness(S, O, golden):
     assert np.array_equal(tf, O.flags_trace(limbs))
     assert [int(tf[4, 1024 + 2 * k]) for k in range(256)] == [(int(limbs[2][k // 32]) >> (k % 32)) & 1 for k in range(256)]   # test_flag_native, flags.rs:354-368
     g = 0x185629DCDA58878C                                       # primitive_root_of_unity(13)^-1 is not needed: z_last = x - g^-1 is any nonzero value off the last row
-    for stark, kind, num_io, t in ((lk, O.AIR_LOOKUP, 0, tr), (fl, O.AIR_FLAGS, 16, tf)):
+    for stark, kind, num_io, t in ((lk, O.AIR_LOOKUP, 0, tr), (fl, O.AIR_FLAGS, 16, tf), (fu, O.AIR_FLAGS_U64, 16, tu)):
         n = t.shape[1]
-        for r in (0, 1, 63, 511, n - 2, n - 1):
+        for r in (0, 1, 63, 127, 511, n - 2, n - 1):
             lv, nv = t[:, r], t[:, (r + 1) % n]
             sel = (1 if r != n - 1 else 0, 1 if r == 0 else 0, 1 if r == n - 1 else 0)   # transition, first row, last row selectors
             assert S.eval_constraints_host(stark, lv, nv, [], [3, 5], *sel) == [0, 0], (kind, r)
