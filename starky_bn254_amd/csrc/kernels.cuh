@@ -38,6 +38,11 @@ struct NttPassParams {
   // the 512-point kernel's footprint and reads the (cache-resident) input twice.
   const u64* pre2;
   u32 split;
+  // fast pass only.  xcd_order = 1: the grid is (columns, tiles) instead of (tiles, columns), so that the workgroups of one
+  // column have equal blockIdx.x % 8 when the column count is a multiple of 8 -- one XCD under the observed round-robin
+  // placement -- in EVERY pass of a column chunk: an experiment in keeping the tmp round trips between passes inside one
+  // XCD's L2 (SBN_NTT_XCD=1 with SBN_NTT_SUB=<columns per sub-chunk>; DESIGN.md section 7 has the measurement).
+  u32 xcd_order;
 };
 
 GL_HD F tw_lookup(const u64* tw, u32 tw_log, u64 e_of_order, u32 order_log) {
@@ -212,8 +217,8 @@ __global__ __launch_bounds__(256) void ntt_fast_pass_kernel(NttPassParams p, u32
   extern __shared__ u64 lds[];
   constexpr u32 NB = 1u << LOG_B;       // 256-point blocks per tile column
   constexpr u32 R = 256u << LOG_B;
-  const size_t col = blockIdx.y;
-  const size_t t0 = (size_t)blockIdx.x << 4;
+  const size_t col = p.xcd_order ? blockIdx.x : blockIdx.y;
+  const size_t t0 = (size_t)(p.xcd_order ? blockIdx.y : blockIdx.x) << 4;
   const u32 half = p.split ? blockIdx.z : 0u;            // split: which parity of the 1,024-point pass's outputs
   const u64* __restrict__ pre = half ? p.pre2 : p.pre;
   const u64* in = p.in + col * p.in_col_stride;

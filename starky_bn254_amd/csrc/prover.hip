@@ -121,6 +121,8 @@ struct sbn_prover {
   hipEvent_t ev[ST_COUNT + 1];
   float stage_ms[ST_COUNT + EX_COUNT];
   size_t ntt_chunk;
+  size_t ntt_sub = 0;                        // SBN_NTT_SUB: transform the columns of a chunk in sub-chunks of this many (0: whole chunk)
+  bool ntt_xcd = false;                      // SBN_NTT_XCD=1: (columns, tiles) grid order in the fast passes
   bool fast_ntt = true;                      // SBN_FAST_NTT=0 selects the generic radix-2 pass everywhere
   hipStream_t hstream = nullptr;             // sponge absorption / Merkle stream
   hipEvent_t chunk_ready[MAX_CHUNKS];        // main -> hash: LDE chunk k is complete
@@ -171,9 +173,11 @@ static int ntt_columns(sbn_prover* P, const u64* in, size_t in_cs, u64* out, siz
     dim3 ga((unsigned)(n2 >> pa.log_t), (unsigned)nc), gb((unsigned)(n1 >> pb.log_t), (unsigned)nc);
     size_t la = ((size_t)1 << pa.log_r) * ((1u << pa.log_t) + 1) * 8, lb = ((size_t)1 << pb.log_r) * ((1u << pb.log_t) + 1) * 8;
     const u32 kperm = inverse ? 11u : 5u;  // omega_16 = (2^12)^13, omega_16^-1 = (2^12)^3: 13^-1 = 5, 3^-1 = 11 (mod 16)
-    auto launch = [&](const NttPassParams& q, dim3 grid, size_t lds_bytes) {
-      if (P->fast_ntt && q.log_t == 4 && q.log_r == 8) hipLaunchKernelGGL(ntt_fast_pass_kernel<0>, grid, dim3(256), 16 * 272 * 8, st, q, kperm);
-      else if (P->fast_ntt && q.log_t == 4 && q.log_r == 9) hipLaunchKernelGGL(ntt_fast_pass_kernel<1>, grid, dim3(256), 32 * 272 * 8, st, q, kperm);
+    auto launch = [&](NttPassParams q, dim3 grid, size_t lds_bytes) {
+      const bool fast = P->fast_ntt && q.log_t == 4 && (q.log_r == 8 || q.log_r == 9);
+      if (fast && P->ntt_xcd) { q.xcd_order = 1; std::swap(grid.x, grid.y); }
+      if (fast && q.log_r == 8) hipLaunchKernelGGL(ntt_fast_pass_kernel<0>, grid, dim3(256), 16 * 272 * 8, st, q, kperm);
+      else if (fast) hipLaunchKernelGGL(ntt_fast_pass_kernel<1>, grid, dim3(256), 32 * 272 * 8, st, q, kperm);
       else hipLaunchKernelGGL(ntt_pass_kernel, grid, dim3(NTT_THREADS), lds_bytes, st, q);
     };
     if (P->fast_ntt && pa.log_r == 9 && log_n2 >= 4) pa.log_t = 4;  // the fast kernel always uses 16-wide tiles
@@ -235,10 +239,16 @@ static int intt_then_lde(sbn_prover* P, const u64* vals, u64* coef, u64* lde, si
 }
 
 static int intt_then_lde_chunk(sbn_prover* P, const u64* vals, u64* coef, u64* lde, size_t c0, size_t nc) {
-  int rc = ntt_columns(P, vals + c0 * P->n, P->n, coef + c0 * P->n, P->n, P->d_tmp, P->m, nc, P->degree_bits, true, P->n, nullptr, nullptr,
-                       host_inv_pow2(P->degree_bits));
-  if (rc) return rc;
-  return ntt_columns(P, coef + c0 * P->n, P->n, lde + c0 * P->m, P->m, P->d_tmp, P->m, nc, P->lde_log, false, P->n, P->d_shift, nullptr, 1);
+  const size_t sub = P->ntt_sub ? P->ntt_sub : nc;
+  for (size_t s0 = 0; s0 < nc; s0 += sub) {   // (sub-chunks reuse the front of d_tmp: an experiment in L2 residency, SBN_NTT_SUB)
+    const size_t a = c0 + s0, k = std::min(sub, nc - s0);
+    int rc = ntt_columns(P, vals + a * P->n, P->n, coef + a * P->n, P->n, P->d_tmp, P->m, k, P->degree_bits, true, P->n, nullptr, nullptr,
+                         host_inv_pow2(P->degree_bits));
+    if (rc) return rc;
+    rc = ntt_columns(P, coef + a * P->n, P->n, lde + a * P->m, P->m, P->d_tmp, P->m, k, P->lde_log, false, P->n, P->d_shift, nullptr, 1);
+    if (rc) return rc;
+  }
+  return 0;
 }
 
 static int tree_alloc(DevTree& t, size_t nleaf, u32 cap_height) {
@@ -527,6 +537,8 @@ static int create_ctx(const sbn_air_desc* air, const sbn_config* cfg, uint32_t d
     P->ntt_chunk = (size_t)v;
   }
   { const char* fe = getenv("SBN_FAST_NTT"); P->fast_ntt = !(fe && fe[0] == '0'); }
+  { const char* xe = getenv("SBN_NTT_XCD"); P->ntt_xcd = xe && xe[0] == '1'; }
+  if (const char* se = getenv("SBN_NTT_SUB")) { const long v = atol(se); if (v >= 8 && v <= 256 && v % 8 == 0) P->ntt_sub = (size_t)v; }
   acc(ntt_fast_setup());
   hipc(hipStreamCreate(&P->stream), "hipStreamCreate");
   hipc(hipStreamCreate(&P->hstream), "hipStreamCreate");
