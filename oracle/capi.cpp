@@ -42,6 +42,16 @@ void orc_poseidon_permute(uint64_t* st) {
   poseidon_permute(s);
   for (int i = 0; i < 12; i++) st[i] = s[i].v;
 }
+// eight permutations at once (poseidon_x8.hpp); states: [8][12]; returns 0, or -1 when the CPU lacks AVX-512F/DQ
+int orc_poseidon_permute_x8(uint64_t* states) {
+#if defined(__x86_64__)
+  if (!px8::available()) return -1;
+  px8::permute8((uint64_t(*)[12])states);
+  return 0;
+#else
+  (void)states; return -1;
+#endif
+}
 void orc_hash_no_pad(const uint64_t* in, size_t n, uint64_t* out) {
   std::vector<GF> v(n); for (size_t i = 0; i < n; i++) v[i] = GF(in[i]);
   Digest d = hash_or_noop(v.data(), n);

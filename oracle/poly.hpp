@@ -7,6 +7,7 @@
 // schedule yields the same bits; a plain iterative radix-2 is used.
 #pragma once
 #include "poseidon.hpp"
+#include "poseidon_x8.hpp"
 #include <algorithm>
 #include <chrono>
 #include <string>
@@ -119,13 +120,38 @@ struct MerkleTree {
     levels.clear();
     levels.emplace_back(n);
     auto& d0 = levels[0];
+    // eight leaves / eight parents per AVX-512 permutation when the CPU has it (poseidon_x8.hpp: the plain round form, lane-wise;
+    // the same digests as the scalar path, tests/test_oracle_core.py), the scalar sparse form otherwise
+    const size_t width = n ? leaves[0].size() : 0;
+    bool uniform = px8::available() && n >= 8 && width > 4;
+    for (size_t i = 0; uniform && i < n; i++) uniform = leaves[i].size() == width;
+#if defined(__x86_64__)
+    if (uniform) {
 #pragma omp parallel for schedule(static)
-    for (size_t i = 0; i < n; i++) d0[i] = hash_or_noop(leaves[i].data(), leaves[i].size());
+      for (size_t i0 = 0; i0 < n; i0 += 8) {
+        const GF* rows[8];
+        for (int j = 0; j < 8; j++) rows[j] = leaves[i0 + j].data();
+        px8::hash_rows8(rows, width, &d0[i0]);
+      }
+    } else
+#endif
+    {
+#pragma omp parallel for schedule(static)
+      for (size_t i = 0; i < n; i++) d0[i] = hash_or_noop(leaves[i].data(), leaves[i].size());
+    }
     for (unsigned l = lg; l > cap_h; l--) {
       const auto& prev = levels.back();
       std::vector<Digest> next(prev.size() / 2);
+#if defined(__x86_64__)
+      if (px8::available() && next.size() >= 8) {
 #pragma omp parallel for schedule(static)
-      for (size_t i = 0; i < next.size(); i++) next[i] = two_to_one(prev[2 * i], prev[2 * i + 1]);
+        for (size_t i0 = 0; i0 < next.size(); i0 += 8) px8::two_to_one8(&prev[2 * i0], &prev[2 * i0 + 1], 2, &next[i0]);
+      } else
+#endif
+      {
+#pragma omp parallel for schedule(static)
+        for (size_t i = 0; i < next.size(); i++) next[i] = two_to_one(prev[2 * i], prev[2 * i + 1]);
+      }
       levels.push_back(std::move(next));
     }
   }

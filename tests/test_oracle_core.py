@@ -131,3 +131,30 @@ def test_g1_scalar_mult_against_python(O, golden):
     row = 512 * k + 511
     bx = sum(int(trace[32 + i, row]) << (16 * i) for i in range(16))
     assert bx == int(case["outputs"][k][0], 16)
+
+
+def test_avx512_eight_lane_permutation_equals_the_definition(O):
+    """oracle/poseidon_x8.hpp (eight permutations per AVX-512 register, the leaf hashing of the CPU baseline) == the plain
+    definition on edge values and random states; the Merkle caps of a commitment are the same with it and without it
+    (ORC_NO_AVX512=1 in a child process).  Skipped on CPUs without AVX-512F/DQ, where the scalar path is the only one."""
+    import os
+    import subprocess
+    import sys
+    P = O.GL_P
+    rng = np.random.default_rng(77)
+    st = rng.integers(0, P, size=(8, 12), dtype=np.uint64)
+    st[0] = P - 1
+    st[1] = 0
+    st[2, :6] = [P - 1, 0, 1, 0xFFFFFFFF, 0xFFFFFFFF00000000, 1 << 63]
+    a = st.copy()
+    if O.lib().orc_poseidon_permute_x8(O.ptr(a)) != 0:
+        pytest.skip("no AVX-512F/DQ on this CPU")
+    for j in range(8):
+        assert [int(x) for x in a[j]] == O.poseidon_permute([int(x) for x in st[j]]), j
+    cols = rng.integers(0, P, size=(21, 1024), dtype=np.uint64)        # 21 columns: a ragged last sponge block
+    cap, _, _ = O.commit_values(cols)
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); import oracle_lib as O; "
+            "rng = np.random.default_rng(77); rng.integers(0, O.GL_P, size=(8, 12), dtype=np.uint64); "
+            "cols = rng.integers(0, O.GL_P, size=(21, 1024), dtype=np.uint64); print(O.commit_values(cols)[0].tolist())") % os.path.dirname(os.path.abspath(__file__))
+    out = subprocess.check_output([sys.executable, "-c", code], env=dict(os.environ, ORC_NO_AVX512="1"))
+    assert eval(out.decode().strip().splitlines()[-1]) == cap.tolist()
