@@ -263,7 +263,8 @@ int sbn_local_comm_create(uint32_t world, const int* devices, uint64_t send_byte
 void sbn_local_comm_abort(sbn_local_group* g);
 void sbn_local_comm_destroy(sbn_local_group* g);
 /* A pattern exchange through `comm` (uneven blocks, self blocks, an all-gather, the host all-gather), checked on the
- * device: every rank calls it; 0 = the transport moved every byte where it belongs. */
+ * device: every rank calls it (with the device of its staging buffers current); 0 = the transport moved every byte where it
+ * belongs. */
 int sbn_comm_selftest(const sbn_comm* comm);
 
 /* Proof object ---------------------------------------------------------------------------------- */

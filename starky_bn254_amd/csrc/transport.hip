@@ -206,18 +206,16 @@ struct sbn_local_group {
 namespace {
 using RankCtx = sbn_local_group::RankCtx;
 
-int local_all_to_all(void* vctx, void* vstream, const uint64_t* so, const uint64_t* sl, const uint64_t* ro, const uint64_t* rl) {
-  RankCtx* rc = (RankCtx*)vctx;
+int local_all_to_all_body(RankCtx* rc, hipStream_t st, const uint64_t* so, const uint64_t* sl, const uint64_t* ro, const uint64_t* rl) {
   sbn_local_group* g = rc->g;
   const uint32_t me = rc->rank, R = g->world;
-  hipStream_t st = (hipStream_t)vstream;
   THIP(hipSetDevice(g->dev[me]));
   g->so[me].assign(so, so + R); g->sl[me].assign(sl, sl + R);
   THIP(hipEventRecord(g->ready[me], st));                     // everything that packed my send blocks precedes this
   if (!g->barrier()) return tfail(SBN_ERR_HIP, "local transport: a rank failed or never arrived");
   for (uint32_t s = 0; s < R; s++) {
     if (!rl[s]) continue;
-    if (g->sl[s][me] != rl[s]) { sbn_local_comm_abort(g); return tfail(SBN_ERR_HIP, "local transport: rank %u sends %llu bytes to rank %u, which expects %llu", s, (unsigned long long)g->sl[s][me], me, (unsigned long long)rl[s]); }
+    if (g->sl[s][me] != rl[s]) return tfail(SBN_ERR_HIP, "local transport: rank %u sends %llu bytes to rank %u, which expects %llu", s, (unsigned long long)g->sl[s][me], me, (unsigned long long)rl[s]);
     if (s != me) THIP(hipStreamWaitEvent(st, g->ready[s], 0));
     const char* src = (const char*)g->send[s] + g->so[s][me];
     char* dst = (char*)g->recv[me] + ro[s];
@@ -229,6 +227,12 @@ int local_all_to_all(void* vctx, void* vstream, const uint64_t* so, const uint64
   // my send blocks may be overwritten by later work on `st` only after every receiver has pulled them
   for (uint32_t d = 0; d < R; d++) if (d != me && sl[d]) THIP(hipStreamWaitEvent(st, g->done[d], 0));
   return 0;
+}
+int local_all_to_all(void* vctx, void* vstream, const uint64_t* so, const uint64_t* sl, const uint64_t* ro, const uint64_t* rl) {
+  RankCtx* rc = (RankCtx*)vctx;
+  const int r = local_all_to_all_body(rc, (hipStream_t)vstream, so, sl, ro, rl);
+  if (r) sbn_local_comm_abort(rc->g);   // whatever went wrong on this rank: the others must not wait for it at the next barrier
+  return r;
 }
 int local_all_gather_host(void* vctx, const void* send, void* recv, uint64_t bytes) {
   RankCtx* rc = (RankCtx*)vctx;
