@@ -38,10 +38,11 @@ struct NttPassParams {
   // the 512-point kernel's footprint and reads the (cache-resident) input twice.
   const u64* pre2;
   u32 split;
-  // fast pass only.  xcd_order = 1: the grid is (columns, tiles) instead of (tiles, columns), so that the workgroups of one
-  // column have equal blockIdx.x % 8 when the column count is a multiple of 8 -- one XCD under the observed round-robin
-  // placement -- in EVERY pass of a column chunk: an experiment in keeping the tmp round trips between passes inside one
-  // XCD's L2 (SBN_NTT_XCD=1 with SBN_NTT_SUB=<columns per sub-chunk>; DESIGN.md section 7 has the measurement).
+  // fast pass only.  xcd_order = 1 (default; SBN_NTT_XCD=0 turns it off): the grid is (columns, tiles) instead of (tiles,
+  // columns): consecutive workgroups -- which the dispatcher deals round-robin over the 8 XCDs -- then work on the SAME tile
+  // of different columns, i.e. read the same twiddle / coset-scale table entries while each XCD keeps a fixed set of columns
+  // (blockIdx.x % 8 when the column count is a multiple of 8).  Measured: 1 % off the proof, five A/B pairs of
+  // five; what it does NOT do is keep a pass's output in L2 for the next launch (SBN_NTT_SUB experiment, same section).
   u32 xcd_order;
 };
 

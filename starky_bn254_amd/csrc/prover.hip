@@ -122,7 +122,7 @@ struct sbn_prover {
   float stage_ms[ST_COUNT + EX_COUNT];
   size_t ntt_chunk;
   size_t ntt_sub = 0;                        // SBN_NTT_SUB: transform the columns of a chunk in sub-chunks of this many (0: whole chunk)
-  bool ntt_xcd = false;                      // SBN_NTT_XCD=1: (columns, tiles) grid order in the fast passes
+  bool ntt_xcd = true;                       // (columns, tiles) grid order in the fast passes; SBN_NTT_XCD=0: (tiles, columns)
   bool fast_ntt = true;                      // SBN_FAST_NTT=0 selects the generic radix-2 pass everywhere
   hipStream_t hstream = nullptr;             // sponge absorption / Merkle stream
   hipEvent_t chunk_ready[MAX_CHUNKS];        // main -> hash: LDE chunk k is complete
@@ -537,7 +537,7 @@ static int create_ctx(const sbn_air_desc* air, const sbn_config* cfg, uint32_t d
     P->ntt_chunk = (size_t)v;
   }
   { const char* fe = getenv("SBN_FAST_NTT"); P->fast_ntt = !(fe && fe[0] == '0'); }
-  { const char* xe = getenv("SBN_NTT_XCD"); P->ntt_xcd = xe && xe[0] == '1'; }
+  { const char* xe = getenv("SBN_NTT_XCD"); P->ntt_xcd = !(xe && xe[0] == '0'); }
   if (const char* se = getenv("SBN_NTT_SUB")) { const long v = atol(se); if (v >= 8 && v <= 256 && v % 8 == 0) P->ntt_sub = (size_t)v; }
   acc(ntt_fast_setup());
   hipc(hipStreamCreate(&P->stream), "hipStreamCreate");
@@ -1113,10 +1113,17 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
   {
     const size_t zn = S ? S->zr : Z;                       // Z columns computed here (the split: this rank's range)
     const PairCols* pairs = S ? S->d_pairs_own : P->d_pairs;
-    if (zn == 0) {}
-    else if (n % 2048 == 0) hipLaunchKernelGGL(permutation_z_kernel<8>, dim3((unsigned)zn), dim3(256), 0, st, P->d_trace, n, pairs, gamma0.v, gamma1.v, P->d_zval);
-    else if (n % 1024 == 0) hipLaunchKernelGGL(permutation_z_kernel<4>, dim3((unsigned)zn), dim3(256), 0, st, P->d_trace, n, pairs, gamma0.v, gamma1.v, P->d_zval);
-    else hipLaunchKernelGGL(permutation_z_kernel<2>, dim3((unsigned)zn), dim3(256), 0, st, P->d_trace, n, pairs, gamma0.v, gamma1.v, P->d_zval);   // n = 512
+    auto launch_z = [&](size_t z0, size_t cnt, hipStream_t s) {
+      if (cnt == 0) return;
+      const PairCols* pp = pairs + z0; u64* out = P->d_zval + z0 * n;
+      if (n % 2048 == 0) hipLaunchKernelGGL(permutation_z_kernel<8>, dim3((unsigned)cnt), dim3(256), 0, s, P->d_trace, n, pp, gamma0.v, gamma1.v, out);
+      else if (n % 1024 == 0) hipLaunchKernelGGL(permutation_z_kernel<4>, dim3((unsigned)cnt), dim3(256), 0, s, P->d_trace, n, pp, gamma0.v, gamma1.v, out);
+      else hipLaunchKernelGGL(permutation_z_kernel<2>, dim3((unsigned)cnt), dim3(256), 0, s, P->d_trace, n, pp, gamma0.v, gamma1.v, out);   // n = 512
+    };
+    // MEASURED and dropped (profiles/r3_ab_z_overlap.txt): only the first column chunk in front of the commit pipeline and the
+    // other Z columns on a third stream beside that chunk's transforms and sponge -- the stage in front shrinks by 0.2 ms (a
+    // single workgroup's scan chain is 0.36 ms long), the Z commitment grows by 0.44 ms (26.25 -> 26.5 ms per proof, five pairs).
+    launch_z(0, zn, st);
   }
   HIPC(hipGetLastError());
   HIPC(hipEventRecord(P->ev[ST_Z_COMMIT], st));
@@ -1542,6 +1549,7 @@ extern "C" int sbn_commit_values(const uint64_t* cols, size_t ncols, size_t n, u
   HIPC(hipSetDevice(g_device));
   { int rc0 = ntt_fast_setup(); if (rc0) return rc0; }
   { const char* fe = getenv("SBN_FAST_NTT"); P.fast_ntt = !(fe && fe[0] == '0'); }
+  { const char* xe = getenv("SBN_NTT_XCD"); P.ntt_xcd = !(xe && xe[0] == '0'); }
   HIPC(hipStreamCreate(&P.stream));
   u64 *d_vals = nullptr, *d_coef = nullptr, *d_lde = nullptr;
   int rc = 0;
