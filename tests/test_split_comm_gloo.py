@@ -130,3 +130,19 @@ def test_split_column_ownership_model():
             edges = [(k * R * ob, min(total, (k + 1) * R * ob)) for k in range(steps)]
             assert edges[0][0] == 0 and edges[-1][1] == total and all(a[1] == b[0] for a, b in zip(edges, edges[1:]))
             assert all((e[1] - e[0]) % 8 == 0 for e in edges[:-1])   # the sponge permutes after every 8 columns
+
+
+def test_python_side_share_and_cpu_helpers():
+    """split.own_columns / exchange_bytes_sent (what bench.py reports as bytes on the wire) restate prover.hip ColShare;
+    sharding.effective_cpus() never exceeds the visible CPUs and honours the affinity mask."""
+    sys.path.insert(0, ROOT)
+    from starky_bn254_amd import sharding, split
+    for total in (1676, 762, 11786, 5328, 63, 64, 65):
+        for world in (1, 2, 4, 8, 16):
+            own = [split.own_columns(total, world, r) for r in range(world)]
+            assert sum(own) == total and max(own) - min(own) <= 64
+            assert own == sorted(own, reverse=True)             # rank 0 never owns fewer columns than a later rank
+    n = sharding.effective_cpus()
+    assert 1 <= n <= (os.cpu_count() or 1)
+    if hasattr(os, "sched_getaffinity"):
+        assert n <= len(os.sched_getaffinity(0))
