@@ -56,8 +56,33 @@ def lib():
         L.orc_permuted_cols.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.orc_eval_constraints.argtypes = [C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                            C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]
+        if "OMP_NUM_THREADS" not in os.environ:
+            # a GPU box shows every hardware thread of the host (256) but grants the container a share (cgroup cpu.max: 16 CPUs);
+            # OpenMP's default of one thread per visible CPU makes the oracle 3-4 x SLOWER there (profiles/r3_oracle_scaling*.jsonl)
+            L.orc_set_threads(_effective_cpus())
         _lib = L
     return _lib
+
+
+def _effective_cpus():
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = max(1, min(n, -(-int(q) // int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and period > 0:
+                n = max(1, min(n, -(-q // period)))
+        except (OSError, ValueError):
+            pass
+    return n
 
 
 def ptr(a):
