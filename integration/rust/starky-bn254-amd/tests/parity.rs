@@ -11,6 +11,16 @@
 //! `prove` (src/curves/g1/exp.rs:811-826), converts the proof to the library's canonical words
 //! (`convert::words_from_proof`) and compares every stage with the committed digests of the `times_x` variant, in prove()
 //! order, naming the FIRST stage that differs -- DESIGN.md section 4 maps each recalled protocol choice to that stage.
+//!
+//! The cheapest first contact is the kit's `mystark_lookup_fixed.json`: `MyStark` on `[6, 3, 1, 1, 0, 0, 0, 0]` / `0..7` is the one
+//! workload whose inputs the reference itself fixes (src/utils/lookup.rs:154-161) -- no input plumbing at all.  `MyStark` is
+//! private to lookup.rs's test module, so add, at the end of `test_mystark` (lookup.rs:228), after `verify_stark_proof(...)`:
+//!
+//!     let words = starky_bn254_amd::convert::words_from_proof::<F, C, D>(&proof, 3, &config).unwrap();
+//!     println!("{:x?}", &words[12..76]);      // the trace cap: kit stages.times_x.trace_cap
+//!     println!("{:x?}", &words[words.len() - 17..words.len() - 1]);   // final polynomial (8 ext coefficients) and, last, pow_witness
+//!
+//! and compare with the kit (8 rows: no FRI layer, a 1,093-word proof; `stages.times_x` vs `stages.plain` decides the x X question).
 //! `RAYON_NUM_THREADS=1` makes plonky2's proof-of-work search (`find_any`) return the smallest witness, which is what the
 //! kit holds; with more threads `pow_witness`, `pow_response`, `query_indices` and `query_rounds` may differ legitimately.
 use ark_bn254::{Fq, G1Affine};
