@@ -84,36 +84,39 @@ __device__ __forceinline__ u64 mad(u32 a, u32 b, u64 c, u64& k) { u64 r; asm("v_
 __device__ __forceinline__ u64 mad0(u32 a, u32 b) { u64 r, k; asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(r), "=s"(k) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ u64 madm1(u32 a, u64 c, u64& k) { u64 r; asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(r), "=s"(k) : "v"(a), "v"(c)); return r; }   // a * (2^32 - 1) + c
 __device__ __forceinline__ u64 cmp_lt_s(u64 x, u64 c) { u64 k; asm("v_cmp_lt_u64_e64 %0, %1, %2" : "=s"(k) : "v"(x), "s"(c)); return k; }   // lanes with x < c (c uniform)
+__device__ __forceinline__ u32 sel(u32 a, u32 b, u64 k) { u32 r; asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(k)); return r; }   // k ? b : a
+// weak -> canonical: w - p = w + (2^32 - 1) - 2^64, so the add carries out exactly when w >= p.  Four instructions with the
+// select mask in an SGPR pair; `x >= p ? x - p : x` compiles to a compare plus a back-to-back v_cndmask_b32_e32 pair on VCC,
+// which profiles/r2_valu_rates.txt prices at ~10 ns each at low occupancy.
+__device__ __forceinline__ u64 canon(u64 w) {
+  u64 k1, k2; u32 cl, ch;
+  asm("v_add_co_u32_e64 %0, %1, %2, -1" : "=v"(cl), "=s"(k1) : "v"(lo32(w)));
+  ch = addc(hi32(w), 0u, k1, k2);
+  return pack(sel(lo32(w), cl, k2), sel(hi32(w), ch, k2));
+}
 }  // namespace gp
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(SBN_NO_ASM_MUL)
-// gfx950 canonical multiply from the primitives above: the 128-bit product as four chained v_mad_u64_u32 (+ one 33-bit
-// column add), reduction lo - hi_hi + hi_lo (2^32 - 1) with borrow / carry repaid through SGPR-pair carries, then one
-// conditional subtraction of p (r >= p <=> r + 2^32 - 1 wraps).  ~21 VALU instructions where the compiler needs ~33, and
-// -- unlike the hand-scheduled stream of round 1 (gl_mul_asm.inc, fixed window v112..v127, still used by the Poseidon
-// S-boxes) -- no fixed registers: kernels that only multiply through F::operator* are no longer pinned at 128 VGPRs.
-__device__ __forceinline__ u64 gl_mul_dev(u64 a, u64 b) {
+// gfx950 multiply from the primitives above, 13 instructions for the weak product (round 3; the derivation is in
+// tools/gen_poseidon_sbox_asm.py): four chained v_mad_u64_u32 -- the third takes the whole second product as its addend, and
+// its carry-out (weight 2^96 = -1) enters the reduction as the borrow-IN of lo - hi_hi; that subtraction's borrow (2^64 = 2^32 - 1
+// too much) comes off the multiplier of the reducing multiply-add, hi_lo - b, whose own borrow b2 (only when hi_lo = 0; 2^32 (2^32 - 1)
+// = -1) and carry c are repaid by one add-with-carry pair.  Then one conditional subtraction of p.  The compiler needs ~33
+// instructions; unlike the hand-scheduled stream of the Poseidon S-boxes there are no fixed registers.
+__device__ __forceinline__ u64 gl_mul_weak(u64 a, u64 b) {
   using namespace gp;
   const u32 a0 = lo32(a), a1 = hi32(a), b0 = lo32(b), b1 = hi32(b);
-  u64 k, kc, k1, k2, k3, k4, k5, k6, k7, k8;
+  u64 k, km, k1, k2, k3, k4, k5, k6;
   const u64 p0 = mad0(a0, b0);
   const u64 p1 = mad(a0, b1, (u64)hi32(p0), k);
-  const u64 p2 = mad(a1, b0, (u64)lo32(p1), k);
-  const u32 sl = addco(hi32(p1), hi32(p2), kc);
-  const u64 p3 = mad(a1, b1, pack(sl, sel01(kc)), k);
-  // (p3 : lo) mod p
-  const u32 l = subco(lo32(p0), hi32(p3), k1), h = subb0(lo32(p2), k1, k2);
-  const u32 l2 = subco(l, selm1(k2), k3), h2 = subb0(h, k3, k4);       // borrow: take off 2^32 - 1 more; cannot borrow again
-  const u64 r = madm1(lo32(p3), pack(l2, h2), k5);
-  const u64 r2 = madm1(sel01(k5), r, k6);                              // carry: add 2^32 - 1; cannot carry again
-  // canonical: r2 - p = r2 + (2^32 - 1) - 2^64
-  u32 cl, ch;
-  asm("v_add_co_u32_e64 %0, %1, %2, -1" : "=v"(cl), "=s"(k7) : "v"(lo32(r2)));
-  asm("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(ch), "=s"(k8) : "v"(hi32(r2)), "s"(k7));
-  u32 ol, oh;
-  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(ol) : "v"(lo32(r2)), "v"(cl), "s"(k8));
-  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(oh) : "v"(hi32(r2)), "v"(ch), "s"(k8));
-  return pack(ol, oh);
+  const u64 p2 = mad(a1, b0, p1, km);
+  const u64 p3 = mad(a1, b1, (u64)hi32(p2), k);
+  const u32 l = subb(lo32(p0), hi32(p3), km, k1), h = subb0(lo32(p2), k1, k2);
+  const u32 t = subb0(lo32(p3), k2, k3);
+  const u64 r = madm1(t, pack(l, h), k4);
+  const u32 rl = addc(lo32(r), selm1(k4), k3, k5), rh = addc(hi32(r), 0u, k5, k6);
+  return pack(rl, rh);
 }
+__device__ __forceinline__ u64 gl_mul_dev(u64 a, u64 b) { return gp::canon(gl_mul_weak(a, b)); }
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SBN_NO_ASM_MUL)
 GL_HD F operator*(F a, F b) { return F(gl_mul_dev(a.v, b.v)); }
 #else
 GL_HD F operator*(F a, F b) { return F(gl_reduce128(a.v * b.v, gl_mulhi(a.v, b.v))); }

@@ -123,7 +123,7 @@ namespace nw {
 // v_mad_u64_u32 x, -1 (x + c (2^32 - 1)) instead of the 64-bit compare + two selects the compiler emits for
 // `if (s < a) s += EPS`.  The compiler still allocates every register, schedules, and pads the SGPR write -> read wait states
 // itself (it sees each primitive's operands), so there is no fixed register window.  A 16-point DFT drops from 942 VALU
-// instructions (+213 s_nop) to 656, a general multiply from 33 to 21.  Set SBN_NTT_CXX_ARITH at compile time for the plain
+// instructions (+213 s_nop) to 656, a general multiply from 33 to 21 (round 3: 13, gl_mul_weak).  Set SBN_NTT_CXX_ARITH at compile time for the plain
 // C++ forms (A/B measurements).
 #if !defined(SBN_NTT_CXX_ARITH)
 using namespace gp;   // single-instruction primitives (gl.cuh)
@@ -142,12 +142,14 @@ __device__ __forceinline__ u64 sub(u64 a, u64 b) {   // a - b - borrow * (2^32 -
 }
 // (hi : lo) mod p for hi < 2^32:  lo + hi * (2^32 - 1)
 __device__ __forceinline__ u64 red32(u64 lo, u32 hi) { u64 k; u64 t = madm1(hi, lo, k); u64 k2; return madm1(sel01(k), t, k2); }
-// (hi : lo) mod p, weak:  lo - hi_hi + hi_lo * (2^32 - 1)
+// (hi : lo) mod p, weak:  lo - hi_hi + hi_lo * (2^32 - 1); the borrow comes off the multiplier (gl_mul_weak, gl.cuh)
 __device__ __forceinline__ u64 red(u64 lo, u64 hi) {
-  u64 k1, k2, k3, k4;
-  u32 l = subco(lo32(lo), hi32(hi), k1); u32 h = subb0(hi32(lo), k1, k2);
-  u32 l2 = subco(l, selm1(k2), k3); u32 h2 = subb0(h, k3, k4);          // borrow: 2^64 = 2^32 - 1 more to take off; cannot borrow again
-  return red32(pack(l2, h2), lo32(hi));
+  u64 k1, k2, k3, k4, k5, k6;
+  const u32 l = subco(lo32(lo), hi32(hi), k1), h = subb0(hi32(lo), k1, k2);
+  const u32 t = subb0(lo32(hi), k2, k3);
+  const u64 r = madm1(t, pack(l, h), k4);
+  const u32 rl = addc(lo32(r), selm1(k4), k3, k5), rh = addc(hi32(r), 0u, k5, k6);
+  return pack(rl, rh);
 }
 template <int E> __device__ __forceinline__ u64 mul_pow2(u64 x) {  // x * 2^E, 0 <= E < 96
   if constexpr (E == 0) return x;
@@ -156,17 +158,8 @@ template <int E> __device__ __forceinline__ u64 mul_pow2(u64 x) {  // x * 2^E, 0
   else if constexpr (E < 64) return red(pack(0, lo32(x) << (E - 32)), x >> (64 - E));
   else return mul_pow2<E - 48>(mul_pow2<48>(x));
 }
-__device__ __forceinline__ u64 mul(u64 a, u64 b) {
-  const u32 a0 = lo32(a), a1 = hi32(a), b0 = lo32(b), b1 = hi32(b);
-  u64 k;
-  const u64 p0 = mad0(a0, b0);
-  const u64 p1 = mad(a0, b1, (u64)hi32(p0), k);
-  const u64 p2 = mad(a1, b0, (u64)lo32(p1), k);
-  u64 kc; const u32 sl = addco(hi32(p1), hi32(p2), kc);
-  const u64 p3 = mad(a1, b1, pack(sl, sel01(kc)), k);
-  return red(pack(lo32(p0), lo32(p2)), p3);
-}
-__device__ __forceinline__ u64 canon(u64 x) { return x >= GLP ? x - GLP : x; }
+__device__ __forceinline__ u64 mul(u64 a, u64 b) { return gl_mul_weak(a, b); }
+__device__ __forceinline__ u64 canon(u64 x) { return gp::canon(x); }
 #else
 __device__ __forceinline__ u64 add(u64 a, u64 b) {
   u64 s = a + b;
@@ -300,6 +293,100 @@ __global__ __launch_bounds__(256) void ntt_fast_pass_kernel(NttPassParams p, u32
     }
   }
   (void)R;
+}
+
+// -------------------------------------------------------------------------------------------------------------
+// K1'' the second pass of the inverse transform FUSED with the first pass of the coset LDE (n = 2^16, 2^17 rows).
+// With n = n1 * n2 (n2 = 256) the inverse transform's pass B leaves a lane with the sixteen coefficients
+// k = k1 + 16 k2 (k2 = 0..15) of tile column tg, i.e. coefficient indices k * n1 + tg -- and the LDE's first pass (512-point
+// over rows r of which only r < 256 are non-zero, stride n1 between rows) wants exactly r = g + 16 q of tile column tg in
+// one lane: the same lane with g = k1, q = k2.  So the coefficients are stored (they are needed by the openings and FRI)
+// and go on, in registers, through the coset scale, the trivial radix-2 stage and the two DFT-16 rounds of the LDE pass.
+// Saves one launch and one read of the coefficients per column chunk, no arithmetic.  The second LDS exchange also
+// TRANSPOSES the lane order (g fastest -> t fastest), so the final stores are 128-byte runs like the unfused pass's.
+// -------------------------------------------------------------------------------------------------------------
+struct NttFusedParams {
+  const u64* in; size_t in_col_stride;      // pass-A output of the inverse transform: element (r, tg) at r + tg * 256
+  u64* coef; size_t coef_col_stride;        // coefficients, natural order: (k, tg) at k * n1 + tg
+  u64* out; size_t out_col_stride;          // pass-A output of the LDE: (k, tg) at k * n1 + tg, k < 512
+  size_t n1;                                // 2^ceil(log n / 2) = tile columns of both passes
+  u32 log_n;                                // 16 or 17
+  const u64* tw_i; const u64* tw_f; u32 tw_log;   // inverse / forward root tables of the LDE size
+  const u64* pre;                           // coset scale 7^i
+  u64 scale;                                // 1 / n
+};
+__global__ __launch_bounds__(256) void ntt_fused_inv_b_lde_a_kernel(NttFusedParams p) {
+  extern __shared__ u64 lds[];
+  const size_t col = blockIdx.x;                       // (columns, tiles) grid order, as the other passes
+  const size_t t0 = (size_t)blockIdx.y << 4;
+  const u64* in = p.in + col * p.in_col_stride;
+  u64* coef = p.coef + col * p.coef_col_stride;
+  u64* out = p.out + col * p.out_col_stride;
+  const u32 g = threadIdx.x & 15, t = threadIdx.x >> 4;   // part 1: lanes over g first (the input rows are contiguous)
+  const size_t tg = t0 + t;
+  u64 x[2][16];
+  // ---- part 1: pass B of the inverse transform (256-point, omega^-1: index permutation 11)
+#pragma unroll
+  for (u32 q = 0; q < 16; q++) x[0][q] = in[(size_t)(g + 16 * q) + tg * 256];
+  nw::dft16_rho(x[0]);
+#pragma unroll
+  for (u32 pidx = 0; pidx < 16; pidx++) {
+    const u32 m = __brev(pidx) >> 28, k1 = (11u * m) & 15;
+    u64 v = x[0][pidx];
+    if (g && k1) v = nw::mul(v, tw_lookup(p.tw_i, p.tw_log, (u64)g * k1, 8).v);
+    lds[k1 * 257 + t * 16 + g] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (u32 gp = 0; gp < 16; gp++) x[0][gp] = lds[g * 257 + t * 16 + gp];   // this lane now owns k1 = g
+  nw::dft16_rho(x[0]);
+  // coefficient k = g + 16 k2, k2 = 11 * brev4(pidx): store it, and keep it as row r = g + 16 q (q = k2) of the LDE pass
+  u64 a[16];
+#pragma unroll
+  for (u32 pidx = 0; pidx < 16; pidx++) {
+    const u32 m = __brev(pidx) >> 28, k2 = (11u * m) & 15;
+    const u32 k = g + 16 * k2;
+    const u64 v = nw::mul(x[0][pidx], p.scale);
+    coef[(size_t)k * p.n1 + tg] = nw::canon(v);
+    a[k2] = v;
+  }
+  __syncthreads();                                    // every lane has read its part-1 values: the LDS is free again
+  // ---- part 2: pass A of the coset LDE (512-point, rows 256.. zero, omega: index permutation 5)
+#pragma unroll
+  for (u32 q = 0; q < 16; q++) {
+    const u32 r = g + 16 * q;
+    const u64 v = nw::mul(a[q], p.pre[(size_t)r * p.n1 + tg]);
+    x[0][q] = v;
+    x[1][q] = nw::mul(v, tw_lookup(p.tw_f, p.tw_log, r, 9).v);     // (u, v) = (a, a w_512^r): the upper half is zero
+  }
+#pragma unroll
+  for (u32 b = 0; b < 2; b++) {
+    nw::dft16_rho(x[b]);
+#pragma unroll
+    for (u32 pidx = 0; pidx < 16; pidx++) {
+      const u32 m = __brev(pidx) >> 28, k1 = (5u * m) & 15;
+      u64 v = x[b][pidx];
+      if (g && k1) v = nw::mul(v, tw_lookup(p.tw_f, p.tw_log, (u64)g * k1, 8).v);
+      lds[(b * 16 + k1) * 272 + g * 17 + t] = v;       // [k1][g][t], g rows padded to 17: both sides (nearly) conflict-free
+    }
+  }
+  __syncthreads();
+  // round 2 with the lanes re-dealt t fastest: lane (k1, t2) -- the stores below are 16 consecutive words per row
+  const u32 t2 = threadIdx.x & 15, k1o = threadIdx.x >> 4;
+  const size_t tg2 = t0 + t2;
+#pragma unroll
+  for (u32 b = 0; b < 2; b++) {
+#pragma unroll
+    for (u32 gp = 0; gp < 16; gp++) x[b][gp] = lds[(b * 16 + k1o) * 272 + gp * 17 + t2];
+    nw::dft16_rho(x[b]);
+#pragma unroll
+    for (u32 pidx = 0; pidx < 16; pidx++) {
+      const u32 m = __brev(pidx) >> 28, k2 = (5u * m) & 15;
+      const u32 k = (k1o + 16 * k2) * 2 + b;           // DIF: block b holds the outputs 2 k256 + b
+      const u64 v = nw::mul(x[b][pidx], tw_lookup(p.tw_f, p.tw_log, (u64)k * tg2, p.log_n + 1).v);
+      out[(size_t)k * p.n1 + tg2] = nw::canon(v);
+    }
+  }
 }
 
 // table[i] = base^i (i < n); one thread per entry (square-and-multiply), used once per prover.

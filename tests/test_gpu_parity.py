@@ -35,6 +35,35 @@ def test_poseidon_permutation_batch(gpu, O, golden):
     assert e.value.code == -2
 
 
+def test_poseidon_reduction_edge_cases(gpu, O):
+    """The 13-instruction multiply of the S-box streams (tools/gen_poseidon_sbox_asm.py) has three rare paths: the
+    cross-term carry (weight 2^96 = -1, taken as a borrow-in), the borrow of the 2^96 term, and the borrow of
+    lo(P3) - b (only when lo(P3) = 0).  States are built so that the FIRST round's S-box inputs x = state + rc hit them:
+    x = k 2^48 squares to k^2 2^96 (lo(P0) = lo(P2) = lo(P3) = 0 with hi(P3) > 0: all three borrows), x near 2^32, 2^64
+    and p exercise the carries.  Every row is compared with the oracle's plain-definition permutation."""
+    rc = O.round_constants()[:12]
+    xs = [k << 48 for k in (1, 2, 3, 255, 256, 257, 4095, 32768, 65535)]
+    xs += [(k << 48) + d for k in (1, 65535) for d in (1, 0xFFFFFFFF, 1 << 32)]
+    xs += [0, 1, 0xFFFFFFFF, 1 << 32, (1 << 32) + 1, P - 1, P - 2, P - (1 << 32), 0xFFFFFFFF00000000 - 1, 0xFFFFFFFE00000001,
+           0x00000001FFFFFFFF, 0x8000000000000000, 0x7FFFFFFFFFFFFFFF, 0xFFFF0000FFFF0000 % P, 0x0000FFFF0000FFFF]
+    rng = np.random.default_rng(77)
+    rows = []
+    for x in xs:                                      # the special value in every position, random elsewhere
+        for pos in range(12):
+            r = [int(v) for v in rng.integers(0, P, size=12, dtype=np.uint64)]
+            r[pos] = (x - rc[pos]) % P
+            rows.append(r)
+    for x in xs:                                      # and in all twelve positions at once (three interleaved streams)
+        rows.append([(x - rc[i]) % P for i in range(12)])
+    st = np.array(rows, dtype=np.uint64)
+    out = gpu.poseidon_permute_batch(st)
+    for r in range(len(rows)):
+        assert [int(v) for v in out[r]] == O.poseidon_permute(rows[r]), f"row {r}"
+    big = rng.integers(0, P, size=(1 << 16, 12), dtype=np.uint64)      # a broad random sweep against the host definition
+    dev = gpu.poseidon_permute_batch(big)
+    assert np.array_equal(dev, gpu.poseidon_permute_host(big, use_definition=True))
+
+
 @pytest.mark.parametrize("ncols,n", [(1, 512), (3, 512), (4, 1024), (5, 512), (8, 2048), (9, 4096), (20, 1024), (17, 65536), (130, 16384), (3, 262144), (66, 262144)])
 def test_commit_matches_oracle(gpu, O, ncols, n):
     """PolynomialBatch::from_values: iNTT, coset LDE (shift 7, blow-up 2), Poseidon leaves, Merkle cap.
