@@ -54,6 +54,12 @@ GL_HD F tw_lookup(const u64* tw, u32 tw_log, u64 e_of_order, u32 order_log) {
   return F(tw[idx]);
 }
 
+// The same root from a FULL table (w^i, i < 2^tw_log): two 32-bit index instructions and the load, where the half table costs
+// a 64-bit compare, a negation and two selects (~17 VALU instructions per root, two roots per element and pass).
+__device__ __forceinline__ u64 tw_full(const u64* __restrict__ tw, u32 tw_log, u32 e_of_order, u32 order_log) {
+  return tw[(e_of_order << (tw_log - order_log)) & ((1u << tw_log) - 1u)];
+}
+
 static constexpr int NTT_THREADS = 256;
 
 __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassParams p) {
@@ -251,7 +257,7 @@ __global__ __launch_bounds__(256) void ntt_fast_pass_kernel(NttPassParams p, u32
     for (u32 q = 0; q < 16; q++) {
       u32 r = g + 16 * q;
       u64 a = x[0][q], bb = x[NB - 1][q];
-      u64 w = tw_lookup(p.tw, p.tw_log, r, 9).v;
+      u64 w = tw_full(p.tw, p.tw_log, r, 9);
       if (upper_zero) { x[NB - 1][q] = nw::mul(a, w); }
       else { x[0][q] = nw::add(a, bb); x[NB - 1][q] = nw::mul(nw::sub(a, bb), w); }
     }
@@ -265,7 +271,7 @@ __global__ __launch_bounds__(256) void ntt_fast_pass_kernel(NttPassParams p, u32
       u32 m = __brev(pidx) >> 28;             // index under rho
       u32 k1 = (kperm * m) & 15;              // index under omega_16 (or its inverse)
       u64 v = x[b][pidx];
-      if (g && k1) v = nw::mul(v, tw_lookup(p.tw, p.tw_log, (u64)g * k1, 8).v);
+      if (g && k1) v = nw::mul(v, tw_full(p.tw, p.tw_log, (u32)(g * k1), 8));
       lds[(b * 16 + k1) * S1 + lane_off + g * g_mul] = v;
     }
   }
@@ -285,7 +291,7 @@ __global__ __launch_bounds__(256) void ntt_fast_pass_kernel(NttPassParams p, u32
       u32 k = LOG_B == 0 ? k256 : (k256 * NB + b);   // DIF: block b holds outputs k = 2 k256 + b
       if (LOG_B == 1) k = (k << p.split) + half;      // split: this 512-point pass yields the outputs 2 k + half of the 1,024-point one
       u64 v = x[b][pidx];
-      if (p.twiddle) v = nw::mul(v, tw_lookup(p.tw, p.tw_log, (u64)k * tg, p.log_n).v);
+      if (p.twiddle) v = nw::mul(v, tw_full(p.tw, p.tw_log, (u32)(k * tg), p.log_n));
       if (p.scale != 1) v = nw::mul(v, p.scale);
       size_t go = (size_t)k * p.out_sr + tg * p.out_st;
       if (p.post) v = nw::mul(v, p.post[go]);
@@ -333,7 +339,7 @@ __global__ __launch_bounds__(256) void ntt_fused_inv_b_lde_a_kernel(NttFusedPara
   for (u32 pidx = 0; pidx < 16; pidx++) {
     const u32 m = __brev(pidx) >> 28, k1 = (11u * m) & 15;
     u64 v = x[0][pidx];
-    if (g && k1) v = nw::mul(v, tw_lookup(p.tw_i, p.tw_log, (u64)g * k1, 8).v);
+    if (g && k1) v = nw::mul(v, tw_full(p.tw_i, p.tw_log, (u32)(g * k1), 8));
     lds[k1 * 257 + t * 16 + g] = v;
   }
   __syncthreads();
@@ -357,7 +363,7 @@ __global__ __launch_bounds__(256) void ntt_fused_inv_b_lde_a_kernel(NttFusedPara
     const u32 r = g + 16 * q;
     const u64 v = nw::mul(a[q], p.pre[(size_t)r * p.n1 + tg]);
     x[0][q] = v;
-    x[1][q] = nw::mul(v, tw_lookup(p.tw_f, p.tw_log, r, 9).v);     // (u, v) = (a, a w_512^r): the upper half is zero
+    x[1][q] = nw::mul(v, tw_full(p.tw_f, p.tw_log, r, 9));     // (u, v) = (a, a w_512^r): the upper half is zero
   }
 #pragma unroll
   for (u32 b = 0; b < 2; b++) {
@@ -366,7 +372,7 @@ __global__ __launch_bounds__(256) void ntt_fused_inv_b_lde_a_kernel(NttFusedPara
     for (u32 pidx = 0; pidx < 16; pidx++) {
       const u32 m = __brev(pidx) >> 28, k1 = (5u * m) & 15;
       u64 v = x[b][pidx];
-      if (g && k1) v = nw::mul(v, tw_lookup(p.tw_f, p.tw_log, (u64)g * k1, 8).v);
+      if (g && k1) v = nw::mul(v, tw_full(p.tw_f, p.tw_log, (u32)(g * k1), 8));
       lds[(b * 16 + k1) * 272 + g * 17 + t] = v;       // [k1][g][t], g rows padded to 17: both sides (nearly) conflict-free
     }
   }
@@ -383,7 +389,7 @@ __global__ __launch_bounds__(256) void ntt_fused_inv_b_lde_a_kernel(NttFusedPara
     for (u32 pidx = 0; pidx < 16; pidx++) {
       const u32 m = __brev(pidx) >> 28, k2 = (5u * m) & 15;
       const u32 k = (k1o + 16 * k2) * 2 + b;           // DIF: block b holds the outputs 2 k256 + b
-      const u64 v = nw::mul(x[b][pidx], tw_lookup(p.tw_f, p.tw_log, (u64)k * tg2, p.log_n + 1).v);
+      const u64 v = nw::mul(x[b][pidx], tw_full(p.tw_f, p.tw_log, (u32)(k * tg2), p.log_n + 1));
       out[(size_t)k * p.n1 + tg2] = nw::canon(v);
     }
   }

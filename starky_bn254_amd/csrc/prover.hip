@@ -596,7 +596,7 @@ static int create_ctx(const sbn_air_desc* air, const sbn_config* cfg, uint32_t d
   acc(dmalloc(&P->d_tmp, std::max(P->ntt_chunk, (size_t)4) * m));
   acc(dmalloc(&P->d_q, 2 * m)); acc(dmalloc(&P->d_qlde, 4 * m));
   acc(tree_alloc(P->tree_q, m, cfg->cap_height));
-  acc(dmalloc(&P->d_tw_f, m / 2)); acc(dmalloc(&P->d_tw_i, m / 2)); acc(dmalloc(&P->d_shift, m)); acc(dmalloc(&P->d_shift_inv, m));
+  acc(dmalloc(&P->d_tw_f, m)); acc(dmalloc(&P->d_tw_i, m)); acc(dmalloc(&P->d_shift, m)); acc(dmalloc(&P->d_shift_inv, m));
   { const char* se = getenv("SBN_NTT_SPLIT1024"); if (P->lde_log == 19 && !(se && se[0] == '0')) acc(dmalloc(&P->d_shift_odd, n)); }   // =0: generic first pass (A/B)
   acc(dmalloc(&P->d_xs, m)); acc(dmalloc(&P->d_lag_first, m)); acc(dmalloc(&P->d_lag_last, m));
   P->apow_n = apow_len(as.nconstraints, as.nzs);
@@ -634,8 +634,10 @@ static int create_ctx(const sbn_air_desc* air, const sbn_config* cfg, uint32_t d
   // tables
   auto blocks = [](size_t k) { return dim3((unsigned)((k + 255) / 256)); };
   F w = f_root_of_unity(P->lde_log);
-  hipLaunchKernelGGL(pow_table_kernel, blocks(m / 2), dim3(256), 0, P->stream, P->d_tw_f, m / 2, w.v);
-  hipLaunchKernelGGL(pow_table_kernel, blocks(m / 2), dim3(256), 0, P->stream, P->d_tw_i, m / 2, f_inv(w).v);
+  // FULL root tables (w^i for every i < m: the second half is the negated first): the register passes index them without the
+  // compare / negate of a half table (tw_full, kernels.cuh); everything else reads the first half only
+  hipLaunchKernelGGL(pow_table_kernel, blocks(m), dim3(256), 0, P->stream, P->d_tw_f, m, w.v);
+  hipLaunchKernelGGL(pow_table_kernel, blocks(m), dim3(256), 0, P->stream, P->d_tw_i, m, f_inv(w).v);
   hipLaunchKernelGGL(pow_table_kernel, blocks(m), dim3(256), 0, P->stream, P->d_shift, m, (u64)GL_GEN);
   hipLaunchKernelGGL(pow_table_kernel, blocks(m), dim3(256), 0, P->stream, P->d_shift_inv, m, f_inv(F(GL_GEN)).v);
   hipLaunchKernelGGL(domain_tables_kernel, blocks(m), dim3(256), 0, P->stream, P->d_xs, P->d_lag_first, P->d_lag_last, m, P->lde_log, degree_bits);
@@ -1554,13 +1556,13 @@ extern "C" int sbn_commit_values(const uint64_t* cols, size_t ncols, size_t n, u
   u64 *d_vals = nullptr, *d_coef = nullptr, *d_lde = nullptr;
   int rc = 0;
   rc |= dmalloc(&d_vals, ncols * n); rc |= dmalloc(&d_coef, ncols * n); rc |= dmalloc(&d_lde, ncols * P.m); rc |= dmalloc(&P.d_tmp, 64 * P.m);
-  rc |= dmalloc(&P.d_tw_f, P.m / 2); rc |= dmalloc(&P.d_tw_i, P.m / 2); rc |= dmalloc(&P.d_shift, P.m);
+  rc |= dmalloc(&P.d_tw_f, P.m); rc |= dmalloc(&P.d_tw_i, P.m); rc |= dmalloc(&P.d_shift, P.m);
   rc |= tree_alloc(P.tree_t, P.m, cap_height);
   if (!rc) {
     auto blocks = [](size_t k) { return dim3((unsigned)((k + 255) / 256)); };
     F w = f_root_of_unity(P.lde_log);
-    hipLaunchKernelGGL(pow_table_kernel, blocks(P.m / 2), dim3(256), 0, P.stream, P.d_tw_f, P.m / 2, w.v);
-    hipLaunchKernelGGL(pow_table_kernel, blocks(P.m / 2), dim3(256), 0, P.stream, P.d_tw_i, P.m / 2, f_inv(w).v);
+    hipLaunchKernelGGL(pow_table_kernel, blocks(P.m), dim3(256), 0, P.stream, P.d_tw_f, P.m, w.v);
+    hipLaunchKernelGGL(pow_table_kernel, blocks(P.m), dim3(256), 0, P.stream, P.d_tw_i, P.m, f_inv(w).v);
     hipLaunchKernelGGL(pow_table_kernel, blocks(P.m), dim3(256), 0, P.stream, P.d_shift, P.m, (u64)GL_GEN);
     if (hipMemcpy(d_vals, cols, ncols * n * sizeof(u64), hipMemcpyHostToDevice) != hipSuccess) rc = fail(SBN_ERR_HIP, "H2D failed");
   }

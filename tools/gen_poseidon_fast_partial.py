@@ -144,6 +144,20 @@ with open(out, "w") as f:
         f.write("  " + ", ".join("0x%016xULL" % x for x in eff[12 * r:12 * r + 12]) + ",\n")
 print("wrote", os.path.normpath(out))
 
+# (1b) the constants the device adds INSIDE the full MDS layers (poseidon.cuh mdsc): row j of the table belongs to the layer
+# of full round j (j < 4: rounds 0..3, then rounds 26..29) and holds the NEXT round's constants split into zero-extended
+# 32-bit halves, [row][lo | hi][12]; the layer of round 3 leaves element 0 to the partial-round loop, the last layer adds 0.
+rows = [eff[12 * 1:12 * 2], eff[12 * 2:12 * 3], eff[12 * 3:12 * 4], [0] + eff[12 * 4 + 1:12 * 5],
+        eff[12 * 27:12 * 28], eff[12 * 28:12 * 29], eff[12 * 29:12 * 30], [0] * 12]
+out = os.path.join(csrc, "poseidon_kx_consts.inc")
+with open(out, "w") as f:
+    f.write("// Generated by tools/gen_poseidon_fast_partial.py -- do not edit.\n")
+    f.write("// [8 layers][lo halves | hi halves][12] of the next round's constants, zero-extended to 64 bits.\n")
+    for row in rows:
+        f.write("  " + ", ".join("0x%08xULL" % (x & 0xFFFFFFFF) for x in row) + ",\n")
+        f.write("  " + ", ".join("0x%08xULL" % (x >> 32) for x in row) + ",\n")
+print("wrote", os.path.normpath(out))
+
 # (2) sparse partial-round matrices (host transcript)
 out = os.path.join(csrc, "poseidon_fast_consts.inc")
 with open(out, "w") as f:
