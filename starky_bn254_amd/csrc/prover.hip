@@ -124,6 +124,8 @@ struct sbn_prover {
   size_t ntt_sub = 0;                        // SBN_NTT_SUB: transform the columns of a chunk in sub-chunks of this many (0: whole chunk)
   bool ntt_xcd = true;                       // (columns, tiles) grid order in the fast passes; SBN_NTT_XCD=0: (tiles, columns)
   bool fast_ntt = true;                      // SBN_FAST_NTT=0 selects the generic radix-2 pass everywhere
+  bool ntt_fused = false;                    // the inverse transform's pass B and the LDE's pass A as ONE kernel (2^16 / 2^17 rows)
+  u64* d_tmp2 = nullptr;                     // its output: the fused kernel cannot work in place
   hipStream_t hstream = nullptr;             // sponge absorption / Merkle stream
   hipEvent_t chunk_ready[MAX_CHUNKS];        // main -> hash: LDE chunk k is complete
   hipEvent_t abs_ev[2 * MAX_CHUNKS];         // hash stream: before/after each absorb launch
@@ -148,8 +150,8 @@ static u32 pick_log_t(u32 log_r, u32 log_s) {
 }
 // One full n-point transform per column (two passes through `tmp`).
 static int ntt_columns(sbn_prover* P, const u64* in, size_t in_cs, u64* out, size_t out_cs, u64* tmp, size_t tmp_cs, size_t ncols,
-                       u32 log_n, bool inverse, size_t n_in, const u64* pre, const u64* post, u64 scale, hipStream_t st = nullptr) {
-  if (ncols == 0) return 0;
+                       u32 log_n, bool inverse, size_t n_in, const u64* pre, const u64* post, u64 scale, hipStream_t st = nullptr, int which = 3) {
+  if (ncols == 0) return 0;                 // which: bit 0 = pass A (in -> tmp), bit 1 = pass B (tmp -> out)
   if (!st) st = P->stream;
   u32 log_n1 = (log_n + 1) / 2, log_n2 = log_n - log_n1;
   size_t n1 = (size_t)1 << log_n1, n2 = (size_t)1 << log_n2;
@@ -188,8 +190,8 @@ static int ntt_columns(sbn_prover* P, const u64* in, size_t in_cs, u64* out, siz
     if (split_a) { pa.log_r = 9; pa.log_t = 4; pa.split = 1; pa.pre2 = P->d_shift_odd; }
     ga = dim3((unsigned)(n2 >> pa.log_t), (unsigned)nc, split_a ? 2u : 1u); gb = dim3((unsigned)(n1 >> pb.log_t), (unsigned)nc);
     la = ((size_t)1 << pa.log_r) * ((1u << pa.log_t) + 1) * 8; lb = ((size_t)1 << pb.log_r) * ((1u << pb.log_t) + 1) * 8;
-    launch(pa, ga, la);
-    launch(pb, gb, lb);
+    if (which & 1) launch(pa, ga, la);
+    if (which & 2) launch(pb, gb, lb);
   }
   HIPC(hipGetLastError());
   return 0;
@@ -202,7 +204,11 @@ static constexpr int SBN_MAX_DEVICES = 64;
 static int ntt_fast_setup() {  // idempotent, so a race between prover threads is harmless; the flag only saves the call
   static std::atomic<bool> done[SBN_MAX_DEVICES];
   const int d = g_device >= 0 && g_device < SBN_MAX_DEVICES ? g_device : 0;
-  if (!done[d].load()) { HIPC(hipFuncSetAttribute((const void*)ntt_fast_pass_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 32 * 272 * 8)); done[d].store(true); }
+  if (!done[d].load()) {
+    HIPC(hipFuncSetAttribute((const void*)ntt_fast_pass_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 32 * 272 * 8));
+    HIPC(hipFuncSetAttribute((const void*)ntt_fused_inv_b_lde_a_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 32 * 272 * 8));
+    done[d].store(true);
+  }
   return 0;
 }
 
@@ -239,6 +245,20 @@ static int intt_then_lde(sbn_prover* P, const u64* vals, u64* coef, u64* lde, si
 }
 
 static int intt_then_lde_chunk(sbn_prover* P, const u64* vals, u64* coef, u64* lde, size_t c0, size_t nc) {
+  if (P->ntt_fused && P->d_tmp2 && !P->ntt_sub) {
+    // three launches instead of four: inverse pass A -> d_tmp, [inverse pass B + LDE pass A] -> coefficients and d_tmp2
+    // (kernels.cuh ntt_fused_inv_b_lde_a_kernel), LDE pass B -> lde
+    int rc = ntt_columns(P, vals + c0 * P->n, P->n, coef + c0 * P->n, P->n, P->d_tmp, P->m, nc, P->degree_bits, true, P->n, nullptr, nullptr,
+                         host_inv_pow2(P->degree_bits), nullptr, 1);
+    if (rc) return rc;
+    NttFusedParams f{};
+    const u32 log_n1 = (P->degree_bits + 1) / 2;
+    f.in = P->d_tmp; f.in_col_stride = P->m; f.coef = coef + c0 * P->n; f.coef_col_stride = P->n; f.out = P->d_tmp2; f.out_col_stride = P->m;
+    f.n1 = (size_t)1 << log_n1; f.log_n = P->degree_bits; f.tw_i = P->d_tw_i; f.tw_f = P->d_tw_f; f.tw_log = P->lde_log; f.pre = P->d_shift;
+    f.scale = host_inv_pow2(P->degree_bits);
+    hipLaunchKernelGGL(ntt_fused_inv_b_lde_a_kernel, dim3((unsigned)nc, (unsigned)(f.n1 >> 4)), dim3(256), 32 * 272 * 8, P->stream, f);
+    return ntt_columns(P, coef + c0 * P->n, P->n, lde + c0 * P->m, P->m, P->d_tmp2, P->m, nc, P->lde_log, false, P->n, P->d_shift, nullptr, 1, nullptr, 2);
+  }
   const size_t sub = P->ntt_sub ? P->ntt_sub : nc;
   for (size_t s0 = 0; s0 < nc; s0 += sub) {   // (sub-chunks reuse the front of d_tmp: an experiment in L2 residency, SBN_NTT_SUB)
     const size_t a = c0 + s0, k = std::min(sub, nc - s0);
@@ -538,6 +558,7 @@ static int create_ctx(const sbn_air_desc* air, const sbn_config* cfg, uint32_t d
   }
   { const char* fe = getenv("SBN_FAST_NTT"); P->fast_ntt = !(fe && fe[0] == '0'); }
   { const char* xe = getenv("SBN_NTT_XCD"); P->ntt_xcd = !(xe && xe[0] == '0'); }
+  { const char* ue = getenv("SBN_NTT_FUSED"); P->ntt_fused = P->fast_ntt && (degree_bits == 16 || degree_bits == 17) && !(ue && ue[0] == '0'); }   // =0: four separate passes (A/B)
   if (const char* se = getenv("SBN_NTT_SUB")) { const long v = atol(se); if (v >= 8 && v <= 256 && v % 8 == 0) P->ntt_sub = (size_t)v; }
   acc(ntt_fast_setup());
   hipc(hipStreamCreate(&P->stream), "hipStreamCreate");
@@ -594,6 +615,7 @@ static int create_ctx(const sbn_air_desc* air, const sbn_config* cfg, uint32_t d
     acc(tree_alloc(P->tree_t, m, cfg->cap_height)); acc(tree_alloc(P->tree_z, m, cfg->cap_height));
   }
   acc(dmalloc(&P->d_tmp, std::max(P->ntt_chunk, (size_t)4) * m));
+  if (P->ntt_fused) acc(dmalloc(&P->d_tmp2, std::max(P->ntt_chunk, (size_t)4) * m));
   acc(dmalloc(&P->d_q, 2 * m)); acc(dmalloc(&P->d_qlde, 4 * m));
   acc(tree_alloc(P->tree_q, m, cfg->cap_height));
   acc(dmalloc(&P->d_tw_f, m)); acc(dmalloc(&P->d_tw_i, m)); acc(dmalloc(&P->d_shift, m)); acc(dmalloc(&P->d_shift_inv, m));
@@ -673,7 +695,7 @@ static int create_ctx(const sbn_air_desc* air, const sbn_config* cfg, uint32_t d
 extern "C" void sbn_prover_destroy(sbn_prover* P) {
   if (!P) return;
   (void)hipSetDevice(P->device);
-  u64* bufs[] = {P->d_trace, P->d_coef, P->d_lde, P->d_tmp, P->d_zval, P->d_zcoef, P->d_zlde, P->d_q, P->d_qlde, P->tree_t.d, P->tree_z.d,
+  u64* bufs[] = {P->d_trace, P->d_coef, P->d_lde, P->d_tmp, P->d_tmp2, P->d_zval, P->d_zcoef, P->d_zlde, P->d_q, P->d_qlde, P->tree_t.d, P->tree_z.d,
                  P->tree_q.d, P->d_tw_f, P->d_tw_i, P->d_shift, P->d_shift_inv, P->d_xs, P->d_lag_first, P->d_lag_last, P->d_apow, P->d_zpow,
                  P->d_open, P->d_part, P->d_w, P->d_fa, P->d_fcoef, P->d_fcoef2, P->d_pow, P->d_qbuf, P->d_shift_odd};
   for (u64* b : bufs) if (b) (void)hipFree(b);

@@ -3,15 +3,17 @@
 hand-scheduled streams, priced with the measured issue costs of tools/microbench/valu_rates.hip
 (profiles/r<N>_valu_rates.txt, wall-clock ns per wave-instruction per SIMD at W waves per SIMD).
 
-usage: poseidon_mix.py profiles/r2_valu_rates.txt [waves=2] > profiles/r2_sponge_issue_model.json
-The compiler-generated glue (constant additions, loads, loop control: ~6 % of the 14.7 k instructions the PMC counts) is
-priced as carry adds."""
+usage: poseidon_mix.py profiles/r2_valu_rates.txt [waves=2] [valu_per_permutation] > profiles/r<N>_sponge_issue_model.json
+The compiler-generated glue (the constant additions left outside the matrix layers, canonicalisation, loads, loop control)
+is priced as carry adds; its count is the VALU instructions per permutation the PMC run measured (third argument: SQ_INSTS_VALU
+of leaf_absorb_kernel / wave-permutations, default 12618 = the count from the kernel's disassembly, round 3) minus the VALU
+instructions of the streams."""
 import collections, json, os, re, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "starky_bn254_amd", "csrc")
 # how often each stream runs in one permutation (poseidon.cuh poseidon_permute_fast)
-RUNS = {"poseidon_sbox3_asm.inc": 8 * 4, "poseidon_mds_asm.inc": 8 * 2, "poseidon_fold3_asm.inc": 8 * 4 + 6 * 4 + 2 * 4,
+RUNS = {"poseidon_sbox3_asm.inc": 8 * 4, "poseidon_mdsc_a_asm.inc": 8 * 2, "poseidon_mdsc_b_asm.inc": 8 * 2, "poseidon_fold3_asm.inc": 8 * 4 + 6 * 4 + 2 * 4,
         "poseidon_sbox1_asm.inc": 6 * 3 + 2 * 2, "poseidon_mdsrow0_asm.inc": 6 + 2, "poseidon_mds2row0_asm.inc": 6, "poseidon_fold1_asm.inc": 6 * 2 + 2,
         "poseidon_mds3_asm.inc": 6 * 2, "poseidon_mds2_asm.inc": 2 * 2}
 # microbenchmark row that prices an opcode
@@ -44,7 +46,9 @@ def main():
             op = "s_load" if op.startswith("s_load") else op
             mix[op] += runs
     asm_total = sum(mix.values())
-    glue = max(0, 14734 - asm_total)          # PMC: 2.414e8 wave-instructions per 2^20 permutations / 16384 wave-permutations
+    valu_total = float(sys.argv[3]) if len(sys.argv) > 3 else 12618.0
+    asm_valu = sum(c for op, c in mix.items() if op.startswith("v_"))
+    glue = max(0, int(round(valu_total - asm_valu)))
     priced = 0.0
     rows = {}
     for op, cnt in sorted(mix.items(), key=lambda kv: -kv[1]):
