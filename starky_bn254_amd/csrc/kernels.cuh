@@ -321,7 +321,7 @@ struct NttFusedParams {
   const u64* pre;                           // coset scale 7^i
   u64 scale;                                // 1 / n
 };
-__global__ __launch_bounds__(256) void ntt_fused_inv_b_lde_a_kernel(NttFusedParams p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void ntt_fused_inv_b_lde_a_kernel(NttFusedParams p) {   // 128 VGPRs: two of its waves fit beside the sponge's two on a SIMD
   extern __shared__ u64 lds[];
   const size_t col = blockIdx.x;                       // (columns, tiles) grid order, as the other passes
   const size_t t0 = (size_t)blockIdx.y << 4;

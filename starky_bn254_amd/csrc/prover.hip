@@ -244,21 +244,27 @@ static int intt_then_lde(sbn_prover* P, const u64* vals, u64* coef, u64* lde, si
   return 0;
 }
 
-static int intt_then_lde_chunk(sbn_prover* P, const u64* vals, u64* coef, u64* lde, size_t c0, size_t nc) {
-  if (P->ntt_fused && P->d_tmp2 && !P->ntt_sub) {
+// values -> coefficients -> coset LDE of nc columns (column strides n, n, m): the unit of the commit pipelines
+static int intt_lde_cols(sbn_prover* P, const u64* v, u64* cf, u64* lde_out, size_t nc) {
+  if (P->ntt_fused && P->d_tmp2) {
     // three launches instead of four: inverse pass A -> d_tmp, [inverse pass B + LDE pass A] -> coefficients and d_tmp2
     // (kernels.cuh ntt_fused_inv_b_lde_a_kernel), LDE pass B -> lde
-    int rc = ntt_columns(P, vals + c0 * P->n, P->n, coef + c0 * P->n, P->n, P->d_tmp, P->m, nc, P->degree_bits, true, P->n, nullptr, nullptr,
-                         host_inv_pow2(P->degree_bits), nullptr, 1);
+    int rc = ntt_columns(P, v, P->n, cf, P->n, P->d_tmp, P->m, nc, P->degree_bits, true, P->n, nullptr, nullptr, host_inv_pow2(P->degree_bits), nullptr, 1);
     if (rc) return rc;
     NttFusedParams f{};
     const u32 log_n1 = (P->degree_bits + 1) / 2;
-    f.in = P->d_tmp; f.in_col_stride = P->m; f.coef = coef + c0 * P->n; f.coef_col_stride = P->n; f.out = P->d_tmp2; f.out_col_stride = P->m;
+    f.in = P->d_tmp; f.in_col_stride = P->m; f.coef = cf; f.coef_col_stride = P->n; f.out = P->d_tmp2; f.out_col_stride = P->m;
     f.n1 = (size_t)1 << log_n1; f.log_n = P->degree_bits; f.tw_i = P->d_tw_i; f.tw_f = P->d_tw_f; f.tw_log = P->lde_log; f.pre = P->d_shift;
     f.scale = host_inv_pow2(P->degree_bits);
     hipLaunchKernelGGL(ntt_fused_inv_b_lde_a_kernel, dim3((unsigned)nc, (unsigned)(f.n1 >> 4)), dim3(256), 32 * 272 * 8, P->stream, f);
-    return ntt_columns(P, coef + c0 * P->n, P->n, lde + c0 * P->m, P->m, P->d_tmp2, P->m, nc, P->lde_log, false, P->n, P->d_shift, nullptr, 1, nullptr, 2);
+    return ntt_columns(P, cf, P->n, lde_out, P->m, P->d_tmp2, P->m, nc, P->lde_log, false, P->n, P->d_shift, nullptr, 1, nullptr, 2);
   }
+  int rc = ntt_columns(P, v, P->n, cf, P->n, P->d_tmp, P->m, nc, P->degree_bits, true, P->n, nullptr, nullptr, host_inv_pow2(P->degree_bits));
+  if (rc) return rc;
+  return ntt_columns(P, cf, P->n, lde_out, P->m, P->d_tmp, P->m, nc, P->lde_log, false, P->n, P->d_shift, nullptr, 1);
+}
+static int intt_then_lde_chunk(sbn_prover* P, const u64* vals, u64* coef, u64* lde, size_t c0, size_t nc) {
+  if (!P->ntt_sub) return intt_lde_cols(P, vals + c0 * P->n, coef + c0 * P->n, lde + c0 * P->m, nc);
   const size_t sub = P->ntt_sub ? P->ntt_sub : nc;
   for (size_t s0 = 0; s0 < nc; s0 += sub) {   // (sub-chunks reuse the front of d_tmp: an experiment in L2 residency, SBN_NTT_SUB)
     const size_t a = c0 + s0, k = std::min(sub, nc - s0);
@@ -426,10 +432,8 @@ static int commit_split(sbn_prover* P, const ColShare& sh, const u64* vals, bool
     if (nc) {
       const u64* v = vals + (vals_global ? b : k) * ob * n;
       u64* cf = coef_own + k * ob * n;
-      int rc = ntt_columns(P, v, n, cf, n, P->d_tmp, m, nc, P->degree_bits, true, n, nullptr, nullptr, host_inv_pow2(P->degree_bits));
-      if (rc) return rc;
       u64* lde_out = R == 1 ? plane_l + b * ob * m : S->d_ldechunk;
-      rc = ntt_columns(P, cf, n, lde_out, m, P->d_tmp, m, nc, P->lde_log, false, n, P->d_shift, nullptr, 1);
+      int rc = intt_lde_cols(P, v, cf, lde_out, nc);
       if (rc) return rc;
       if (R > 1 && k >= 2) HIPC(hipStreamWaitEvent(P->stream, S->xchg_done[k - 2], 0));   // send slot k & 1 has left
       if (R > 1)
