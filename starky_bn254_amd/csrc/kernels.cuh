@@ -419,7 +419,7 @@ __global__ void scale_pow_kernel(u64* v, size_t n, u64 base) {
 // Digest stored at leaf index bitrev(row).  Algorithmic bytes: 8*M*C read + 32*M written.
 // This kernel is ALU-bound (ceil(C/8) permutations per row), not HBM-bound.
 // =================================================================================================
-__global__ __launch_bounds__(256) void leaf_hash_kernel(const u64* __restrict__ lde, size_t m, u32 lde_log, u32 ncols,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void leaf_hash_kernel(const u64* __restrict__ lde, size_t m, u32 lde_log, u32 ncols,
                                                         u64* __restrict__ digests) {
   size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= m) return;
@@ -431,17 +431,12 @@ __global__ __launch_bounds__(256) void leaf_hash_kernel(const u64* __restrict__ 
     for (u32 c = 0; c < 4; c++) digests[leaf * 4 + c] = c < ncols ? lde[(size_t)c * m + row] : 0;
     return;
   }
-  u32 c = 0;
-  for (; c + 8 <= ncols; c += 8) {
-#pragma unroll
-    for (int i = 0; i < 8; i++) s[i] = F(lde[(size_t)(c + i) * m + row]);
-    poseidon_permute(s);
-  }
-  if (c < ncols) {
+  // one call site (the permutation is inlined once); a block that is followed by a FULL block only hands its capacity on
+  for (u32 c = 0; c < ncols; c += 8) {
 #pragma unroll
     for (u32 i = 0; i < 8; i++)
       if (c + i < ncols) s[i] = F(lde[(size_t)(c + i) * m + row]);
-    poseidon_permute(s);
+    poseidon_permute_keep(s, c + 8 >= ncols ? P_KEEP_DIGEST : (c + 16 <= ncols ? P_KEEP_CAPACITY : P_KEEP_ALL));
   }
 #pragma unroll
   for (int i = 0; i < 4; i++) digests[leaf * 4 + i] = s[i].v;
@@ -456,7 +451,7 @@ __global__ __launch_bounds__(256) void merkle_level_kernel(const u64* __restrict
   for (int k = 0; k < 8; k++) s[k] = F(child[i * 8 + k]);
 #pragma unroll
   for (int k = 8; k < 12; k++) s[k] = F(0);
-  poseidon_permute(s);
+  poseidon_permute_keep(s, P_KEEP_DIGEST);
 #pragma unroll
   for (int k = 0; k < 4; k++) parent[i * 4 + k] = s[k].v;
 }
@@ -467,8 +462,8 @@ __global__ __launch_bounds__(256) void merkle_level_kernel(const u64* __restrict
 // overlaps the ALU-bound hashing of chunk k.  Sponge state: [12][m] words, column-major (coalesced).
 // ncols_chunk is a multiple of 8 except for the last chunk; `first` starts from the zero state, `last`
 // writes the digest to leaf bitrev(row).
-__global__ __launch_bounds__(256) void leaf_absorb_kernel(const u64* __restrict__ lde_chunk, size_t m, u32 lde_log, u32 ncols_chunk,
-                                                          u64* __restrict__ state, int first, int last, u64* __restrict__ digests) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void leaf_absorb_kernel(const u64* __restrict__ lde_chunk, size_t m, u32 lde_log, u32 ncols_chunk,
+                                                          u64* __restrict__ state, int first, int last, u64* __restrict__ digests, int next_full) {
   size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= m) return;
   F s[12];
@@ -479,25 +474,32 @@ __global__ __launch_bounds__(256) void leaf_absorb_kernel(const u64* __restrict_
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = F(state[(size_t)i * m + row]);
   }
-  u32 c = 0;
-  for (; c + 8 <= ncols_chunk; c += 8) {
-#pragma unroll
-    for (int i = 0; i < 8; i++) s[i] = F(lde_chunk[(size_t)(c + i) * m + row]);
-    poseidon_permute(s);
-  }
-  if (c < ncols_chunk) {
+  // Overwrite-mode sponge: a block of eight inputs replaces state[0..7], so a permutation that is followed by a FULL block only
+  // hands its capacity state[8..11] on, and the last one of the row only its digest: the last matrix layer then computes four rows
+  // instead of twelve (poseidon_permute_keep).  `next_full`: the next launch of this row starts with a full block (the host knows the
+  // next chunk's width); a ragged block (the last of the row) keeps state[len..7], so the permutation before it keeps everything.
+  // One call site: the permutation is inlined once.
+  for (u32 c = 0; c < ncols_chunk; c += 8) {
 #pragma unroll
     for (u32 i = 0; i < 8; i++)
       if (c + i < ncols_chunk) s[i] = F(lde_chunk[(size_t)(c + i) * m + row]);
-    poseidon_permute(s);
+    const bool end = c + 8 >= ncols_chunk;
+    const int keep = end ? (last ? P_KEEP_DIGEST : (next_full ? P_KEEP_CAPACITY : P_KEEP_ALL)) : (c + 16 <= ncols_chunk ? P_KEEP_CAPACITY : P_KEEP_ALL);
+    poseidon_permute_keep(s, keep);
   }
+  // the store addresses are recomputed from an opaque copy of the lane index instead of being kept live across the permutations
+  // (the kernel sits exactly at 128 VGPRs: two more live pairs would go to scratch)
+  u32 tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const size_t row2 = (size_t)blockIdx.x * blockDim.x + tid;
   if (last) {
-    size_t leaf = bitrev32((u32)row, lde_log);
+    size_t leaf = bitrev32((u32)row2, lde_log);
 #pragma unroll
     for (int i = 0; i < 4; i++) digests[leaf * 4 + i] = s[i].v;
   } else {
+    // (with next_full only the capacity is meaningful; the whole state is stored so that the buffer layout does not depend on it)
 #pragma unroll
-    for (int i = 0; i < 12; i++) state[(size_t)i * m + row] = s[i].v;
+    for (int i = 0; i < 12; i++) state[(size_t)i * m + row2] = s[i].v;
   }
 }
 
@@ -529,7 +531,7 @@ __global__ __launch_bounds__(MERKLE_SUBTREE_THREADS) void merkle_subtree_kernel(
         for (int k = 0; k < 8; k++) s[k] = F(buf[tid * 8 + k]);
 #pragma unroll
         for (int k = 8; k < 12; k++) s[k] = F(0);
-        poseidon_permute(s);
+        poseidon_permute_keep(s, P_KEEP_DIGEST);
       }
       __syncthreads();
       if (tid < active) {
@@ -573,7 +575,7 @@ __global__ __launch_bounds__(256) void merkle_level_thread_kernel(u64* __restric
   for (int k = 0; k < 8; k++) s[k] = F(child[i * 8 + k]);
 #pragma unroll
   for (int k = 8; k < 12; k++) s[k] = F(0);
-  poseidon_permute(s);
+  poseidon_permute_keep(s, P_KEEP_DIGEST);
 #pragma unroll
   for (int k = 0; k < 4; k++) out[i * 4 + k] = s[k].v;
 }
@@ -605,7 +607,7 @@ __global__ __launch_bounds__(256) void fri_leaf_hash_kernel(const u64* __restric
       u32 nat = bitrev32((u32)(leaf * arity + t + u), log_m);
       s[2 * u] = F(va[nat]); s[2 * u + 1] = F(vb[nat]);
     }
-    poseidon_permute(s);
+    poseidon_permute_keep(s, t + 4 >= arity ? P_KEEP_DIGEST : P_KEEP_CAPACITY);
   }
 #pragma unroll
   for (int i = 0; i < 4; i++) digests[leaf * 4 + i] = s[i].v;

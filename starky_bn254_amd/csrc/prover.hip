@@ -42,7 +42,7 @@ static const char* STAGE_NAMES[ST_COUNT + EX_COUNT] = {
   "openings", "fri_combine", "fri_layers", "pow", "queries",
   "trace_absorb_kernels_ms", "trace_absorb_launches", "z_absorb_kernels_ms", "z_absorb_launches", "device_tracegen_ms",
   "split_exchange_ms"};
-static constexpr int MAX_CHUNKS = 256;
+static constexpr int MAX_CHUNKS = 512;
 
 struct DevTree {  // Merkle digests, levels concatenated (leaf level first)
   u64* d = nullptr; size_t nleaf = 0; u32 nlevels = 0;  // nlevels = number of levels BELOW the cap
@@ -339,7 +339,8 @@ static int commit_pipeline(sbn_prover* P, const u64* vals, u64* coef, u64* lde, 
     HIPC(hipStreamWaitEvent(P->hstream, P->chunk_ready[k], 0));
     HIPC(hipEventRecord(P->abs_ev[2 * k], P->hstream));
     hipLaunchKernelGGL(leaf_absorb_kernel, dim3((unsigned)((P->m + 255) / 256)), dim3(256), 0, P->hstream, lde + c0 * P->m, P->m, P->lde_log, (u32)nc,
-                       P->d_sponge, k == 0 ? 1 : 0, k + 1 == nchunks ? 1 : 0, t.d);
+                       P->d_sponge, k == 0 ? 1 : 0, k + 1 == nchunks ? 1 : 0, t.d,
+                       (k + 1 < nchunks && std::min(ch, ncols - (c0 + nc)) >= 8) ? 1 : 0);
     HIPC(hipEventRecord(P->abs_ev[2 * k + 1], P->hstream));
   }
   int rc = tree_build_inner(P, t, P->hstream);
@@ -468,7 +469,8 @@ static int commit_split(sbn_prover* P, const ColShare& sh, const u64* vals, bool
     for (size_t c0 = c_begin; c0 < c_end; c0 += ob) {
       const size_t ncs = std::min(ob, c_end - c0);
       hipLaunchKernelGGL(leaf_absorb_kernel, dim3((unsigned)((ml + 255) / 256)), dim3(256), 0, P->hstream, plane_l + c0 * ml, ml, row_log, (u32)ncs,
-                         P->d_sponge, c0 == 0 ? 1 : 0, c0 + ncs == sh.total ? 1 : 0, t.d);
+                         P->d_sponge, c0 == 0 ? 1 : 0, c0 + ncs == sh.total ? 1 : 0, t.d,
+                         (c0 + ncs < sh.total && sh.total - (c0 + ncs) >= 8) ? 1 : 0);
     }
     HIPC(hipGetLastError());
   }
@@ -554,7 +556,10 @@ static int create_ctx(const sbn_air_desc* air, const sbn_config* cfg, uint32_t d
   if (P->fri.total_arity() > degree_bits + cfg->rate_bits - cfg->cap_height) { sbn_prover_destroy(P); return fail(SBN_ERR_UNSUPPORTED, "FRI total reduction arity is too large"); }
   // Column chunk of the commit pipeline: a multiple of 8 (the sponge permutes after every 8 absorbed columns, so any other
   // chunk boundary would change the leaf digests), between 8 and 256.
-  P->ntt_chunk = 64;
+  // Default 64; 48 from 2^19 LDE rows up: a chunk's LDE (chunk * M * 8 bytes) is written by the transform stream and read by the
+  // sponge out of the 256 MiB Infinity Cache, and 64 columns of 2^19 rows are 268 MB (Fq12ExpStark(512): 0.708 -> 0.675 s,
+  // profiles/r3_v2_fq12_chunk.txt).
+  P->ntt_chunk = P->lde_log >= 19 ? 48 : 64;
   if (const char* ce = getenv("SBN_NTT_CHUNK")) {
     const long v = atol(ce);
     if (v < 8 || v > 256 || (v % 8) != 0) { sbn_prover_destroy(P); return fail(SBN_ERR_BAD_ARG, "SBN_NTT_CHUNK must be a multiple of 8 between 8 and 256"); }
@@ -582,6 +587,7 @@ static int create_ctx(const sbn_air_desc* air, const sbn_config* cfg, uint32_t d
     u32 lr = 0; while ((1u << lr) < R) lr++;
     uint64_t sb = 0, rb = 0; size_t sw = 0, slotw = 0;
     if (comm->struct_size != sizeof(sbn_comm)) { sbn_prover_destroy(P); return fail(SBN_ERR_BAD_ARG, "sbn_comm.struct_size does not match this library (ABI %d)", SBN_ABI_VERSION); }
+    if (!getenv("SBN_NTT_CHUNK")) P->ntt_chunk = SPLIT_BLOCK;   // (the size-dependent default above is the single-GPU pipeline's: a rank's rows are M / world)
     if (P->ntt_chunk != SPLIT_BLOCK) { sbn_prover_destroy(P); return fail(SBN_ERR_UNSUPPORTED, "the split prover deals columns in blocks of %zu: unset SBN_NTT_CHUNK", SPLIT_BLOCK); }
     split_sizes(as, degree_bits, cfg->rate_bits, R, SPLIT_BLOCK, &sb, &rb, &sw, &slotw);
     if ((1u << lr) != R || lr > cfg->cap_height || comm->rank >= R || !comm->all_to_all || !comm->all_gather_host || !comm->send_buf || !comm->recv_buf ||
@@ -1599,7 +1605,7 @@ extern "C" int sbn_commit_values(const uint64_t* cols, size_t ncols, size_t n, u
     for (size_t c0 = 0; !rc && c0 < ncols; c0 += 64) {
       size_t nc = std::min<size_t>(64, ncols - c0);
       hipLaunchKernelGGL(leaf_absorb_kernel, dim3((unsigned)((P.m + 255) / 256)), dim3(256), 0, P.stream, d_lde + c0 * P.m, P.m, P.lde_log, (u32)nc, P.d_sponge,
-                         c0 == 0 ? 1 : 0, c0 + 64 >= ncols ? 1 : 0, P.tree_t.d);
+                         c0 == 0 ? 1 : 0, c0 + 64 >= ncols ? 1 : 0, P.tree_t.d, (c0 + 64 < ncols && ncols - (c0 + 64) >= 8) ? 1 : 0);
     }
     if (!rc) rc = tree_build_inner(&P, P.tree_t, P.stream);
   }
