@@ -13,8 +13,10 @@ import collections, json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "starky_bn254_amd", "csrc")
 # how often each stream runs in one permutation (poseidon.cuh poseidon_permute_fast)
-RUNS = {"poseidon_sbox3_asm.inc": 8 * 4, "poseidon_mdsc_a_asm.inc": 8 * 2, "poseidon_mdsc_b_asm.inc": 8 * 2, "poseidon_fold3_asm.inc": 8 * 4 + 6 * 4 + 2 * 4,
-        "poseidon_sbox1_asm.inc": 6 * 3 + 2 * 2, "poseidon_mdsrow0_asm.inc": 6 + 2, "poseidon_mds2row0_asm.inc": 6, "poseidon_fold1_asm.inc": 6 * 2 + 2,
+# (the sponge's usual permutation: its last layer computes the four capacity rows only, poseidon_permute_keep)
+RUNS = {"poseidon_sbox3_asm.inc": 8 * 4, "poseidon_mdsc_a_asm.inc": 7 * 2, "poseidon_mdsc_b_asm.inc": 7 * 2, "poseidon_mdsq8_asm.inc": 2,
+        "poseidon_fold3_asm.inc": 7 * 4 + 1 + 6 * 4 + 2 * 4,
+        "poseidon_sbox1_asm.inc": 6 * 3 + 2 * 2, "poseidon_mdsrow0_asm.inc": 6 + 2, "poseidon_mds2row0_asm.inc": 6, "poseidon_fold1_asm.inc": 6 * 2 + 2 + 1,
         "poseidon_mds3_asm.inc": 6 * 2, "poseidon_mds2_asm.inc": 2 * 2}
 # microbenchmark row that prices an opcode
 ROW = {"v_mad_u64_u32": "v_mad_u64_u32 v,v (+vcc)", "v_addc_co_u32": "v_addc_co_u32 sgpr->sgpr' (VOP3)", "v_add_co_u32": "v_add_co_u32 ->sgpr (VOP3)",
