@@ -285,6 +285,10 @@ int sbn_commit_values(const uint64_t* cols, size_t ncols, size_t n, uint32_t rat
                       uint64_t* cap_out, uint64_t* coeffs_out, uint64_t* lde_out);
 /* Poseidon permutation of `count` independent width-12 states on the device (host in/out). */
 int sbn_poseidon_permute_batch(uint64_t* states, size_t count);
+/* out[i] = a[i] * b[i] in the Goldilocks field with the DEVICE multiply of every kernel (csrc/gl.cuh: 13-instruction weak product +
+ * canonicalisation; mode 0), or the weak product of the transform passes canonicalised afterwards (mode 1).  a, b: any 64-bit
+ * values (non-canonical representatives included: the kernels' intermediate values are); out canonical.  Host in/out. */
+int sbn_field_mul_batch(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t count, int mode);
 /* The host permutation behind the Fiat-Shamir transcript of prove()/verify() (plonky2 Challenger's
  * PoseidonPermutation): sparse partial rounds, or the plain definition when use_definition != 0.  Host only. */
 int sbn_poseidon_permute_host(uint64_t* states, size_t count, int use_definition);

@@ -7,5 +7,5 @@ symbol table can be checked), but every prove()/commit call fails loudly without
 from .api import (  # noqa: F401
     AIR_G1_OP, AIR_G1_EXP, AIR_G2_EXP, AIR_FQ12_EXP, AIR_FQ_EXP, AIR_FQ12_EXP_U64, AIR_MODULAR, AIR_FQ12_MUL, AIR_LOOKUP, AIR_FLAGS, AIR_FLAGS_U64, LookupStark, MyStark, FlagStark, FlagU64Stark, SbnError, StarkConfig, G1Stark, ModularStark, Fq12Stark, G1ExpStark, G2ExpStark, Fq12ExpStark,
     FqExpStark, Fq12ExpU64Stark, Prover, BatchProver, Proof,
-    prove, verify_stark_proof, commit_values, eval_constraints_host, poseidon_permute_batch, poseidon_permute_host, lib, lib_path, EXPORTS,
+    prove, verify_stark_proof, commit_values, eval_constraints_host, poseidon_permute_batch, poseidon_permute_host, field_mul_batch, lib, lib_path, EXPORTS,
 )

@@ -36,7 +36,7 @@ EXPORTS = [
     "sbn_prover_generate_trace", "sbn_prover_read_trace",
     "sbn_batch_prover_create", "sbn_batch_prover_prove_ios", "sbn_batch_prover_destroy",
     "sbn_prove", "sbn_proof_num_words", "sbn_proof_words", "sbn_proof_serialize", "sbn_proof_degree_bits",
-    "sbn_proof_free", "sbn_verify", "sbn_commit_values", "sbn_poseidon_permute_batch", "sbn_poseidon_permute_host",
+    "sbn_proof_free", "sbn_verify", "sbn_commit_values", "sbn_poseidon_permute_batch", "sbn_poseidon_permute_host", "sbn_field_mul_batch",
     "sbn_eval_constraints_host", "sbn_split_exchange_bytes", "sbn_split_prover_create", "sbn_split_prover_destroy", "sbn_split_prover_generate_trace",
     "sbn_split_prover_load_trace", "sbn_split_prover_prove", "sbn_split_prover_stage_times",
     "sbn_abi_version", "sbn_rccl_unique_id", "sbn_rccl_comm_create", "sbn_rccl_comm_destroy",
@@ -125,6 +125,7 @@ def lib():
         L.sbn_commit_values.argtypes = [vp, sz, sz, u32, u32, vp, vp, vp]
         L.sbn_poseidon_permute_batch.argtypes = [vp, sz]
         L.sbn_poseidon_permute_host.argtypes = [vp, sz, C.c_int]
+        L.sbn_field_mul_batch.argtypes = [vp, vp, vp, sz, C.c_int]
         L.sbn_set_device.argtypes = [C.c_int]
         _LIB = L
     return _LIB
@@ -573,6 +574,16 @@ def poseidon_permute_batch(states):
     s = np.ascontiguousarray(states, dtype=np.uint64).copy()
     _check(lib().sbn_poseidon_permute_batch(_ptr(s), s.shape[0]))
     return s
+
+
+def field_mul_batch(a, b, mode=0):
+    """a[i] * b[i] mod p with the device multiply (mode 0: the canonical operator* of every kernel; 1: the transforms' weak product),
+    on arbitrary 64-bit representatives; canonical results."""
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    b = np.ascontiguousarray(b, dtype=np.uint64)
+    out = np.zeros_like(a)
+    _check(lib().sbn_field_mul_batch(_ptr(a), _ptr(b), _ptr(out), a.shape[0], mode))
+    return out
 
 
 def eval_constraints_host(stark, local_row, next_row, public_inputs, alphas, z_last, l_first, l_last):

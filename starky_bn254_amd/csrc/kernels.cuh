@@ -632,6 +632,14 @@ __global__ __launch_bounds__(256) void fri_leaf_hash_coop_kernel(const u64* __re
   if (leaf < nleaf && lane < 4) digests[leaf * 4 + lane] = st;
 }
 
+// test hook: the device multiply on arbitrary 64-bit representatives (sbn_field_mul_batch)
+__global__ void field_mul_batch_kernel(const u64* a, const u64* b, u64* out, size_t count, int mode) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+#if defined(__HIP_DEVICE_COMPILE__)
+  out[i] = mode ? nw::canon(nw::canon(nw::mul(a[i], b[i]))) : (F(a[i]) * F(b[i])).v;
+#endif
+}
 __global__ void poseidon_batch_kernel(u64* states, size_t count) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;

@@ -1634,6 +1634,25 @@ extern "C" int sbn_poseidon_permute_batch(uint64_t* states, size_t count) {
   return SBN_OK;
 }
 
+extern "C" int sbn_field_mul_batch(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t count, int mode) {
+  if (!a || !b || !out) return fail(SBN_ERR_BAD_ARG, "null argument");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(SBN_ERR_NO_DEVICE, "no HIP device available: no CPU fallback");
+  HIPC(hipSetDevice(g_device));
+  if (count == 0) return SBN_OK;
+  u64* d = nullptr;
+  HIPC(hipMalloc((void**)&d, 3 * count * sizeof(u64)));
+  hipError_t e = hipMemcpy(d, a, count * sizeof(u64), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d + count, b, count * sizeof(u64), hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(field_mul_batch_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, 0, d, d + count, d + 2 * count, count, mode);
+    e = hipMemcpy(out, d + 2 * count, count * sizeof(u64), hipMemcpyDeviceToHost);
+  }
+  (void)hipFree(d);
+  if (e != hipSuccess) return fail(SBN_ERR_HIP, "sbn_field_mul_batch: %s", hipGetErrorString(e));
+  return SBN_OK;
+}
+
 // The transcript's host permutation (sparse partial rounds) or, with use_definition != 0, the plain round-by-round
 // form it must agree with.  No device involved: this is the Fiat-Shamir hasher of prove() / verify().
 extern "C" int sbn_poseidon_permute_host(uint64_t* states, size_t count, int use_definition) {

@@ -35,6 +35,25 @@ def test_poseidon_permutation_batch(gpu, O, golden):
     assert e.value.code == -2
 
 
+def test_device_field_multiply_edge_cases(gpu):
+    """The 13-instruction multiply from single-instruction primitives (csrc/gl.cuh gl_mul_weak: operator* of every kernel and the
+    transforms' twiddle multiply) on arbitrary 64-bit representatives, against Python integers: operands that make the cross-term
+    carry (2^96 = -1 as a borrow-in), the reduction's borrow and the borrow of lo(P3) - b (k 2^48 times j 2^48) fire, and a random sweep."""
+    sp = [0, 1, 2, 0xFFFFFFFF, 1 << 32, (1 << 32) + 1, 1 << 63, 2**64 - 1, P, P - 1, P + 1, 2**64 - 2**32, 0xFFFFFFFE00000001, 0x00000001FFFFFFFF]
+    sp += [k << 48 for k in (1, 3, 255, 256, 4095, 0x3B05, 0x1345, 65535)]
+    a = [x for x in sp for _ in sp]
+    b = [y for _ in sp for y in sp]
+    rng = np.random.default_rng(31)
+    ra = rng.integers(0, 2**64, size=1 << 16, dtype=np.uint64)
+    rb = rng.integers(0, 2**64, size=1 << 16, dtype=np.uint64)
+    rb[::3] &= np.uint64(0xFFFFFFFF00000000); ra[::5] &= np.uint64(0xFFFF000000000000)
+    a = np.concatenate([np.array(a, dtype=np.uint64), ra]); b = np.concatenate([np.array(b, dtype=np.uint64), rb])
+    want = [(int(x) * int(y)) % P for x, y in zip(a, b)]
+    for mode in (0, 1):
+        got = gpu.field_mul_batch(a, b, mode)
+        assert [int(v) for v in got] == want, mode
+
+
 def test_poseidon_reduction_edge_cases(gpu, O):
     """The 13-instruction multiply of the S-box streams (tools/gen_poseidon_sbox_asm.py) has three rare paths: the
     cross-term carry (weight 2^96 = -1, taken as a borrow-in), the borrow of the 2^96 term, and the borrow of
