@@ -275,9 +275,9 @@ def rooflines(args, stark, cfg, stage_ms, ms_per_proof, degree_bits=DEGREE_BITS)
     launches = max(stage_ms.get("trace_absorb_launches", 1.0), 1.0)
     # a launch absorbs cols_in_launch columns of the M-row LDE (8 M bytes each) and the last one writes
     # the M digests (32 M bytes); averaged over the launches of one proof.  The sponge state carried between the 64-column
-    # launches ([12][M] words out and in again) is an artefact of the chunking, not algorithmic traffic: reported apart.
+    # launches (its capacity, [4][M] words out and in again) is an artefact of the chunking, not algorithmic traffic: reported apart.
     alg_bytes = (8.0 * m * C + 32.0 * m) / launches
-    chunk_state_bytes = 2 * 96.0 * m * (launches - 1) / launches
+    chunk_state_bytes = 2 * 32.0 * m * (launches - 1) / launches     # the sponge capacity [4][M] out and in again (the rate part is overwritten)
     dom_ms = stage_ms.get("trace_absorb_kernels_ms", float("nan")) / launches
     achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms and dom_ms > 0 else None
     p_cols = 1 + 3 * (Zc // 2)                         # distinct trace columns read by the permutation argument

@@ -467,12 +467,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void l
   size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= m) return;
   F s[12];
-  if (first) {
 #pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = F(0);
-  } else {
+  for (int i = 0; i < 12; i++) s[i] = F(0);
+  if (!first) {
+    // a launch that starts with a full block needs the capacity only (its first block overwrites state[0..7], and the launch before
+    // stored nothing else: next_full); a launch of fewer than eight columns (the ragged end of the row) gets the whole state
 #pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = F(state[(size_t)i * m + row]);
+    for (int i = 8; i < 12; i++) s[i] = F(state[(size_t)i * m + row]);
+    if (ncols_chunk < 8) {
+#pragma unroll
+      for (int i = 0; i < 8; i++) s[i] = F(state[(size_t)i * m + row]);
+    }
   }
   // Overwrite-mode sponge: a block of eight inputs replaces state[0..7], so a permutation that is followed by a FULL block only
   // hands its capacity state[8..11] on, and the last one of the row only its digest: the last matrix layer then computes four rows
@@ -497,9 +502,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void l
 #pragma unroll
     for (int i = 0; i < 4; i++) digests[leaf * 4 + i] = s[i].v;
   } else {
-    // (with next_full only the capacity is meaningful; the whole state is stored so that the buffer layout does not depend on it)
+    // with next_full only the capacity is meaningful, and only the capacity is stored and loaded again: 8 + 8 words per row and
+    // launch less of carried state (the buffer layout [12][m] stays)
 #pragma unroll
-    for (int i = 0; i < 12; i++) state[(size_t)i * m + row2] = s[i].v;
+    for (int i = 8; i < 12; i++) state[(size_t)i * m + row2] = s[i].v;
+    if (!next_full) {
+#pragma unroll
+      for (int i = 0; i < 8; i++) state[(size_t)i * m + row2] = s[i].v;
+    }
   }
 }
 
