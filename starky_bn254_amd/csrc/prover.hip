@@ -287,9 +287,19 @@ static int tree_build_inner(sbn_prover* P, DevTree& t, hipStream_t st) {
   // One permutation costs 39 us on a lane and 16 us on 16 lanes, and a single wave saturates its SIMD.  So: levels with
   // >= 2^14 parents run one lane per parent over the whole GPU; narrower levels run 16 lanes per parent, 16 parents per
   // workgroup (one wave per SIMD), one launch per level; the last <= 16 parents finish inside one workgroup.
+  // Round 3: the narrow levels (<= 8192 parents) run FIVE levels per launch -- a workgroup owns 32 consecutive nodes and hashes its
+  // own 16 -> 8 -> 4 -> 2 -> 1 parents through LDS (merkle_subtree_kernel, 16 lanes per permutation), so a 2^17-leaf tree takes
+  // 3 + 2 launches instead of 3 + 10 and the dependent chain loses eight launch gaps (SBN_MERKLE_FUSE=0: one launch per level, A/B).
+  static const bool fuse = [] { const char* e = getenv("SBN_MERKLE_FUSE"); return !(e && e[0] == '0'); }();
   u32 l0 = 0;
   while (l0 < t.nlevels) {
     const size_t parents = t.nleaf >> (l0 + 1);
+    if (fuse && parents <= 8192 && parents >= 16 && ((t.nleaf >> l0) % 32) == 0) {
+      const u32 nlev = std::min<u32>(t.nlevels - l0, 5);
+      hipLaunchKernelGGL(merkle_subtree_kernel, dim3((unsigned)((t.nleaf >> l0) / 32)), dim3(MERKLE_SUBTREE_THREADS), 0, st, t.d, t.nleaf, l0, nlev, 32u);
+      l0 += nlev;
+      continue;
+    }
     if (parents >= 16384) {
       hipLaunchKernelGGL(merkle_level_thread_kernel, dim3((unsigned)((parents + 255) / 256)), dim3(256), 0, st, t.d, t.nleaf, l0);
       l0++;
