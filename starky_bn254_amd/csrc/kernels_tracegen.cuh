@@ -357,6 +357,82 @@ __global__ void __launch_bounds__(64) fq12_row_kernel(const uint32_t* __restrict
   }
 }
 
+// The same rows with one lane per (row, output coefficient) -- round 3.  fq12_row_kernel keeps 22 limb polynomials of 31 signed
+// 64-bit coefficients per lane (d[11], s[11] of fq12_output_row: 5.4 KB) next to the operand limbs: 9.8 KB of scratch per lane and
+// 420 VGPRs, every limb product a round trip through scratch memory (44 ms for the 2^18 rows of Fq12ExpStark(512)).  Coefficient c
+// of x*y needs only  d[m] + 9 d[m+6] - s[m+6]  (c < 6, m = c)  or  s[m] + d[m+6] + 9 s[m+6]  (c >= 6, m = c - 6)  with
+// d[q] = sum_{i+j=q} x_i y_j - x_{i+6} y_{j+6},  s[q] = sum_{i+j=q} x_i y_{j+6} + x_{i+6} y_j  (mul.rs:24-87, w^6 = 9 + i): a lane
+// accumulates those (at most 22) weighted limb products straight into ONE polynomial of 31 coefficients held in registers, runs
+// mod_witness on it and writes the 16 + 95 + 1 columns of its coefficient plus the limb columns of a[c] and b[c].  1.4 x the limb
+// products of the shared form (d[m+6], s[m+6] are formed by two lanes), 12 x the lanes, no scratch arrays for the products.  Lanes
+// of a wave share c (lane index = c * n + row): no divergence, coalesced stores.
+__device__ __forceinline__ void conv16_acc(const u64* __restrict__ x4, const u64* __restrict__ y4, int w, int64_t* t) {
+  int xl[16], yl[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) { xl[i] = (int)((x4[i >> 2] >> (16 * (i & 3))) & 0xffff); yl[i] = w * (int)((y4[i >> 2] >> (16 * (i & 3))) & 0xffff); }
+#pragma unroll
+  for (int i = 0; i < 16; i++)
+#pragma unroll
+    for (int j = 0; j < 16; j++) t[i + j] += (int64_t)xl[i] * (int64_t)yl[j];
+}
+__global__ void __launch_bounds__(256) fq12_gadget_kernel(const uint32_t* __restrict__ ios, size_t iow, int log_rpb, const u64* __restrict__ ca,
+                                                          const u64* __restrict__ cb, size_t n, u64* __restrict__ trace, int* __restrict__ err) {
+  const size_t tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (tid >= 12 * n) return;
+  const size_t row = tid % n;
+  const int c = (int)(tid / n);
+  const size_t k = row >> log_rpb, cl = ((size_t)1 << (log_rpb - 1)) + 1;  // chain entries per instance
+  const int r = (int)(row & (((size_t)1 << log_rpb) - 1)), t = r >> 1; const bool sq = r & 1;
+  const bool bit = (ios[iow * k + 192 + (t >> 5)] >> (t & 31)) & 1;
+  const int op = sq ? 1 : (bit ? 2 : 0);  // 1 square, 2 multiply
+  const u64* a = ca + ((k * cl + t) * 12) * 4;                       // [12][4]
+  const u64* b = cb + ((k * cl + t + (sq ? 1 : 0)) * 12) * 4;
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    trace[(size_t)(16 * c + i) * n + row] = (a[4 * c + (i >> 2)] >> (16 * (i & 3))) & 0xffff;
+    trace[(size_t)(192 + 16 * c + i) * n + row] = (b[4 * c + (i >> 2)] >> (16 * (i & 3))) & 0xffff;
+  }
+  u64* g = trace + (size_t)384 * n + row;
+  auto put = [&](int i, u64 v) { g[(size_t)i * n] = v; };
+  if (!op) {  // Fq12Output::default (mul.rs:179-187): zeros, quotient signs 1
+    for (int i = 0; i < 16; i++) put(16 * c + i, 0);
+    for (int i = 0; i < 95; i++) put(192 + 95 * c + i, 0);
+    put(1332 + c, 1);
+    return;
+  }
+  const u64* x = a;
+  const u64* y = op == 1 ? a : b;
+  const u64* out = (op == 1 ? ca : cb) + ((k * cl + t + 1) * 12 + c) * 4;
+  const int m = c < 6 ? c : c - 6;
+  const bool re = c < 6;
+  int64_t pol[31];
+#pragma unroll
+  for (int q = 0; q < 31; q++) pol[q] = 0;
+#pragma unroll 1
+  for (int i = 0; i < 6; i++) {
+    const int jl = m - i, jh = m + 6 - i;          // i + j = m (weights of d[m] / s[m]) and i + j = m + 6 (of d[m+6], s[m+6])
+    if (jl >= 0) {
+      if (re) { conv16_acc(x + 4 * i, y + 4 * jl, 1, pol); conv16_acc(x + 4 * (i + 6), y + 4 * (jl + 6), -1, pol); }
+      else { conv16_acc(x + 4 * i, y + 4 * (jl + 6), 1, pol); conv16_acc(x + 4 * (i + 6), y + 4 * jl, 1, pol); }
+    }
+    if (jh >= 0 && jh <= 5) {
+      const int wd = re ? 9 : 1, ws = re ? -1 : 9;
+      conv16_acc(x + 4 * i, y + 4 * jh, wd, pol); conv16_acc(x + 4 * (i + 6), y + 4 * (jh + 6), -wd, pol);
+      conv16_acc(x + 4 * i, y + 4 * (jh + 6), ws, pol); conv16_acc(x + 4 * (i + 6), y + 4 * jh, ws, pol);
+    }
+  }
+  ModW w;
+  if (!mod_witness(pol, out, true, w)) { atomicOr(err, TG_ERR_WITNESS); return; }
+#pragma unroll
+  for (int i = 0; i < 16; i++) put(16 * c + i, (out[i >> 2] >> (16 * (i & 3))) & 0xffff);
+  int cur = 192 + 95 * c;
+  for (int i = 0; i < 16; i++) put(cur++, (u64)w.out_aux_red[i]);
+  for (int i = 0; i < 17; i++) put(cur++, (u64)w.quot_abs[i]);
+  for (int i = 0; i < 31; i++) put(cur++, (u64)w.aux_lo[i]);
+  for (int i = 0; i < 31; i++) put(cur++, (u64)w.aux_hi[i]);
+  put(1332 + c, w.sign > 0 ? (u64)1 : GLP - 1);
+}
+
 // ---- FqExpStark rows (src/fields/fq/exp.rs:128-176): as fq12_row_kernel with one coefficient; ca / cb: [K][257][4] ---------
 __global__ void __launch_bounds__(128) fq_row_kernel(const uint32_t* __restrict__ ios, const u64* __restrict__ ca, const u64* __restrict__ cb, size_t n,
                                                      u64* __restrict__ trace, int* __restrict__ err) {

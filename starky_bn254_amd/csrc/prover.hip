@@ -949,7 +949,10 @@ static int generate_trace_device_fq12(sbn_prover* P, const uint32_t* ios, size_t
   tracegen_host_chains_fq12(ios, IOW, steps, K, P->h_chain, P->h_chain + cw);
   HIPC(hipMemcpyAsync(ca, P->h_chain, 2 * cw * sizeof(u64), hipMemcpyHostToDevice, st));  // ca and cb are adjacent
   mark();
-  hipLaunchKernelGGL(tg::fq12_row_kernel, blocks(n, 64), dim3(64), 0, st, d_ios, IOW, log_rpb, ca, cb, n, P->d_trace, d_err);
+  // one lane per (row, output coefficient) by default; SBN_FQ12_ROW_KERNEL=1: round 2's one lane per row (A/B)
+  static const bool row_kernel = [] { const char* e = getenv("SBN_FQ12_ROW_KERNEL"); return e && e[0] == '1'; }();
+  if (row_kernel) hipLaunchKernelGGL(tg::fq12_row_kernel, blocks(n, 64), dim3(64), 0, st, d_ios, IOW, log_rpb, ca, cb, n, P->d_trace, d_err);
+  else hipLaunchKernelGGL(tg::fq12_gadget_kernel, blocks(12 * n, 256), dim3(256), 0, st, d_ios, IOW, log_rpb, ca, cb, n, P->d_trace, d_err);
   mark();
   hipLaunchKernelGGL(tg::split_range_check_kernel, dim3((unsigned)sh.num_rc), dim3(256), 0, st, P->d_trace, n, sh.rc_start, sh.start_lookups, d_err);
   mark();
