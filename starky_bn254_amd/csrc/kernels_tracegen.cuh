@@ -357,6 +357,62 @@ __global__ void __launch_bounds__(64) fq12_row_kernel(const uint32_t* __restrict
   }
 }
 
+// ---- the square-and-multiply chains of Fq12ExpStark on the device (round 3) ------------------------------------------------------
+// A[t] = x^(2^t), B[0] = offset, B[t+1] = bit_t ? A[t] B[t] : B[t] (fq12/exp.rs:165-221): 2 x 256 DEPENDENT Fq12 products per
+// instance.  A lane would take ~0.2 s for them and the host pool 1 ms per instance and core (32 ms for 512 instances on a 16-CPU
+// share); but one Fq12 product is 144 independent Fq products, so ONE WORKGROUP walks the chain of one instance: lanes 0..143 form
+// a_i a_j, lanes 144..287 a_i b_j (Montgomery, eight 32-bit limbs), the products meet in LDS, and 24 lanes fold them into the 12 + 12
+// new coefficients (flat basis, w^6 = 9 + i, exactly fq12_mul_m's sums: field arithmetic is exact, so the standard forms written
+// to ca / cb are the host's words).  512 instances = 512 workgroups side by side.
+__device__ __forceinline__ Fq fq12_fold_coeff(const Fq* P, int c) {   // coefficient c of the product from P[i * 12 + j] = x_i y_j
+  const int m = c < 6 ? c : c - 6;
+  const bool re = c < 6;
+  const Fq z = {{0, 0, 0, 0}};
+  Fq lo = z, hd = z, hs = z;     // d[m] (or s[m]),  d[m+6],  s[m+6]
+  for (int i = 0; i < 6; i++) {
+    const int jl = m - i, jh = m + 6 - i;
+    if (jl >= 0) {
+      if (re) lo = fadd(lo, fsub(P[i * 12 + jl], P[(i + 6) * 12 + jl + 6]));
+      else lo = fadd(lo, fadd(P[i * 12 + jl + 6], P[(i + 6) * 12 + jl]));
+    }
+    if (jh >= 0 && jh <= 5) {
+      hd = fadd(hd, fsub(P[i * 12 + jh], P[(i + 6) * 12 + jh + 6]));
+      hs = fadd(hs, fadd(P[i * 12 + jh + 6], P[(i + 6) * 12 + jh]));
+    }
+  }
+  if (m == 5) return lo;
+  const Fq& nine = re ? hd : hs;
+  Fq t = fadd(nine, nine); t = fadd(t, t); t = fadd(t, t); t = fadd(t, nine);     // 9 x
+  return re ? fsub(fadd(lo, t), hs) : fadd(fadd(lo, hd), t);
+}
+__global__ void __launch_bounds__(320) fq12_chain_kernel(const uint32_t* __restrict__ ios, size_t iow, int steps, u64* __restrict__ ca, u64* __restrict__ cb,
+                                                         u64* __restrict__ outs) {   // outs: [K][12][4], B[steps] again, compact (the public inputs' outputs)
+  __shared__ Fq A[12], B[12], PA[144], PB[144];
+  const size_t k = blockIdx.x;
+  const uint32_t* io = ios + iow * k;
+  const int tid = threadIdx.x, c = tid % 12;
+  const bool is_a = tid < 12, is_b = tid >= 12 && tid < 24;
+  if (is_a || is_b) {
+    u64 t4[4]; u32x8_to_u64x4(io + (is_a ? 0 : 96) + 8 * c, t4);
+    (is_a ? A : B)[c] = to_m(t4);
+  }
+  __syncthreads();
+  for (int t = 0;; t++) {
+    if (is_a || is_b) from_m((is_a ? A : B)[c], (is_a ? ca : cb) + ((k * (size_t)(steps + 1) + t) * 12 + c) * 4);
+    if (t == steps) { if (is_b) from_m(B[c], outs + (k * 12 + c) * 4); break; }
+    const bool bit = (io[192 + (t >> 5)] >> (t & 31)) & 1;          // uniform over the workgroup
+    if (tid < 144) PA[tid] = mmul(A[tid / 12], A[tid % 12]);
+    else if (tid < 288 && bit) PB[tid - 144] = mmul(A[(tid - 144) / 12], B[(tid - 144) % 12]);
+    __syncthreads();
+    Fq nv;
+    if (is_a) nv = fq12_fold_coeff(PA, c);
+    else if (is_b && bit) nv = fq12_fold_coeff(PB, c);
+    __syncthreads();                                                   // every product has been read, A / B may change
+    if (is_a) A[c] = nv; else if (is_b && bit) B[c] = nv;
+    __syncthreads();
+  }
+}
+
 // The same rows with one lane per (row, output coefficient) -- round 3.  fq12_row_kernel keeps 22 limb polynomials of 31 signed
 // 64-bit coefficients per lane (d[11], s[11] of fq12_output_row: 5.4 KB) next to the operand limbs: 9.8 KB of scratch per lane and
 // 420 VGPRs, every limb product a round trip through scratch memory (44 ms for the 2^18 rows of Fq12ExpStark(512)).  Coefficient c

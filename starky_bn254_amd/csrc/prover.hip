@@ -921,6 +921,7 @@ static int generate_trace_device_fq12(sbn_prover* P, const uint32_t* ios, size_t
   const size_t cw = (size_t)(steps + 1) * 48 * K;  // one chain of every instance, standard form
   u64* ca = take(cw); u64* cb = take(cw);
   u64* inv = take(n);
+  u64* d_outs = take(K * 48);
   uint32_t* d_ios = (uint32_t*)take(IOW * K / 2 + 1);
   int* d_err = (int*)take(1);
   if ((size_t)(w - wbase) > P->lde_scratch_words) return fail(SBN_ERR_UNSUPPORTED, "scratch does not fit");
@@ -940,14 +941,19 @@ static int generate_trace_device_fq12(sbn_prover* P, const uint32_t* ios, size_t
   hipLaunchKernelGGL(tg::periodic_kernel, blocks(n, 256), dim3(256), 0, st, inv, n, sh.start_periodic, sh.start_io_pulses, sh.start_lookups, (u64)255, P->d_trace);
   hipLaunchKernelGGL(tg::io_pulse_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)(2 * K)), dim3(256), 0, st, inv, n, (size_t)sh.rpb, sh.witness_col(0), P->d_trace);
   mark();
-  if (P->h_chain_words < 2 * cw) {
-    if (P->h_chain) (void)hipHostFree(P->h_chain);
-    P->h_chain = nullptr; P->h_chain_words = 0;
-    HIPC(hipHostMalloc((void**)&P->h_chain, 2 * cw * sizeof(u64), hipHostMallocDefault));
-    P->h_chain_words = 2 * cw;
-  }
-  tracegen_host_chains_fq12(ios, IOW, steps, K, P->h_chain, P->h_chain + cw);
-  HIPC(hipMemcpyAsync(ca, P->h_chain, 2 * cw * sizeof(u64), hipMemcpyHostToDevice, st));  // ca and cb are adjacent
+  // the square-and-multiply chains: one workgroup per instance on the device (kernels_tracegen.cuh fq12_chain_kernel);
+  // SBN_FQ12_HOST_CHAIN=1: the library's host threads + a pinned upload, as in round 2 (A/B)
+  static const bool host_chain = [] { const char* e = getenv("SBN_FQ12_HOST_CHAIN"); return e && e[0] == '1'; }();
+  if (host_chain) {
+    if (P->h_chain_words < 2 * cw) {
+      if (P->h_chain) (void)hipHostFree(P->h_chain);
+      P->h_chain = nullptr; P->h_chain_words = 0;
+      HIPC(hipHostMalloc((void**)&P->h_chain, 2 * cw * sizeof(u64), hipHostMallocDefault));
+      P->h_chain_words = 2 * cw;
+    }
+    tracegen_host_chains_fq12(ios, IOW, steps, K, P->h_chain, P->h_chain + cw);
+    HIPC(hipMemcpyAsync(ca, P->h_chain, 2 * cw * sizeof(u64), hipMemcpyHostToDevice, st));  // ca and cb are adjacent
+  } else hipLaunchKernelGGL(tg::fq12_chain_kernel, dim3((unsigned)K), dim3(320), 0, st, d_ios, IOW, steps, ca, cb, d_outs);
   mark();
   // one lane per (row, output coefficient) by default; SBN_FQ12_ROW_KERNEL=1: round 2's one lane per row (A/B)
   static const bool row_kernel = [] { const char* e = getenv("SBN_FQ12_ROW_KERNEL"); return e && e[0] == '1'; }();
@@ -959,6 +965,11 @@ static int generate_trace_device_fq12(sbn_prover* P, const uint32_t* ios, size_t
   HIPC(hipGetLastError());
   int err = 0;
   HIPC(hipMemcpyAsync(&err, d_err, sizeof(int), hipMemcpyDeviceToHost, st));
+  std::vector<u64> chain_out;                 // B[steps] of every instance (the outputs among the public inputs) when the chains ran on the device
+  if (!host_chain) {
+    chain_out.resize(K * 48);
+    HIPC(hipMemcpyAsync(chain_out.data(), d_outs, K * 48 * sizeof(u64), hipMemcpyDeviceToHost, st));
+  }
   HIPC(hipEventRecord(e1, st));
   HIPC(hipStreamSynchronize(st));
   float ms = 0; HIPC(hipEventElapsedTime(&ms, e0, e1));
@@ -979,7 +990,7 @@ static int generate_trace_device_fq12(sbn_prover* P, const uint32_t* ios, size_t
       for (int i = 0; i < 16; i++) p[16 * c + i] = (ios[IOW * k + 8 * c + (i >> 1)] >> (16 * (i & 1))) & 0xffff;
     if (u64e) p[384] = (u64)ios[IOW * k + 192] | ((u64)ios[IOW * k + 193] << 32);
     else for (int i = 0; i < 8; i++) p[384 + i] = ios[IOW * k + 192 + i];
-    const u64* out = P->h_chain + cw + ((k * (steps + 1) + steps) * 12) * 4;  // B[steps]
+    const u64* out = host_chain ? P->h_chain + cw + ((k * (steps + 1) + steps) * 12) * 4 : chain_out.data() + k * 48;  // B[steps]
     const int ob = 384 + sh.n_exp_slots;
     for (int c = 0; c < 12; c++) for (int i = 0; i < 16; i++) p[ob + 16 * c + i] = (out[4 * c + (i >> 2)] >> (16 * (i & 3))) & 0xffff;
   }
