@@ -85,6 +85,62 @@ __global__ void chain_kernel(const uint32_t* __restrict__ ios, size_t K, u64* __
   if (bad) atomicOr(err, bad);
 }
 
+// ---- the curve chains with ONE WAVE per instance (round 3) --------------------------------------------------------------------
+// exp_chains is 512 dependent point operations per instance: 13 ms on one lane, 2.2 ms on the host pool.  But a Jacobian doubling
+// and an addition are ~25 Fq (4 x that: Fq2) products of which up to 8 (32) are independent, and the doubling of a and the addition
+// b += a of one step do not depend on each other.  The host lays one step out as LEVELS of independent micro-operations over Fq
+// slots (ChainProgram in prover.hip: every product, sum, difference of jac_double / jac_add, Fq2 products expanded into their four
+// Fq products; level = longest dependency path), and a wave executes a level with one micro-operation per lane, operands and
+// results in LDS.  Field arithmetic is exact, so the stored Jacobian coordinates are word for word those of exp_chains.
+// Micro-operation word: kind | dst << 8 | a << 16 | b << 24 (slot numbers < 256).
+enum { CP_NOP = 0, CP_MUL = 1, CP_ADD = 2, CP_SUB = 3, CP_COPY = 4, CP_CHK1 = 5, CP_CHK2 = 6, CP_LANES = 64, CP_MAX_SLOTS = 256 };
+struct ChainProgDev {
+  const uint32_t* ops[2];     // [bit]: [levels][CP_LANES] micro-operations
+  int levels[2];
+  unsigned char in_slot[8];   // slots of x.x x.y offset.x offset.y (E each, component-major as in the io words)
+  unsigned char one_slot[2];  // first components of a.Z and b.Z (set to 1; the other components to 0)
+  unsigned char zero_slot[2]; // second components of a.Z and b.Z (E = 2; 255 = none)
+  unsigned char coord[12];    // slots of a.X a.Y a.Z b.X b.Y b.Z, E each
+};
+template <int E>
+__global__ void __launch_bounds__(CP_LANES) chain_coop_kernel(const uint32_t* __restrict__ ios, size_t K, u64* __restrict__ ja, u64* __restrict__ jb,
+                                                              int* __restrict__ err, ChainProgDev cp) {
+  __shared__ Fq V[CP_MAX_SLOTS];
+  __shared__ uint32_t prog[2][24 * CP_LANES];     // both programs (<= 24 levels each), read 256 times: kept in LDS
+  const size_t k = blockIdx.x;
+  const int lane = threadIdx.x;
+  for (int b = 0; b < 2; b++) for (int lv = 0; lv < cp.levels[b]; lv++) prog[b][lv * CP_LANES + lane] = cp.ops[b][lv * CP_LANES + lane];
+  const uint32_t* io = ios + 8 * (4 * E + 1) * k;
+  if (lane < 4 * E) { u64 t4[4]; u32x8_to_u64x4(io + 8 * lane, t4); V[cp.in_slot[lane]] = to_m(t4); }
+  if (lane >= 32 && lane < 34) V[cp.one_slot[lane - 32]] = fq_one();
+  if (E == 2 && lane >= 40 && lane < 42) V[cp.zero_slot[lane - 40]] = Fq{{0, 0, 0, 0}};
+  __syncthreads();
+  const uint32_t* e = io + 32 * E;
+  for (int t = 0;; t++) {
+    if (lane < 6 * E) {                       // the Jacobian coordinates of step t, Montgomery form (affine_kernel reads them)
+      const int which = lane / (3 * E), cc = (lane % (3 * E)) / E, q = lane % E;
+      const Fq v = V[cp.coord[lane]];
+      u64* dst = (which ? jb : ja) + jac_at<E>(k, t, cc) + 4 * q;
+      for (int i = 0; i < 4; i++) dst[i] = v.l[i];
+    }
+    if (t == 256) break;
+    const int bit = (e[t >> 5] >> (t & 31)) & 1;
+    const uint32_t* ops = prog[bit];
+    const int nl = cp.levels[bit];
+    for (int lv = 0; lv < nl; lv++) {
+      const uint32_t op = ops[lv * CP_LANES + lane];
+      const int kind = op & 255, d = (op >> 8) & 255, a = (op >> 16) & 255, b = op >> 24;
+      if (kind == CP_MUL) V[d] = mmul(V[a], V[b]);
+      else if (kind == CP_ADD) V[d] = fadd(V[a], V[b]);
+      else if (kind == CP_SUB) V[d] = fsub(V[a], V[b]);
+      else if (kind == CP_COPY) V[d] = V[a];
+      else if (kind == CP_CHK1) { if (fzero(V[a])) atomicOr(err, TG_ERR_DEGENERATE); }
+      else if (kind == CP_CHK2) { if (fzero(V[a]) && fzero(V[b])) atomicOr(err, TG_ERR_DEGENERATE); }
+      __syncthreads();
+    }
+  }
+}
+
 // One lane per TG_INV_BATCH values (which, t, k): affine x = X / Z^2, y = Y / Z^3 (Montgomery form) for t = 0..256 of both chains.
 // Lane L owns the values L, L + NL, L + 2 NL, ... (NL lanes): neighbouring lanes read neighbouring values.
 template <int E>

@@ -797,6 +797,89 @@ static int range_check_setup(int device) {
   }
   return 0;
 }
+// One step of the curve chains as levels of independent micro-operations for tg::chain_coop_kernel: the formulas of
+// bnw::jac_double / bnw::jac_add (bn254w.cuh) written once over builder values, Fq2 products expanded into four Fq products,
+// every value in a fresh slot (no hazards), level = 1 + the deepest operand.  Program 0: a <- 2a (exponent bit clear);
+// program 1: b <- b + a, a <- 2a.  Persistent slots: a.X a.Y a.Z b.X b.Y b.Z, E each, in that order from slot 0.
+struct ChainProgram {
+  std::vector<uint32_t> ops[2];
+  int levels[2] = {0, 0};
+  int slots = 0;
+};
+static ChainProgram build_chain_program(int E) {
+  struct Op { int kind, d, a, b, level; };
+  struct Val { int s[2]; };
+  ChainProgram out;
+  for (int bit = 0; bit < 2; bit++) {
+    std::vector<int> lvl;
+    std::vector<Op> ops;
+    auto fresh = [&](int level) { lvl.push_back(level); return (int)lvl.size() - 1; };
+    auto emit = [&](int kind, int a, int b) { const int L = 1 + std::max(lvl[a], lvl[b]); const int d = fresh(L); ops.push_back({kind, d, a, b, L}); return d; };
+    auto add = [&](Val x, Val y) { Val r{}; for (int q = 0; q < E; q++) r.s[q] = emit(tg::CP_ADD, x.s[q], y.s[q]); return r; };
+    auto sub = [&](Val x, Val y) { Val r{}; for (int q = 0; q < E; q++) r.s[q] = emit(tg::CP_SUB, x.s[q], y.s[q]); return r; };
+    auto mul = [&](Val x, Val y) {
+      Val r{};
+      if (E == 1) { r.s[0] = emit(tg::CP_MUL, x.s[0], y.s[0]); return r; }
+      const int t0 = emit(tg::CP_MUL, x.s[0], y.s[0]), t1 = emit(tg::CP_MUL, x.s[1], y.s[1]);
+      const int t2 = emit(tg::CP_MUL, x.s[0], y.s[1]), t3 = emit(tg::CP_MUL, x.s[1], y.s[0]);
+      r.s[0] = emit(tg::CP_SUB, t0, t1); r.s[1] = emit(tg::CP_ADD, t2, t3);   // Fq2 = Fq[i] / (i^2 + 1), cmul of bn254w.cuh
+      return r;
+    };
+    auto chk_zero = [&](Val x) {   // czero: every component zero -> TG_ERR_DEGENERATE
+      const int a = x.s[0], b = E == 2 ? x.s[1] : x.s[0];
+      ops.push_back({E == 2 ? tg::CP_CHK2 : tg::CP_CHK1, 0, a, b, 1 + std::max(lvl[a], lvl[b])});
+    };
+    Val pa[3], pb[3];                                           // persistent a, b: slots 0 .. 6E-1, level 0
+    for (int c = 0; c < 3; c++) for (int q = 0; q < E; q++) pa[c].s[q] = fresh(0);
+    for (int c = 0; c < 3; c++) for (int q = 0; q < E; q++) pb[c].s[q] = fresh(0);
+    Val nb[3] = {pb[0], pb[1], pb[2]};
+    if (bit) {   // b + a: add-2007-bl, p = b, q = a (exp_chains: b = jac_add(b, a))
+      const Val Z1Z1 = mul(pb[2], pb[2]), Z2Z2 = mul(pa[2], pa[2]);
+      const Val U1 = mul(pb[0], Z2Z2), U2 = mul(pa[0], Z1Z1);
+      const Val S1 = mul(mul(pb[1], pa[2]), Z2Z2), S2 = mul(mul(pa[1], pb[2]), Z1Z1);
+      const Val H = sub(U2, U1);
+      chk_zero(H);
+      const Val H2 = add(H, H), I = mul(H2, H2), J = mul(H, I);
+      const Val rr0 = sub(S2, S1), r = add(rr0, rr0);
+      const Val V = mul(U1, I);
+      nb[0] = sub(sub(mul(r, r), J), add(V, V));
+      const Val sj = mul(S1, J);
+      nb[1] = sub(mul(r, sub(V, nb[0])), add(sj, sj));
+      const Val zs = add(pb[2], pa[2]);
+      nb[2] = mul(sub(sub(mul(zs, zs), Z1Z1), Z2Z2), H);
+    }
+    chk_zero(pa[1]);   // exp_chains: czero(a.Y) before every doubling
+    Val na[3];
+    {   // 2a: dbl-2009-l
+      const Val A = mul(pa[0], pa[0]), B = mul(pa[1], pa[1]), C = mul(B, B);
+      const Val t0 = add(pa[0], B), t1 = mul(t0, t0), t2 = sub(sub(t1, A), C);
+      const Val D = add(t2, t2), Ee = add(add(A, A), A), F = mul(Ee, Ee);
+      na[0] = sub(F, add(D, D));
+      const Val C2 = add(C, C), C4 = add(C2, C2), C8 = add(C4, C4);
+      na[1] = sub(mul(Ee, sub(D, na[0])), C8);
+      const Val yz = mul(pa[1], pa[2]);
+      na[2] = add(yz, yz);
+    }
+    int top = 0;
+    for (const Op& o : ops) top = std::max(top, o.level);
+    for (int c = 0; c < 3; c++) for (int q = 0; q < E; q++) {   // the new points replace the old ones after every read
+      ops.push_back({tg::CP_COPY, pa[c].s[q], na[c].s[q], na[c].s[q], top + 1});
+      if (bit) ops.push_back({tg::CP_COPY, pb[c].s[q], nb[c].s[q], nb[c].s[q], top + 1});
+    }
+    const int nl = top + 1;
+    out.levels[bit] = nl;
+    out.slots = std::max(out.slots, (int)lvl.size());
+    out.ops[bit].assign((size_t)nl * tg::CP_LANES, 0u);
+    std::vector<int> fill(nl, 0);
+    for (const Op& o : ops) {
+      const int L = o.level - 1;
+      if (fill[L] >= tg::CP_LANES || (int)lvl.size() > tg::CP_MAX_SLOTS) { out.levels[0] = out.levels[1] = -1; return out; }   // (cannot happen for E <= 2: checked by the caller)
+      out.ops[bit][(size_t)L * tg::CP_LANES + fill[L]++] = (uint32_t)o.kind | ((uint32_t)o.d << 8) | ((uint32_t)o.a << 16) | ((uint32_t)o.b << 24);
+    }
+  }
+  return out;
+}
+
 template <int E>
 static int generate_trace_device(sbn_prover* P, const uint32_t* ios, size_t K, uint64_t* pi_out) {
   const size_t n = P->n;
@@ -821,6 +904,7 @@ static int generate_trace_device(sbn_prover* P, const uint32_t* ios, size_t K, u
   u64* d_out = take(16 * E * K);
   unsigned char* row_op = (unsigned char*)take(n / 8 + 1);
   uint32_t* d_ios = (uint32_t*)take(IOW * K / 2 + 1);
+  uint32_t* d_prog[2] = {(uint32_t*)take(64 * tg::CP_LANES / 2), (uint32_t*)take(64 * tg::CP_LANES / 2)};   // chain programs: <= 64 levels of 64 micro-operations
   int* d_err = (int*)take(1);
   unsigned int* d_cnt = n > 65536 ? (unsigned int*)take((size_t)sh.num_rc * 32768) : nullptr;   // u32 histograms of the range-checked columns
   if ((size_t)(w - wbase) > P->lde_scratch_words) return fail(SBN_ERR_UNSUPPORTED, "scratch does not fit");
@@ -841,7 +925,23 @@ static int generate_trace_device(sbn_prover* P, const uint32_t* ios, size_t K, u
   hipLaunchKernelGGL(tg::io_pulse_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)(2 * K)), dim3(256), 0, st, inv, n, (size_t)sh.rpb, sh.witness_col(0), P->d_trace);
   mark();
   // the two 256-step curve chains per instance: host threads while the device writes the input-independent columns
-  if (getenv("SBN_TRACEGEN_DEVICE_CHAIN")) hipLaunchKernelGGL(tg::chain_kernel<E>, blocks(K, 64), dim3(64), 0, st, d_ios, K, ja, jb, d_err);
+  // SBN_TRACEGEN_DEVICE_CHAIN: 2 = one wave per instance walking levels of independent Fq operations (tg::chain_coop_kernel),
+  // 1 = one lane per instance (tg::chain_kernel, 13 ms), unset = host threads + pinned upload
+  const char* dce = getenv("SBN_TRACEGEN_DEVICE_CHAIN");
+  if (dce && dce[0] == '2') {
+    static const ChainProgram prog = build_chain_program(E);
+    if (prog.levels[0] <= 0 || prog.levels[0] > 24 || prog.levels[1] > 24) return fail(SBN_ERR_UNSUPPORTED, "internal: chain program does not fit");
+    tg::ChainProgDev cp{};
+    for (int b = 0; b < 2; b++) {
+      HIPC(hipMemcpyAsync(d_prog[b], prog.ops[b].data(), prog.ops[b].size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+      cp.ops[b] = d_prog[b]; cp.levels[b] = prog.levels[b];
+    }
+    for (int v = 0; v < 4; v++) for (int q = 0; q < E; q++) cp.in_slot[v * E + q] = (unsigned char)((v < 2 ? v : v + 1) * E + q);   // a.X a.Y | b.X b.Y
+    cp.one_slot[0] = (unsigned char)(2 * E); cp.one_slot[1] = (unsigned char)(5 * E);
+    cp.zero_slot[0] = (unsigned char)(2 * E + 1); cp.zero_slot[1] = (unsigned char)(5 * E + 1);
+    for (int i = 0; i < 6 * E; i++) cp.coord[i] = (unsigned char)i;
+    hipLaunchKernelGGL(tg::chain_coop_kernel<E>, dim3((unsigned)K), dim3(tg::CP_LANES), 0, st, d_ios, K, ja, jb, d_err, cp);
+  } else if (dce) hipLaunchKernelGGL(tg::chain_kernel<E>, blocks(K, 64), dim3(64), 0, st, d_ios, K, ja, jb, d_err);
   else {
     if (P->h_chain_words < 2 * cw) {
       if (P->h_chain) (void)hipHostFree(P->h_chain);
