@@ -1203,10 +1203,12 @@ template <int KIND>
 static void launch_quotient_kind(sbn_prover* P, const QuotientParams& qp, size_t qblocks) {
   const dim3 g1((unsigned)qblocks, 1), g2((unsigned)qblocks, 2);
   if (qp.seg_mask & 12u) hipLaunchKernelGGL((quotient_kernel<KIND, 2>), g2, dim3(256), 0, P->hstream, qp, qp.apow[0], qp.apow[1], qp.pic);
+  // SBN_QUOTIENT_TAIL (A/B): 1 = the tail segment behind the permutation checks on the second stream instead of behind the head;
+  // 2 = the tail IN FRONT of the head on the main stream (it then walks the lookup columns at the same time as the permutation checks)
+  static const int tail_mode = [] { const char* e = getenv("SBN_QUOTIENT_TAIL"); return e ? atoi(e) : 0; }();
+  if (tail_mode == 2 && (qp.seg_mask & 2u)) hipLaunchKernelGGL((quotient_kernel<KIND, 1>), g1, dim3(256), 0, P->stream, qp, qp.apow[0], qp.apow[1], qp.pic);
   if (qp.seg_mask & 1u) hipLaunchKernelGGL((quotient_kernel<KIND, 0>), g1, dim3(256), 0, P->stream, qp, qp.apow[0], qp.apow[1], qp.pic);
-  // SBN_QUOTIENT_TAIL=1 (A/B): the tail segment behind the permutation checks on the second stream instead of behind the head
-  static const bool tail_on_second = [] { const char* e = getenv("SBN_QUOTIENT_TAIL"); return e && e[0] == '1'; }();
-  if (qp.seg_mask & 2u) hipLaunchKernelGGL((quotient_kernel<KIND, 1>), g1, dim3(256), 0, tail_on_second ? P->hstream : P->stream, qp, qp.apow[0], qp.apow[1], qp.pic);
+  if (tail_mode != 2 && (qp.seg_mask & 2u)) hipLaunchKernelGGL((quotient_kernel<KIND, 1>), g1, dim3(256), 0, tail_mode == 1 ? P->hstream : P->stream, qp, qp.apow[0], qp.apow[1], qp.pic);
 }
 static int launch_quotient_parts(sbn_prover* P, const QuotientParams& qp, size_t qblocks) {
   switch (P->air.kind) {
