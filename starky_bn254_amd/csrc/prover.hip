@@ -127,6 +127,9 @@ struct sbn_prover {
   bool ntt_fused = false;                    // the inverse transform's pass B and the LDE's pass A as ONE kernel (2^16 / 2^17 rows)
   u64* d_tmp2 = nullptr;                     // its output: the fused kernel cannot work in place
   hipStream_t hstream = nullptr;             // sponge absorption / Merkle stream
+  hipStream_t nstream = nullptr;             // second transform stream (2^19 LDE rows and up): the LDE of chunk k beside the inverse transform of chunk k+1
+  hipEvent_t intt_done[MAX_CHUNKS];          // main -> second transform stream: the coefficients of chunk k are complete
+  bool ntt_two_streams = false;
   hipEvent_t chunk_ready[MAX_CHUNKS];        // main -> hash: LDE chunk k is complete
   hipEvent_t abs_ev[2 * MAX_CHUNKS];         // hash stream: before/after each absorb launch
   hipEvent_t hash_done;                      // hash -> main
@@ -343,9 +346,20 @@ static int commit_pipeline(sbn_prover* P, const u64* vals, u64* coef, u64* lde, 
   // (12.3 -> 14.8 ms of sponge kernel time).
   for (size_t k = 0; k < nchunks; k++) {
     size_t c0 = k * ch, nc = std::min(ch, ncols - c0);
-    int rc = intt_then_lde_chunk(P, vals, coef, lde, c0, nc);
-    if (rc) return rc;
-    HIPC(hipEventRecord(P->chunk_ready[k], P->stream));
+    int rc;
+    if (P->ntt_two_streams && !P->ntt_sub && !P->ntt_fused) {
+      rc = ntt_columns(P, vals + c0 * P->n, P->n, coef + c0 * P->n, P->n, P->d_tmp, P->m, nc, P->degree_bits, true, P->n, nullptr, nullptr, host_inv_pow2(P->degree_bits));
+      if (rc) return rc;
+      HIPC(hipEventRecord(P->intt_done[k], P->stream));
+      HIPC(hipStreamWaitEvent(P->nstream, P->intt_done[k], 0));
+      rc = ntt_columns(P, coef + c0 * P->n, P->n, lde + c0 * P->m, P->m, P->d_tmp2, P->m, nc, P->lde_log, false, P->n, P->d_shift, nullptr, 1, P->nstream);
+      if (rc) return rc;
+      HIPC(hipEventRecord(P->chunk_ready[k], P->nstream));
+    } else {
+      rc = intt_then_lde_chunk(P, vals, coef, lde, c0, nc);
+      if (rc) return rc;
+      HIPC(hipEventRecord(P->chunk_ready[k], P->stream));
+    }
     HIPC(hipStreamWaitEvent(P->hstream, P->chunk_ready[k], 0));
     HIPC(hipEventRecord(P->abs_ev[2 * k], P->hstream));
     hipLaunchKernelGGL(leaf_absorb_kernel, dim3((unsigned)((P->m + 255) / 256)), dim3(256), 0, P->hstream, lde + c0 * P->m, P->m, P->lde_log, (u32)nc,
@@ -582,6 +596,15 @@ static int create_ctx(const sbn_air_desc* air, const sbn_config* cfg, uint32_t d
   acc(ntt_fast_setup());
   hipc(hipStreamCreate(&P->stream), "hipStreamCreate");
   hipc(hipStreamCreate(&P->hstream), "hipStreamCreate");
+  // From 2^19 LDE rows up the transform stream, not the sum of the instruction streams, bounds the commitments (profiles/
+  // r3_v8_fq12_512_kernel_stats.csv: five passes of 410 us per chunk beside a 1.19 ms sponge launch, 1.63 ms of VALU work in a 2.05 ms
+  // period): the LDE passes of chunk k then run on a second stream beside the inverse passes of chunk k+1 (SBN_NTT_STREAMS=1: one
+  // stream, =2: two streams at any size -- at 2^16 rows, where the stage IS at its VALU bound, this was measured slower in round 2).
+  { const char* ne = getenv("SBN_NTT_STREAMS"); P->ntt_two_streams = ne ? ne[0] == '2' : P->lde_log >= 19; }
+  if (P->ntt_two_streams) {
+    hipc(hipStreamCreate(&P->nstream), "hipStreamCreate");
+    for (auto& e : P->intt_done) hipc(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
+  }
   for (auto& e : P->ev) hipc(hipEventCreate(&e), "hipEventCreate");
   for (auto& e : P->abs_ev) hipc(hipEventCreate(&e), "hipEventCreate");
   for (auto& e : P->chunk_ready) hipc(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
@@ -635,7 +658,7 @@ static int create_ctx(const sbn_air_desc* air, const sbn_config* cfg, uint32_t d
     acc(tree_alloc(P->tree_t, m, cfg->cap_height)); acc(tree_alloc(P->tree_z, m, cfg->cap_height));
   }
   acc(dmalloc(&P->d_tmp, std::max(P->ntt_chunk, (size_t)4) * m));
-  if (P->ntt_fused) acc(dmalloc(&P->d_tmp2, std::max(P->ntt_chunk, (size_t)4) * m));
+  if (P->ntt_fused || P->ntt_two_streams) acc(dmalloc(&P->d_tmp2, std::max(P->ntt_chunk, (size_t)4) * m));
   acc(dmalloc(&P->d_q, 2 * m)); acc(dmalloc(&P->d_qlde, 4 * m));
   acc(tree_alloc(P->tree_q, m, cfg->cap_height));
   acc(dmalloc(&P->d_tw_f, m)); acc(dmalloc(&P->d_tw_i, m)); acc(dmalloc(&P->d_shift, m)); acc(dmalloc(&P->d_shift_inv, m));
@@ -742,6 +765,7 @@ extern "C" void sbn_prover_destroy(sbn_prover* P) {
   if (P->h_open) (void)hipHostFree(P->h_open);
   if (P->h_open2) (void)hipHostFree(P->h_open2);
   if (P->hstream) (void)hipStreamDestroy(P->hstream);
+  if (P->nstream) { (void)hipStreamDestroy(P->nstream); for (auto& e : P->intt_done) if (e) (void)hipEventDestroy(e); }
   if (P->stream) (void)hipStreamDestroy(P->stream);
   delete P;
 }
