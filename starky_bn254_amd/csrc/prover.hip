@@ -452,21 +452,33 @@ static int commit_split(sbn_prover* P, const ColShare& sh, const u64* vals, bool
   const u32 row_log = P->lde_log - S->log_r;
   for (size_t k = 0; k < steps; k++) {
     const size_t b = k * R + me, nc = sh.block_cols(b);
+    hipStream_t tstream = P->stream;                                        // the stream that completes block k's LDE (and pack)
     u64* const slot = (u64*)S->comm.send_buf + (k & 1) * S->slot_words;     // [plane][dest][ob][ml]
     u64* const slot_n = S->planes == 2 ? slot + (size_t)R * ob * ml : nullptr;
     if (nc) {
       const u64* v = vals + (vals_global ? b : k) * ob * n;
       u64* cf = coef_own + k * ob * n;
       u64* lde_out = R == 1 ? plane_l + b * ob * m : S->d_ldechunk;
-      int rc = intt_lde_cols(P, v, cf, lde_out, nc);
+      // two transform streams from 2^19 LDE rows up (as in commit_pipeline): the LDE (and the pack) of block k beside the inverse
+      // transform of block k + 1
+      const bool two = P->ntt_two_streams && !P->ntt_fused && P->d_tmp2;
+      tstream = two ? P->nstream : P->stream;
+      int rc;
+      if (two) {
+        rc = ntt_columns(P, v, n, cf, n, P->d_tmp, m, nc, P->degree_bits, true, n, nullptr, nullptr, host_inv_pow2(P->degree_bits));
+        if (rc) return rc;
+        HIPC(hipEventRecord(P->intt_done[k], P->stream));
+        HIPC(hipStreamWaitEvent(P->nstream, P->intt_done[k], 0));
+        rc = ntt_columns(P, cf, n, lde_out, m, P->d_tmp2, m, nc, P->lde_log, false, n, P->d_shift, nullptr, 1, P->nstream);
+      } else rc = intt_lde_cols(P, v, cf, lde_out, nc);
       if (rc) return rc;
-      if (R > 1 && k >= 2) HIPC(hipStreamWaitEvent(P->stream, S->xchg_done[k - 2], 0));   // send slot k & 1 has left
+      if (R > 1 && k >= 2) HIPC(hipStreamWaitEvent(tstream, S->xchg_done[k - 2], 0));   // send slot k & 1 has left
       if (R > 1)
-        hipLaunchKernelGGL(split_pack_kernel, dim3((unsigned)((m + 255) / 256), (unsigned)nc), dim3(256), 0, P->stream, S->d_ldechunk, m, (u32)nc, (u32)ob, S->log_r, me,
+        hipLaunchKernelGGL(split_pack_kernel, dim3((unsigned)((m + 255) / 256), (unsigned)nc), dim3(256), 0, tstream, S->d_ldechunk, m, (u32)nc, (u32)ob, S->log_r, me,
                            slot, slot_n, plane_l + b * ob * ml, plane_n ? plane_n + b * ob * ml : nullptr);
       HIPC(hipGetLastError());
     }
-    HIPC(hipEventRecord(P->chunk_ready[k], P->stream));
+    HIPC(hipEventRecord(P->chunk_ready[k], tstream));
     hipEvent_t arrived = P->chunk_ready[k];
     if (R > 1) {
       HIPC(hipStreamWaitEvent(S->cstream, P->chunk_ready[k], 0));
