@@ -208,29 +208,34 @@ struct PolynomialBatch {
     size_t m = n << rate_bits;
     unsigned lgm = b.degree_log + rate_bits;
     PhaseTimer pt;
-    std::vector<std::vector<GF>> lde(ncols);
-#pragma omp parallel for schedule(dynamic, 4)
-    for (size_t c = 0; c < ncols; c++) lde[c] = coset_lde(polys[c], rate_bits, GF(GL_GENERATOR));
-    pt.lap("commit: coset LDE (per column)");
-    // transpose + reverse_index_bits_in_place
+    // transpose + reverse_index_bits_in_place, in CHUNKS of columns: a chunk's LDE columns are scattered into the leaf rows and
+    // freed before the next chunk is transformed, so the transient column-major copy of the LDE matrix is bounded (1 GiB) instead
+    // of a second whole matrix (49 GB for the 2^18-row Fq12 table; tools/oracle_digest.py).  Same leaves, same digests.
     // (blocks of 64 natural-order points: every column is read in contiguous runs and the 64 destination rows stay in cache)
     b.tree.leaves.assign(m, std::vector<GF>());
 #pragma omp parallel for schedule(static)
     for (size_t i = 0; i < m; i++) b.tree.leaves[i].resize(ncols);
     pt.lap("commit: leaf allocation");
+    size_t chunk = ((size_t)1 << 27) / m;          // 2^27 words = 1 GiB of LDE columns in flight
+    if (chunk < 64) chunk = 64;
     const size_t TB = m < 64 ? m : 64;
+    for (size_t c0 = 0; c0 < ncols; c0 += chunk) {
+      const size_t nc = ncols - c0 < chunk ? ncols - c0 : chunk;
+      std::vector<std::vector<GF>> lde(nc);
+#pragma omp parallel for schedule(dynamic, 4)
+      for (size_t c = 0; c < nc; c++) lde[c] = coset_lde(polys[c0 + c], rate_bits, GF(GL_GENERATOR));
+      pt.lap("commit: coset LDE (per column)");
 #pragma omp parallel for schedule(static)
-    for (size_t s0 = 0; s0 < m; s0 += TB) {
-      GF* dst[64];
-      for (size_t k = 0; k < TB; k++) dst[k] = b.tree.leaves[reverse_bits(s0 + k, lgm)].data();
-      for (size_t c = 0; c < ncols; c++) {
-        const GF* col = lde[c].data() + s0;
-        for (size_t k = 0; k < TB; k++) dst[k][c] = col[k];
+      for (size_t s0 = 0; s0 < m; s0 += TB) {
+        GF* dst[64];
+        for (size_t k = 0; k < TB; k++) dst[k] = b.tree.leaves[reverse_bits(s0 + k, lgm)].data() + c0;
+        for (size_t c = 0; c < nc; c++) {
+          const GF* col = lde[c].data() + s0;
+          for (size_t k = 0; k < TB; k++) dst[k][c] = col[k];
+        }
       }
+      pt.lap("commit: transpose + bit reversal");
     }
-    pt.lap("commit: transpose + bit reversal");
-    { std::vector<std::vector<GF>>().swap(lde); }
-    pt.lap("commit: free LDE columns");
     b.tree.build(cap_height);
     pt.lap("commit: leaf hashes + Merkle levels");
     b.polynomials = std::move(polys);

@@ -3,6 +3,7 @@ libsbn254.so and is compared bit-for-bit with the CPU oracle, the committed gold
 the full BASELINE size -- through size-independent properties (independent verifier accepts, tamper
 rejection, determinism)."""
 import hashlib
+import json
 import os
 
 import numpy as np
@@ -10,6 +11,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 P = 0xFFFFFFFF00000001
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 @pytest.fixture(scope="module")
@@ -566,10 +568,21 @@ def test_fq12exp_proof_matches_oracle_digest_and_verifies(gpu, O, fq12exp_case, 
         gpu.verify_stark_proof(stark, gpu.Proof(t, 13), cfg)
 
 
-def test_fq12exp_2pow16_independent_verifier(gpu, O):
-    """Size-independent property at 2^16 rows (Fq12ExpStark(128), 10250 columns, 74752 public inputs): the CPU
+def _assert_stages_equal_kit(O, words, key):
+    """The device proof against the committed ORACLE-PROVER run of the same instance list (tools/oracle_digest.py, run once on a
+    GPU box: Fq12ExpStark(128) 27 s / 44 GB, Fq12ExpStark(512) 178 s / 167 GB on 16 threads): proof sha256 and every stage of
+    prove() in order -- a mismatch names the first stage that differs."""
+    import parity_kit as K
+    kit = json.load(open(os.path.join(GOLD, "parity_kit", key + ".json")))
+    got = json.loads(json.dumps(K.stage_digests(words, O.poseidon_permute)))
+    assert K.first_difference(got, kit["stages"]["times_x"]) is None, (key, K.first_difference(got, kit["stages"]["times_x"]))
+
+
+def test_fq12exp_2pow16_independent_verifier(gpu, O, golden):
+    """Fq12ExpStark(128) (2^16 rows x 10250 columns, 74752 public inputs): GPU proof bytes == the CPU oracle PROVER's
+    (committed sha256 and per-stage digests, tests/golden/proof_digests.json fq12exp_io128_seed11), the CPU
     oracle's VERIFIER (independent code) accepts the GPU proof, outputs equal offset * x^e computed with python
-    tower arithmetic, and a flipped opening is rejected.  (The oracle's prover would need ~10 minutes here.)"""
+    tower arithmetic, and a flipped opening is rejected."""
     num_io = 128
     ios, native = O.fq12exp_inputs(num_io, 11)
     stark = gpu.Fq12ExpStark(num_io)
@@ -580,6 +593,11 @@ def test_fq12exp_2pow16_independent_verifier(gpu, O):
         got = [sum(int(pi[584 * k + 392 + 16 * c + i]) << (16 * i) for i in range(16)) for c in range(12)]
         assert got == O.fq12_mul(off, O.fq12_pow(x, e))
     proof = gpu.prove(stark, cfg, trace, pi)
+    g = golden["proof_digests"]["fq12exp_io128_seed11"]
+    assert hashlib.sha256(pi.tobytes()).hexdigest() == g["pi_sha256"]
+    assert len(proof.words) == g["proof_words"] and [int(x) for x in proof.words[12:16]] == g["trace_cap0"]
+    assert hashlib.sha256(proof.to_bytes()).hexdigest() == g["proof_sha256"]
+    _assert_stages_equal_kit(O, proof.words, "fq12exp_io128_seed11")
     assert O.verify(O.AIR_FQ12_EXP, num_io, proof.words) == (0, "")
     gpu.verify_stark_proof(stark, proof, cfg)
     t = proof.words.copy()
@@ -587,12 +605,14 @@ def test_fq12exp_2pow16_independent_verifier(gpu, O):
     assert O.verify(O.AIR_FQ12_EXP, num_io, t)[0] != 0
 
 
-def test_fq12exp_2pow18_config4(gpu, O):
+def test_fq12exp_2pow18_config4(gpu, O, golden):
     """BASELINE config[4] on one GPU: Fq12ExpStark(512), 2^18 rows x 11786 columns (24.7 GB trace, never on the host:
-    the witness is generated on the device), reference workload src/fields/fq12/exp.rs:638-696.  The oracle's prover
-    would need an hour here, so the size-independent checks of the 2^16 case: outputs equal offset * x^e by python tower
-    arithmetic, the oracle's VERIFIER (independent code) and the product's accept the proof, a flipped opening / cap /
-    public input is rejected, and a second prove() is word-identical."""
+    the witness is generated on the device), reference workload src/fields/fq12/exp.rs:638-696.  GPU proof bytes == the CPU
+    oracle PROVER's proof of the same 512 instances (committed sha256 and per-stage digests: tests/golden/proof_digests.json
+    fq12exp_io512_seed3, tests/golden/parity_kit/fq12exp_io512_seed3.json, generated by tools/oracle_digest.py), plus the
+    size-independent checks: outputs equal offset * x^e by python tower arithmetic, the oracle's VERIFIER (independent code)
+    and the product's accept the proof, a flipped opening / cap / public input is rejected, and a second prove() is
+    word-identical."""
     num_io = 512
     ios, native = O.fq12exp_inputs(num_io, 3)
     stark = gpu.Fq12ExpStark(num_io)
@@ -611,6 +631,11 @@ def test_fq12exp_2pow18_config4(gpu, O):
     finally:
         prover.close()
     assert np.array_equal(p1.words, p2.words)
+    g = golden["proof_digests"]["fq12exp_io512_seed3"]
+    assert hashlib.sha256(np.asarray(pi, dtype=np.uint64).tobytes()).hexdigest() == g["pi_sha256"]
+    assert len(p1.words) == g["proof_words"] and [int(x) for x in p1.words[12:16]] == g["trace_cap0"]
+    assert hashlib.sha256(p1.to_bytes()).hexdigest() == g["proof_sha256"]
+    _assert_stages_equal_kit(O, p1.words, "fq12exp_io512_seed3")
     assert p1.recover_degree_bits(cfg) == 18
     assert np.array_equal(p1.words[-299008:], pi)
     assert O.verify(O.AIR_FQ12_EXP, num_io, p1.words) == (0, "")

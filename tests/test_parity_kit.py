@@ -52,6 +52,27 @@ def test_kit_file_is_complete_and_matches_the_proof_digests(case, golden):
     assert len(kit["inputs_u32"]) == int(np.prod(kit["inputs_shape"]))
 
 
+# The two tables whose oracle proof takes minutes and tens to hundreds of GB (tools/oracle_digest.py, run once on a GPU box):
+# default FRI variant only, inputs by seed (their sha256 is committed instead of 25,600 / 102,400 numbers).
+BIG_CASES = ["fq12exp_io128_seed11", "fq12exp_io512_seed3"]
+
+
+@pytest.mark.parametrize("case", BIG_CASES)
+def test_big_kit_files_match_the_proof_digests_and_the_seeded_inputs(case, golden, O):
+    kit = load(case)
+    d = kit["stages"]["times_x"]
+    assert [k for k in K.STAGES if k not in d] == []
+    assert d["pow_ok"] and len(d["query_indices"]) == 84 and len(d["trace_cap"]) == 64 and len(d["fri_commit_caps"]) == len(d["fri_betas"]) == 3
+    g = golden["proof_digests"][case]
+    assert d["proof"] == {"sha256": g["proof_sha256"], "words": g["proof_words"]}
+    assert kit["trace_sha256"] == g["trace_sha256"] and kit["public_inputs_sha256"] == g["pi_sha256"]
+    assert g["gpu_proof_equal_on_the_box"] is True
+    ios, _ = O.fq12exp_inputs(kit["num_io"], kit["seed"])
+    assert list(ios.shape) == kit["inputs_shape"]
+    assert hashlib.sha256(np.ascontiguousarray(ios, dtype="<u4").tobytes()).hexdigest() == kit["inputs_u32_sha256"]
+    assert kit["rows"] == 512 * kit["num_io"] and kit["num_columns"] == O.lib().orc_air_num_columns(O.AIR_FQ12_EXP, kit["num_io"])
+
+
 def _oracle_case(O, kit):
     if kit["table"] == "MyStark":
         ins, tab = O.lookup_inputs(kit["rows"], kit["seed"])

@@ -156,7 +156,7 @@ def test_split_proof_over_the_native_rccl_transport_world_1(S, O, golden):
     assert t["split_exchange_ms"] > 0
 
 
-def test_split_proof_at_config4_size_two_local_ranks(S, O):
+def test_split_proof_at_config4_size_two_local_ranks(S, O, golden):
     """BASELINE config[4]'s table at full size -- Fq12ExpStark(512): 2^18 rows x 11,786 columns, 185 + 84 column blocks, send
     slots of 0.27 GB, a 36 GB row matrix per rank -- split over two ranks (threads, one GPU; four and more ranks of this size
     do not fit one card's HBM beside each other): the offsets and counts that only get large here (block * 64 * M words, the
@@ -180,6 +180,10 @@ def test_split_proof_at_config4_size_two_local_ranks(S, O):
     finally:
         single.close()
     assert np.array_equal(split_words, ref.words)
+    # ... and the CPU oracle PROVER's proof of the same instances (committed digest, tools/oracle_digest.py)
+    g = golden["proof_digests"]["fq12exp_io512_seed3"]
+    assert len(split_words) == g["proof_words"]
+    assert hashlib.sha256(np.ascontiguousarray(split_words, dtype="<u8").tobytes()).hexdigest() == g["proof_sha256"]
     S.verify_stark_proof(stark, ref, cfg)
     print(f"config[4] size, 2 local ranks: exchange {[round(t['split_exchange_ms'], 1) for t in times]} ms")
 
