@@ -58,6 +58,9 @@ def main():
                     help="--split with --backend nccl: rccl = the library's own RCCL transport (grouped ncclSend / ncclRecv, no Python in the data "
                          "path; default), torch = the same exchanges through torch.distributed")
     ap.add_argument("--num-io", type=int, default=None, help="instances of the table (default 128; --split --table fq12: 512)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="print the per-rank plan of this mode for --gpus ranks (units per rank, or column blocks / bytes per xGMI link / staging sizes of a "
+                         "split proof) as one JSON object and exit: touches no GPU and needs no process group (first contact with an 8-GPU node)")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="PMC-measured HBM bytes per dominant-kernel launch; default: profiles/*_pmc_summary.json (separate rocprofv3 --pmc passes)")
     args = ap.parse_args()
@@ -65,6 +68,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.dry_run:
+        print(json.dumps(dry_run_plan(args), indent=1))
+        return
     # host worker pool of the library (Jacobian chains of the device witness generation, canonical checks): the ranks of a
     # node share its cores
     from starky_bn254_amd.sharding import effective_cpus
@@ -219,12 +225,18 @@ def main():
     if rank == 0:
         prover.generate_trace(ios)
         t0 = time.perf_counter()
+        wall_gen = wall_prove = 0.0
         for _ in range(5):
+            ta = time.perf_counter()
             pi_dev = prover.generate_trace(ios)
+            tb = time.perf_counter()
             tg_ms = prover.stage_times()["device_tracegen_ms"]
             proof_dev = prover.prove()
+            wall_gen += tb - ta
+            wall_prove += time.perf_counter() - tb
         torch.cuda.synchronize()
         e2e = {"device_tracegen_ms": tg_ms, "ios_to_proof_ms_device_witness": (time.perf_counter() - t0) / 5 * 1e3,
+               "generate_trace_wall_ms": wall_gen / 5 * 1e3, "prove_after_generate_wall_ms": wall_prove / 5 * 1e3,
                "same_proof_as_host_witness": bool((proof_dev.words == proof.words).all() and (pi_dev == pi).all())}
 
     if rank == 0:
@@ -243,13 +255,18 @@ def main():
                        "degree_bits": DEGREE_BITS, "num_columns": stark.num_columns, "num_public_inputs": stark.num_public_inputs,
                        "permutation_zs": stark.num_permutation_zs(cfg), "fri": "rate_bits=1 cap=4 arity=16 queries=84 pow_bits=16",
                        "proofs_per_rank": args.steps * max(args.concurrency, 1), "proofs_in_flight_per_gpu": max(args.concurrency, 1),
-                       "parallelism": f"independent proofs x{world}, no collective", "host_threads_per_rank": int(os.environ["SBN_HOST_THREADS"])},
+                       "parallelism": f"independent proofs x{world}, no collective", "host_threads_per_rank": int(os.environ["SBN_HOST_THREADS"]),
+                       "switches": prover.describe()},
             "stage_ms": stage_ms,
             "host": {"tracegen_s": t_tracegen, "h2d_s": t_h2d, "trace_bytes": int(trace.nbytes)},
         }
         line.update(rooflines(args, stark, cfg, stage_ms, ms_per_step))
         if batch:
             line["batch_mode"] = batch
+            # BASELINE's unit is throughput: the two 3-proofs-in-flight figures at the top level beside `value` (= ONE proof in flight,
+            # the figure every round has reported)
+            line["throughput_resident_traces_3_in_flight_proofs_per_s"] = batch["resident_traces_proofs_per_s"]
+            line["throughput_instance_lists_3_in_flight_proofs_per_s"] = batch["proofs_per_s"]
         if e2e:
             e2e["ios_to_proof_ms_host_witness"] = (t_tracegen + t_h2d) * 1e3 + ms_per_step / max(args.concurrency, 1) * max(args.concurrency, 1)
             line["end_to_end"] = e2e
@@ -358,6 +375,14 @@ def bench_split(args, S, np, torch, dist, rank, world, barrier, max_over_ranks):
     ios = synthetic_ios_fq12(num_io, args.seed) if args.table == "fq12" else synthetic_ios(num_io, args.seed, args.table)
     native = args.backend == "nccl" and args.transport == "rccl"
     sp = SplitProver(stark, cfg, bits, staged=(args.backend != "nccl"), transport="rccl" if native else "torch")
+    selftest = None
+    if world > 1:
+        # first contact with a multi-GPU node: a pattern exchange over the very transport the proof will use (uneven blocks, the
+        # all-gather form, the host all-gather), checked on the device, BEFORE the first proof -- a wrong byte names the receiving
+        # rank and the block (= sending rank) instead of surfacing as a proof that does not verify
+        t0 = time.perf_counter()
+        sp.selftest()
+        selftest = {"passed": True, "seconds": time.perf_counter() - t0}
     sp.generate_trace(ios)
     proof = None
     for _ in range(args.warmup):
@@ -391,13 +416,57 @@ def bench_split(args, S, np, torch, dist, rank, world, barrier, max_over_ranks):
                 "proof_roofline": {"algorithmic_bytes_per_proof": alg, "achieved_GBps": alg / (ms * 1e-3) / 1e9,
                                    "frac_of_aggregate_hbm_peak": alg / (ms * 1e-3) / 1e9 / (HBM_PEAK_GBS * world)},
                 "stage_ms_rank0": {k: v / steps for k, v in acc.items()},
-                "exchange": {"bytes_sent_per_proof_rank0": exchange_bytes_sent(stark, cfg, bits, world, 0), "exchange_ms_rank0": acc.get("split_exchange_ms", 0.0) / steps},
+                "exchange": {"bytes_sent_per_proof_rank0": exchange_bytes_sent(stark, cfg, bits, world, 0), "exchange_ms_rank0": acc.get("split_exchange_ms", 0.0) / steps,
+                             "transport_selftest": selftest},
                 "all_ranks_same_proof": len(set(digests.values())) == 1}
         emit(line)
     sp.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def dry_run_plan(args):
+    """The per-rank plan of `--gpus N [--batch B | --split]` without touching a GPU: what every rank will own, send and allocate.
+    Library calls used: table shapes and sbn_split_exchange_bytes (host arithmetic) and sbn_settings_check."""
+    import starky_bn254_amd as S
+    from starky_bn254_amd import sharding, split
+    world = max(args.gpus, 1)
+    plan = {"mode": "split" if args.split else ("batch" if args.batch else "default"), "n_gpus": world,
+            "launch": f"python -m torch.distributed.run --nnodes=1 --nproc-per-node {world} --master-addr 127.0.0.1 --master-port P bench.py --gpus {world} ..." if world > 1 else "python bench.py ...",
+            "host_cpus_effective": sharding.effective_cpus(), "host_threads_per_rank": max(1, min(64, sharding.effective_cpus() // world))}
+    try:
+        plan["switches"] = S.api.settings_check()
+    except S.SbnError as e:
+        plan["switches_error"] = str(e)
+    if args.split:
+        num_io = args.num_io or (512 if args.table == "fq12" else NUM_IO)
+        stark = {"g1": S.G1ExpStark, "g2": S.G2ExpStark, "fq12": S.Fq12ExpStark}[args.table](num_io)
+        cfg = stark.config()
+        bits = (512 * num_io).bit_length() - 1
+        C, Z, m = stark.num_columns, stark.num_permutation_zs(cfg), 2 << bits
+        sb, rb = split.exchange_bytes(stark, cfg, bits, world)
+        planes = 2 if world >= 4 else 1
+        plan.update({"table": f"{type(stark).__name__}({num_io})", "degree_bits": bits, "num_columns": C, "permutation_zs": Z, "column_block": 64,
+                     "planes_per_block": planes, "staging_send_bytes_per_rank": sb, "staging_recv_bytes_per_rank": rb,
+                     "merkle_cap_subtrees_per_rank": 16 // world if world <= 16 else 0, "lde_rows_per_rank": m // world,
+                     "message_bytes_per_peer_block_plane": 64 * (m // world) * 8, "xgmi_links_per_gpu": max(world - 1, 0)})
+        ranks = []
+        for r in range(world):
+            tc, zc = split.own_columns(C, world, r), split.own_columns(Z, world, r)
+            sent = split.exchange_bytes_sent(stark, cfg, bits, world, r)
+            ranks.append({"rank": r, "trace_column_blocks": len(range(r, -(-C // 64), world)), "trace_columns": tc, "z_column_blocks": len(range(r, -(-Z // 64), world)),
+                          "z_columns": zc, "bytes_sent_per_proof": sent, "bytes_per_link_per_proof": sent // max(world - 1, 1)})
+        plan["ranks"] = ranks
+    elif args.batch:
+        plan.update({"table": f"G1ExpStark({NUM_IO})", "units": args.batch, "seeds": f"{args.seed}..{args.seed + args.batch - 1}", "proofs_in_flight_per_gpu": 3,
+                     "collectives": "none on the data path (barrier, MAX of the timed region, all-gather of digests)",
+                     "ranks": [{"rank": r, "units": len(sharding.shard_units(args.batch, r, world)), "first_units": sharding.shard_units(args.batch, r, world)[:4]} for r in range(world)]})
+    else:
+        plan.update({"table": f"{'G2' if args.table == 'g2' else 'G1'}ExpStark({NUM_IO})", "proofs_per_rank": args.steps, "scaling": "weak",
+                     "collectives": "none on the data path (barrier, MAX of the timed region)",
+                     "ranks": [{"rank": r, "seed": sharding.unit_seed(args.seed, r), "proofs": args.steps} for r in range(world)]})
+    return plan
 
 
 def digest_of(proof):
@@ -484,11 +553,15 @@ def valu_issue(dom_ms, perms_per_launch):
         m = json.load(open(files[-1]))
         wave_perms_per_simd = perms_per_launch / 64 / 1024      # wave64 permutations of one launch per SIMD (1,024 SIMDs)
         issue_ms = m["issue_us_per_wave_permutation_per_simd"] * wave_perms_per_simd * 1e-3
-        out.update({"issue_floor_ms_per_launch": issue_ms, "frac": issue_ms / dom_ms, "peak_per_s": 1024 / (m["weighted_ns_per_wave_instruction"] * 1e-9),
+        # two fractions: against the MODEL (the stream priced with measured per-class issue costs -- a model, not a bound: a launch can
+        # beat it) and against the CLOCK peak (one wave-instruction per SIMD every 4 cycles at 2.4 GHz: a bound)
+        clock_peak = 1024 * 2.4e9 / 4
+        out.update({"issue_model_ms_per_launch": issue_ms, "frac_of_model": issue_ms / dom_ms, "model_peak_per_s": 1024 / (m["weighted_ns_per_wave_instruction"] * 1e-9),
+                    "clock_peak_per_s": clock_peak, "frac_of_clock_peak": (out["achieved_per_s"] / clock_peak) if out["achieved_per_s"] else None,
                     "model": os.path.relpath(files[-1], ROOT), "rates": m["source"]})
     else:
         peak = 1024 * 2.4e9 / 4
-        out.update({"peak_per_s": peak, "frac": out["achieved_per_s"] / peak if out["achieved_per_s"] else None, "model": "4 cycles at 2.4 GHz (no committed model)"})
+        out.update({"clock_peak_per_s": peak, "frac_of_clock_peak": out["achieved_per_s"] / peak if out["achieved_per_s"] else None, "model": "4 cycles at 2.4 GHz (no committed model)"})
     return out
 
 

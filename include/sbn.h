@@ -94,8 +94,8 @@ typedef struct sbn_config {
   /* Not a StarkConfig field: which plonky2 FRI this library speaks (sbn_fri_variant).  SBN_FRI_TIMES_X = the 0.1.x line
    * the reference pins (plonky2 0.1.3 @ 541e127, Cargo.lock:529-531): fri/oracle.rs `prove_openings` multiplies the final
    * polynomial by X (`final_poly.coeffs.insert(0, ZERO)`, mir-protocol/plonky2 PR #436) and fri/verifier.rs
-   * `fri_combine_initial` returns `sum * subgroup_x`.  SBN_FRI_PLAIN = later upstream versions, which dropped the step
-   * (the quotients are zero-padded at the end).  0 = SBN_FRI_DEFAULT (= SBN_FRI_TIMES_X), so a zero-initialised field
+   * `fri_combine_initial` returns `sum * subgroup_x`.  SBN_FRI_PLAIN = the form without that step (the quotients are
+   * zero-padded at the end), kept selectable.  0 = SBN_FRI_DEFAULT (= SBN_FRI_TIMES_X), so a zero-initialised field
    * selects the default and not the other protocol.  The dependency is un-vendored, so the default is recalled
    * ([DEP-RECALL]); both forms are tested. */
   uint32_t fri_variant;
@@ -108,12 +108,18 @@ typedef struct sbn_proof sbn_proof;   /* host-side proof object (canonical words
 /* Library / device ------------------------------------------------------------------------------ */
 const char* sbn_version(void);
 /* Bumped whenever a struct or a function signature of this header changes (3: sbn_config.fri_variant replaces
- * fri_final_poly_times_x, sbn_comm carries struct_size and stream-ordered callbacks).  Callers compare with SBN_ABI_VERSION. */
-#define SBN_ABI_VERSION 3
+ * fri_final_poly_times_x, sbn_comm carries struct_size and stream-ordered callbacks; 4: sbn_set_thread_device,
+ * sbn_prover_describe, sbn_set_device also selects HIP's current device).  Callers compare with SBN_ABI_VERSION. */
+#define SBN_ABI_VERSION 4
 int sbn_abi_version(void);
 const char* sbn_last_error(void);                    /* thread-local message of the last failure */
 int sbn_device_count(void);
-int sbn_set_device(int device);                      /* device used by subsequently created provers */
+/* Device of the provers and transports the calling thread creates afterwards, and the default of threads that never chose one.
+ * Also makes it HIP's current device of the calling thread (hipSetDevice), so sbn_set_device(r) followed by
+ * sbn_rccl_comm_create puts the staging buffers, the communicator and the prover of rank r on GPU r. */
+int sbn_set_device(int device);
+/* The same for the calling thread ONLY (the process default stays): for rank threads of one process (sbn_local_comm_create). */
+int sbn_set_thread_device(int device);
 void sbn_standard_fast_config(sbn_config* out);      /* StarkConfig::standard_fast_config */
 
 /* Table shape (ExpStarkConstants, src/curves/g1/exp.rs:6-34) ----------------------------------- */
@@ -171,6 +177,17 @@ int sbn_prover_prove(sbn_prover* p, sbn_proof** out);
  * names via sbn_prover_stage_name(i); returns the number of stages written. */
 int sbn_prover_stage_times(const sbn_prover* p, float* ms_out, int cap);
 const char* sbn_prover_stage_name(int i);
+/* Parity hook: the two Jacobian curve chains of every G1ExpStark (E = 1) / G2ExpStark (E = 2) instance as the device witness
+ * generator consumes them ([num_io][257][3][E][4] u64 each, Montgomery form; csrc/bn254w.cuh exp_chains).  form 0 = the library's
+ * choice (eight instances per AVX-512 IFMA register when the CPU has it), 1 = one instance at a time, 2 = IFMA or
+ * SBN_ERR_UNSUPPORTED.  The forms write the same words. */
+int sbn_host_curve_chains(int E, const uint32_t* ios, size_t num_io, uint64_t* ja_out, uint64_t* jb_out, int form);
+/* The SBN_* environment switches this prover was created under, resolved, as one line of key=value pairs (csrc/settings.hpp:
+ * the environment is read once, at creation; experiment switches need SBN_EXPERIMENTAL=1 and are listed under ignored=[...]
+ * otherwise; a value that is not understood makes sbn_prover_create fail with SBN_ERR_BAD_ARG). */
+int sbn_prover_describe(const sbn_prover* p, char* out, size_t cap);
+/* The same check without a prover or a device: SBN_OK and the resolved switches of the calling process, or SBN_ERR_BAD_ARG. */
+int sbn_settings_check(char* out, size_t cap);
 /* Raw device pointer of the loaded trace buffer (for callers that fill it on-device). */
 uint64_t* sbn_prover_trace_device_ptr(sbn_prover* p);
 /* Witness generation ON THE DEVICE, straight into the prover's trace buffer: G1ExpStark / G2ExpStark / Fq12ExpStark / FqExpStark

@@ -55,6 +55,7 @@ extern "C" {
     pub fn sbn_abi_version() -> i32;
     pub fn sbn_last_error() -> *const c_char;
     pub fn sbn_set_device(device: i32) -> i32;
+    pub fn sbn_set_thread_device(device: i32) -> i32;
     pub fn sbn_device_count() -> i32;
     pub fn sbn_air_num_columns(air: *const sbn_air_desc) -> usize;
     pub fn sbn_air_num_public_inputs(air: *const sbn_air_desc) -> usize;
@@ -66,6 +67,8 @@ extern "C" {
     pub fn sbn_prover_prove(p: *mut sbn_prover, out: *mut *mut sbn_proof) -> i32;
     pub fn sbn_prover_stage_times(p: *const sbn_prover, ms_out: *mut f32, cap: i32) -> i32;
     pub fn sbn_prover_stage_name(i: i32) -> *const c_char;
+    pub fn sbn_prover_describe(p: *const sbn_prover, out: *mut c_char, cap: usize) -> i32;
+    pub fn sbn_settings_check(out: *mut c_char, cap: usize) -> i32;
 
     pub fn sbn_batch_prover_create(air: *const sbn_air_desc, cfg: *const sbn_config, degree_bits: u32, inflight: u32, out: *mut *mut sbn_batch_prover) -> i32;
     pub fn sbn_batch_prover_prove_ios(b: *mut sbn_batch_prover, ios: *const u32, ios_words_per_unit: usize, num_io: usize, count: usize, proofs_out: *mut *mut sbn_proof) -> i32;

@@ -27,17 +27,17 @@ _LIB = None
 
 # every symbol include/sbn.h declares
 EXPORTS = [
-    "sbn_version", "sbn_last_error", "sbn_device_count", "sbn_set_device", "sbn_standard_fast_config",
+    "sbn_version", "sbn_last_error", "sbn_device_count", "sbn_set_device", "sbn_set_thread_device", "sbn_standard_fast_config",
     "sbn_air_num_columns", "sbn_air_num_public_inputs", "sbn_air_num_permutation_zs", "sbn_air_num_constraints",
     "sbn_generate_trace_g1_exp", "sbn_generate_trace_g2_exp", "sbn_generate_trace_fq12_exp", "sbn_generate_trace_fq_exp", "sbn_generate_trace_fq12_exp_u64",
     "sbn_generate_trace_g1_op", "sbn_generate_trace_modular", "sbn_generate_trace_fq12_mul", "sbn_generate_trace_lookup", "sbn_generate_trace_flags", "sbn_generate_trace_flags_u64",
     "sbn_prover_create", "sbn_prover_destroy", "sbn_prover_load_trace", "sbn_prover_load_trace_device",
-    "sbn_prover_prove", "sbn_prover_stage_times", "sbn_prover_stage_name", "sbn_prover_trace_device_ptr",
+    "sbn_prover_prove", "sbn_prover_stage_times", "sbn_prover_stage_name", "sbn_prover_describe", "sbn_settings_check", "sbn_prover_trace_device_ptr",
     "sbn_prover_generate_trace", "sbn_prover_read_trace",
     "sbn_batch_prover_create", "sbn_batch_prover_prove_ios", "sbn_batch_prover_destroy",
     "sbn_prove", "sbn_proof_num_words", "sbn_proof_words", "sbn_proof_serialize", "sbn_proof_degree_bits",
     "sbn_proof_free", "sbn_verify", "sbn_commit_values", "sbn_poseidon_permute_batch", "sbn_poseidon_permute_host", "sbn_field_mul_batch",
-    "sbn_eval_constraints_host", "sbn_split_exchange_bytes", "sbn_split_prover_create", "sbn_split_prover_destroy", "sbn_split_prover_generate_trace",
+    "sbn_eval_constraints_host", "sbn_host_curve_chains", "sbn_split_exchange_bytes", "sbn_split_prover_create", "sbn_split_prover_destroy", "sbn_split_prover_generate_trace",
     "sbn_split_prover_load_trace", "sbn_split_prover_prove", "sbn_split_prover_stage_times",
     "sbn_abi_version", "sbn_rccl_unique_id", "sbn_rccl_comm_create", "sbn_rccl_comm_destroy",
     "sbn_local_comm_create", "sbn_local_comm_abort", "sbn_local_comm_destroy", "sbn_comm_selftest",
@@ -127,6 +127,10 @@ def lib():
         L.sbn_poseidon_permute_host.argtypes = [vp, sz, C.c_int]
         L.sbn_field_mul_batch.argtypes = [vp, vp, vp, sz, C.c_int]
         L.sbn_set_device.argtypes = [C.c_int]
+        L.sbn_set_thread_device.argtypes = [C.c_int]
+        L.sbn_host_curve_chains.argtypes = [C.c_int, vp, sz, vp, vp, C.c_int]
+        L.sbn_prover_describe.argtypes = [vp, C.c_char_p, sz]
+        L.sbn_settings_check.argtypes = [C.c_char_p, sz]
         _LIB = L
     return _LIB
 
@@ -458,6 +462,14 @@ def _take_proof(h):
     return Proof(words, db)
 
 
+def settings_check():
+    """The SBN_* switches of this process as a prover created now would resolve them (csrc/settings.hpp), as a dict of strings;
+    raises SbnError(-1) naming a value that is not understood.  Needs no device."""
+    buf = C.create_string_buffer(1024)
+    _check(lib().sbn_settings_check(buf, 1024))
+    return dict(kv.partition("=")[::2] for kv in buf.value.decode().split(" "))
+
+
 class Prover:
     """Device context for one (table, degree_bits): buffers stay allocated across proofs."""
 
@@ -499,6 +511,16 @@ class Prover:
         buf = (C.c_float * 32)()
         k = lib().sbn_prover_stage_times(self._h, buf, 32)
         return {lib().sbn_prover_stage_name(i).decode(): float(buf[i]) for i in range(k)}
+
+    def describe(self):
+        """The SBN_* switches this prover was created under, resolved (csrc/settings.hpp), as a dict of strings."""
+        buf = C.create_string_buffer(1024)
+        _check(lib().sbn_prover_describe(self._h, buf, 1024))
+        out = {}
+        for kv in buf.value.decode().split(" "):
+            k, _, v = kv.partition("=")
+            out[k] = v
+        return out
 
     def close(self):
         if self._h:

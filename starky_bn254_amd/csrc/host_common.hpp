@@ -109,11 +109,17 @@ static inline bool config_supported(const sbn_config* c) {
 static inline u32 fri_times_x(const sbn_config& c) { return c.fri_variant == SBN_FRI_PLAIN ? 0u : 1u; }
 
 // tracegen.hip: Jacobian curve chains of every G1ExpStark instance on host threads (layout: bn254w.cuh g1_chains)
-int tracegen_host_chains(int E, const uint32_t* ios, size_t K, u64* ja, u64* jb);
+int tracegen_host_chains(int E, const uint32_t* ios, size_t K, u64* ja, u64* jb, int form = 0);   // form: tracegen.hip
 // tracegen.hip: square-and-multiply chains of every Fq12ExpStark / Fq12ExpU64Stark instance, standard form, [K][steps+1][12][4] each
 int tracegen_host_chains_fq12(const uint32_t* ios, size_t iow, int steps, size_t K, u64* ca, u64* cb);
 // the same for FqExpStark: [K][257][4] each
 int tracegen_host_chains_fq(const uint32_t* ios, size_t K, u64* ca, u64* cb);
+// tracegen.hip: threads of the host worker pool (the caller's included): SBN_HOST_THREADS, else one per visible CPU (<= 64)
+unsigned tracegen_host_threads();
+// tracegen.hip: the curve chains run eight instances per AVX-512 IFMA register on this CPU (0.15 ms per group of eight)
+bool tracegen_host_chains_vectorized();
+// prover.hip: the device sbn_set_device / sbn_set_thread_device selected for the calling thread (else the process default)
+int current_device();
 
 }  // namespace sbn
 

@@ -7,9 +7,9 @@
 //   * both chains of an instance are walked in Jacobian coordinates (no inversion): bn254w.cuh g1_chains, run on host
 //     threads by default (512 strictly sequential point operations per instance are 0.1% of the arithmetic and
 //     latency-bound on a lane) or by chain_kernel, one lane per instance;
-//   * affine_kernel / lambda_kernel then invert all Z's and all slope denominators at once (the inversions of different
-//     rows are independent once the chain is known): a lane owns eight values and inverts their product (Montgomery's
-//     trick; Fermat, a^(p-2), for the one inversion left);
+//   * affine_lambda_kernel then inverts all Z's and all slope denominators at once (the inversions of different
+//     rows are independent once the chain is known, and the denominators have closed forms in Jacobian coordinates): a lane owns
+//     the eight values of two rows and inverts their product (Montgomery's trick; Fermat, a^(p-2), for the one inversion left);
 //   * gadget_witness_kernel computes the limb columns and the modular-gadget witnesses, one lane per (row, gadget);
 //   * flags / pulse columns are closed forms of the row index;
 //   * range_check_kernel: one workgroup per range-checked column, histogram and prefix counts in LDS, and the
@@ -66,15 +66,6 @@ __device__ __forceinline__ void batch_inverse(Fq (&nrm)[TG_INV_BATCH]) {
   nrm[0] = inv;
 }
 
-// affine storage: coordinate c (x, y) of step t, component q: limb i of instance k at base + aff_off<E>(t, c, q, K) + i*K + k
-template <int E> __device__ __forceinline__ size_t aff_off(int t, int c, int q, size_t K) { return ((size_t)((t * 2 + c) * E + q) * 4) * K; }
-template <int E> __device__ __forceinline__ Co<E> lda(const u64* base, int t, int c, size_t k, size_t K) {
-  Co<E> r; for (int q = 0; q < E; q++) r.c[q] = ldq(base + aff_off<E>(t, c, q, K), k, K); return r;
-}
-template <int E> __device__ __forceinline__ void sta(u64* base, int t, int c, size_t k, size_t K, const Co<E>& v) {
-  for (int q = 0; q < E; q++) stq(base + aff_off<E>(t, c, q, K), k, K, v.c[q]);
-}
-
 // One lane per instance: exp_chains (bn254w.cuh).  512 strictly sequential point operations per lane: the host
 // threads do this faster (prover.hip picks), the kernel keeps the path host-free when asked (SBN_TRACEGEN_DEVICE_CHAIN=1).
 template <int E>
@@ -117,7 +108,7 @@ __global__ void __launch_bounds__(CP_LANES) chain_coop_kernel(const uint32_t* __
   __syncthreads();
   const uint32_t* e = io + 32 * E;
   for (int t = 0;; t++) {
-    if (lane < 6 * E) {                       // the Jacobian coordinates of step t, Montgomery form (affine_kernel reads them)
+    if (lane < 6 * E) {                       // the Jacobian coordinates of step t, Montgomery form (affine_lambda_kernel reads them)
       const int which = lane / (3 * E), cc = (lane % (3 * E)) / E, q = lane % E;
       const Fq v = V[cp.coord[lane]];
       u64* dst = (which ? jb : ja) + jac_at<E>(k, t, cc) + 4 * q;
@@ -141,43 +132,7 @@ __global__ void __launch_bounds__(CP_LANES) chain_coop_kernel(const uint32_t* __
   }
 }
 
-// One lane per TG_INV_BATCH values (which, t, k): affine x = X / Z^2, y = Y / Z^3 (Montgomery form) for t = 0..256 of both chains.
-// Lane L owns the values L, L + NL, L + 2 NL, ... (NL lanes): neighbouring lanes read neighbouring values.
-template <int E>
-__global__ void affine_kernel(const u64* __restrict__ ja, const u64* __restrict__ jb, size_t K, u64* __restrict__ aa, u64* __restrict__ ab, int* __restrict__ err) {
-  const size_t L = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  const size_t per = 257 * K, total = 2 * per, NL = (total + TG_INV_BATCH - 1) / TG_INV_BATCH;
-  if (L >= NL) return;
-  Fq nrm[TG_INV_BATCH];
-  for (int j = 0; j < TG_INV_BATCH; j++) {   // (not unrolled: the eight values sit in scratch memory, which costs nothing next to ~45 multiplies each)
-    const size_t g = L + (size_t)j * NL;
-    nrm[j] = fq_one();
-    if (g < total) {
-      const bool second = g >= per;
-      const size_t h = second ? g - per : g;
-      const Co<E> Z = ldc<E>((second ? jb : ja) + jac_at<E>(h % K, (int)(h / K), 2));
-      if (czero<E>(Z)) atomicOr(err, TG_ERR_DEGENERATE); else nrm[j] = cnorm(Z);   // (a zero would poison the batch; the proof is refused anyway)
-    }
-  }
-  batch_inverse(nrm);
-  for (int j = 0; j < TG_INV_BATCH; j++) {   // (not unrolled: the eight values sit in scratch memory, which costs nothing next to ~45 multiplies each)
-    const size_t g = L + (size_t)j * NL;
-    if (g >= total) continue;
-    const bool second = g >= per;
-    const size_t h = second ? g - per : g;
-    const int t = (int)(h / K); const size_t k = h % K;
-    const u64* jj = second ? jb : ja; u64* o = second ? ab : aa;
-    const Co<E> X = ldc<E>(jj + jac_at<E>(k, t, 0)), Y = ldc<E>(jj + jac_at<E>(k, t, 1)), Z = ldc<E>(jj + jac_at<E>(k, t, 2));
-    const Co<E> zi = cinv_from_norm(Z, nrm[j]), zi2 = cmul(zi, zi);
-    sta<E>(o, t, 0, k, K, cmul(X, zi2));
-    sta<E>(o, t, 1, k, K, cmul(Y, cmul(zi2, zi)));
-  }
-}
-
-// One lane per TG_INV_BATCH rows (row = L + j NL): the standard-form values ax ay bx by lam nx ny of the row
-// (sv[((v*E + q)*4 + limb) * n + row]) and its operation (0 none, 1 add, 2 double).  Row r of instance k: a = A[r>>1]; even
-// rows: b = B[r>>1], add if bit; odd rows: b = B[(r>>1)+1], double.  Also writes the instance output B[256] (u32 limbs) for
-// the public inputs.  The slope denominators of a lane's rows are inverted as one batch.
+// Row r of instance k: a = A[r>>1]; even rows: b = B[r>>1], add if bit; odd rows: b = B[(r>>1)+1], double.
 template <int E>
 struct LambdaRow {
   size_t k; int t, tb, op; bool dbl;
@@ -188,42 +143,61 @@ struct LambdaRow {
     tb = dbl ? t + 1 : t;
   }
 };
+// One lane per TG_ROWS rows (row = L + j NL), straight from the JACOBIAN chains: the standard-form values ax ay bx by lam nx ny of
+// the row (sv[((v*E + q)*4 + limb) * n + row]) and its operation (0 none, 1 add, 2 double); also the instance output B[256] (u32
+// limbs) for the public inputs.  Rounds 2-3 ran two kernels, each waiting for one Fermat chain (~350 dependent products, 0.44 +
+// 0.49 ms): affine_kernel inverted every Z, lambda_kernel then the slope denominators.  The denominators have closed forms in
+// Jacobian coordinates -- x2 - x1 = (X2 Z1^2 - X1 Z2^2) / (Z1^2 Z2^2), 2 y1 = 2 Y1 / Z1^3 -- so ONE batch per lane inverts Z1, Z2,
+// Z_next and D = X2 Z1^2 - X1 Z2^2 (or 2 Y1) of its rows together (Montgomery's trick, one Fermat chain), and
+// lambda = (y2 - y1) Z1^2 Z2^2 / D  (or 3 x1^2 Z1^3 / (2 Y1)).  Field elements are exact, so every word written equals the two-kernel
+// path's.  D = 0 iff the affine denominator is 0 (the Z's are non-zero): the same instances are refused.
+static constexpr int TG_ROWS = TG_INV_BATCH / 4;
 template <int E>
-__global__ void lambda_kernel(const uint32_t* __restrict__ ios, size_t K, const u64* __restrict__ aa, const u64* __restrict__ ab, size_t n,
-                              u64* __restrict__ sv, unsigned char* __restrict__ row_op, u64* __restrict__ pi_out, int* __restrict__ err) {
+__global__ void affine_lambda_kernel(const uint32_t* __restrict__ ios, size_t K, const u64* __restrict__ ja, const u64* __restrict__ jb, size_t n,
+                                     u64* __restrict__ sv, unsigned char* __restrict__ row_op, u64* __restrict__ pi_out, int* __restrict__ err) {
   const size_t L = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  const size_t NL = (n + TG_INV_BATCH - 1) / TG_INV_BATCH;
+  const size_t NL = (n + TG_ROWS - 1) / TG_ROWS;
   if (L >= NL) return;
   Fq nrm[TG_INV_BATCH];
-  for (int j = 0; j < TG_INV_BATCH; j++) {   // (not unrolled: the eight values sit in scratch memory, which costs nothing next to ~45 multiplies each)
+  for (int j = 0; j < TG_ROWS; j++) {
     const size_t row = L + (size_t)j * NL;
-    nrm[j] = fq_one();
-    if (row < n) {
-      const LambdaRow<E> R(ios, row);
-      if (R.op) {
-        Co<E> den;
-        if (R.dbl) { const Co<E> y = lda<E>(aa, R.t, 1, R.k, K); den = cadd(y, y); }
-        else den = csub(lda<E>(ab, R.tb, 0, R.k, K), lda<E>(aa, R.t, 0, R.k, K));
-        if (czero<E>(den)) atomicOr(err, TG_ERR_DEGENERATE); else nrm[j] = cnorm(den);
-      }
-    }
+    for (int i = 0; i < 4; i++) nrm[4 * j + i] = fq_one();
+    if (row >= n) continue;
+    const LambdaRow<E> R(ios, row);
+    const Co<E> Z1 = ldc<E>(ja + jac_at<E>(R.k, R.t, 2)), Z2 = ldc<E>(jb + jac_at<E>(R.k, R.tb, 2));
+    if (czero<E>(Z1) || czero<E>(Z2)) { atomicOr(err, TG_ERR_DEGENERATE); continue; }   // (a zero would poison the batch; the proof is refused anyway)
+    nrm[4 * j] = cnorm(Z1); nrm[4 * j + 1] = cnorm(Z2);
+    if (!R.op) continue;
+    const Co<E> Zn = ldc<E>((R.dbl ? ja : jb) + jac_at<E>(R.k, R.t + 1, 2));
+    Co<E> D;
+    if (R.dbl) { const Co<E> Y1 = ldc<E>(ja + jac_at<E>(R.k, R.t, 1)); D = cadd(Y1, Y1); }
+    else D = csub(cmul(ldc<E>(jb + jac_at<E>(R.k, R.tb, 0)), cmul(Z1, Z1)), cmul(ldc<E>(ja + jac_at<E>(R.k, R.t, 0)), cmul(Z2, Z2)));
+    if (czero<E>(Zn) || czero<E>(D)) { atomicOr(err, TG_ERR_DEGENERATE); continue; }
+    nrm[4 * j + 2] = cnorm(Zn); nrm[4 * j + 3] = cnorm(D);
   }
   batch_inverse(nrm);
-  for (int j = 0; j < TG_INV_BATCH; j++) {   // (not unrolled: the eight values sit in scratch memory, which costs nothing next to ~45 multiplies each)
+  for (int j = 0; j < TG_ROWS; j++) {
     const size_t row = L + (size_t)j * NL;
     if (row >= n) continue;
     const LambdaRow<E> R(ios, row);
     const size_t k = R.k; const int t = R.t, op = R.op; const bool dbl = R.dbl;
+    const Co<E> X1 = ldc<E>(ja + jac_at<E>(k, t, 0)), Y1 = ldc<E>(ja + jac_at<E>(k, t, 1)), Z1 = ldc<E>(ja + jac_at<E>(k, t, 2));
+    const Co<E> X2 = ldc<E>(jb + jac_at<E>(k, R.tb, 0)), Y2 = ldc<E>(jb + jac_at<E>(k, R.tb, 1)), Z2 = ldc<E>(jb + jac_at<E>(k, R.tb, 2));
     Co<E> v[7];
-    v[0] = lda<E>(aa, t, 0, k, K); v[1] = lda<E>(aa, t, 1, k, K);
-    v[2] = lda<E>(ab, R.tb, 0, k, K); v[3] = lda<E>(ab, R.tb, 1, k, K);
+    const Co<E> zi1 = cinv_from_norm(Z1, nrm[4 * j]), zi1s = cmul(zi1, zi1);
+    const Co<E> zi2 = cinv_from_norm(Z2, nrm[4 * j + 1]), zi2s = cmul(zi2, zi2);
+    v[0] = cmul(X1, zi1s); v[1] = cmul(Y1, cmul(zi1s, zi1));
+    v[2] = cmul(X2, zi2s); v[3] = cmul(Y2, cmul(zi2s, zi2));
     if (op) {
-      Co<E> den, num;
-      if (dbl) { den = cadd(v[1], v[1]); Co<E> x2 = cmul(v[0], v[0]); num = cadd(cadd(x2, x2), x2); }
-      else { den = csub(v[2], v[0]); num = csub(v[3], v[1]); }
-      v[4] = cmul(num, cinv_from_norm(den, nrm[j]));
-      const u64* nsrc = dbl ? aa : ab;
-      v[5] = lda<E>(nsrc, t + 1, 0, k, K); v[6] = lda<E>(nsrc, t + 1, 1, k, K);
+      const Co<E> Z1s = cmul(Z1, Z1);
+      Co<E> D, num, scale;
+      if (dbl) { D = cadd(Y1, Y1); const Co<E> x2 = cmul(v[0], v[0]); num = cadd(cadd(x2, x2), x2); scale = cmul(Z1s, Z1); }
+      else { const Co<E> Z2s = cmul(Z2, Z2); D = csub(cmul(X2, Z1s), cmul(X1, Z2s)); num = csub(v[3], v[1]); scale = cmul(Z1s, Z2s); }
+      v[4] = cmul(cmul(num, scale), cinv_from_norm(D, nrm[4 * j + 3]));
+      const u64* nsrc = dbl ? ja : jb;
+      const Co<E> Xn = ldc<E>(nsrc + jac_at<E>(k, t + 1, 0)), Yn = ldc<E>(nsrc + jac_at<E>(k, t + 1, 1)), Zn = ldc<E>(nsrc + jac_at<E>(k, t + 1, 2));
+      const Co<E> zin = cinv_from_norm(Zn, nrm[4 * j + 2]), zins = cmul(zin, zin);
+      v[5] = cmul(Xn, zins); v[6] = cmul(Yn, cmul(zins, zin));
     }
     for (int w = 0; w < (op ? 7 : 4); w++)
       for (int q = 0; q < E; q++) {
@@ -263,7 +237,7 @@ __global__ void __launch_bounds__(256) gadget_witness_kernel(const u64* __restri
   const size_t row = tid % n;
   const int g = (int)(tid / n), blk = g / E, q = g % E;
   const int op = row_op[row];
-  // sv (lambda_kernel): value w in {ax ay bx by lam nx ny}, component c, 64-bit word i at ((w * E + c) * 4 + i) * n + row
+  // sv (affine_lambda_kernel): value w in {ax ay bx by lam nx ny}, component c, 64-bit word i at ((w * E + c) * 4 + i) * n + row
   auto ld = [&](int w, int c, u64* out4) { for (int i = 0; i < 4; i++) out4[i] = sv[(size_t)((w * E + c) * 4 + i) * n + row]; };
   auto ldl = [&](int w, int c, int64_t* out16) { u64 t4[4]; ld(w, c, t4); limbs16(t4, out16); };
   u64* gc = trace + (size_t)gadget_col * n + row;
@@ -660,6 +634,14 @@ __global__ void __launch_bounds__(256) split_range_check_kernel(u64* __restrict_
 //   if there is no such x it is still pooled at the end, at height h = S[u] - min(0, min S), and fills the deferred
 //   slot of rank h-1, which is slot v + h where v is the first value with S[v] < -(h-1) (or a repeat of 65535).
 // Every lane owns 64 consecutive values; "first x >= from with S[x] < target" walks a two-level min tree (32 / 1024).
+// tools/microbench/range_check_phases.hip defines SBN_RC_PROFILE: workgroup 0 then stamps the constant 100 MHz clock at the phase
+// boundaries of range_check_kernel (a barrier in front of each stamp); the library never defines it.
+#ifdef SBN_RC_PROFILE
+__device__ unsigned long long g_rc_prof[16];
+#define RC_MARK(k) do { __syncthreads(); if (blockIdx.x == 0 && threadIdx.x == 0) g_rc_prof[k] = wall_clock64(); } while (0)
+#else
+#define RC_MARK(k) do { } while (0)
+#endif
 static constexpr int RC_THREADS = 1024;
 static constexpr int RC_HEAVY_MAX = 1024;  // values with more than 64 (BIG: 256) occurrences are expanded by the whole block
 static constexpr size_t RC_LDS_BYTES = 65536 * 2 + 2 * 2048 * 4 + 64 * 4 + 64 * 4 + RC_HEAVY_MAX * 8;
@@ -682,7 +664,7 @@ __global__ void range_count_kernel(const u64* __restrict__ trace, size_t n, int 
 // the table and are deferred, and table copies left over when the inputs end are appended to the pool (lookup.rs:100-101).
 template <bool BIG>
 __global__ void __launch_bounds__(RC_THREADS) range_check_kernel(u64* __restrict__ trace, size_t n, int first_col, int start_lookups, int* __restrict__ err,
-                                                                 const unsigned int* __restrict__ cnt) {
+                                                                 const unsigned int* __restrict__ cnt, int old_form) {
   extern __shared__ unsigned int lds[];
   unsigned int* t32 = lds;                                                  // 32768 words = 65536 u16 counters, then T (mod 2^16)
   const unsigned short* t16 = reinterpret_cast<const unsigned short*>(lds);
@@ -699,17 +681,26 @@ __global__ void __launch_bounds__(RC_THREADS) range_check_kernel(u64* __restrict
   const int N = (int)n, KT = N - 65535;             // rows; copies of 65535 in the table
   constexpr int HEAVY = BIG ? 256 : 64;
 
+  RC_MARK(0);
   for (int i = tid; i < 32768; i += RC_THREADS) t32[i] = 0;
   if (tid < 64) misc[tid] = tid >= 40 && tid < 44 ? 65536u : 0u;
   __syncthreads();
+  RC_MARK(1);
   if constexpr (!BIG) {
     const u64 v0 = col[0];
     bool differs = false, bad = false; unsigned vm = 0;
-    for (size_t i = tid; i < n; i += RC_THREADS) {
-      const u64 v = col[i];
-      if (v >= 65536) { bad = true; continue; }
-      differs |= v != v0; vm = vm > (unsigned)v ? vm : (unsigned)v;
-      atomicAdd(&t32[v >> 1], 1u << (16 * (v & 1)));
+    for (size_t i0 = tid; i0 < n; i0 += 8 * RC_THREADS) {   // eight loads in flight, then their eight LDS atomics
+      u64 vv[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) { const size_t i = i0 + (size_t)k * RC_THREADS; vv[k] = i < n ? col[i] : v0; }
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const u64 v = vv[k];
+        if (i0 + (size_t)k * RC_THREADS >= n) continue;
+        if (v >= 65536) { bad = true; continue; }
+        differs |= v != v0; vm = vm > (unsigned)v ? vm : (unsigned)v;
+        atomicAdd(&t32[v >> 1], 1u << (16 * (v & 1)));
+      }
     }
     if (bad) atomicOr(err, TG_ERR_RANGE);
     if (differs) misc[32] = 1;
@@ -720,6 +711,7 @@ __global__ void __launch_bounds__(RC_THREADS) range_check_kernel(u64* __restrict
     __syncthreads();
   }
 
+  RC_MARK(2);
   // counts -> inclusive prefix counts T (mod 2^16), in place
   if constexpr (!BIG) {
     uint4* p = reinterpret_cast<uint4*>(t32 + 32 * tid);
@@ -758,15 +750,52 @@ __global__ void __launch_bounds__(RC_THREADS) range_check_kernel(u64* __restrict
     }
   }
   __syncthreads();
+  RC_MARK(3);
   const int vmax = (int)misc[33];
   const int thr1 = (int)misc[40], thr2 = (int)misc[41], thr3 = (int)misc[42];
   auto Thi = [&](int v) __attribute__((always_inline)) -> int { return BIG ? ((v >= thr1) + (v >= thr2) + (v >= thr3)) << 16 : 0; };
   auto T = [&](int v) __attribute__((always_inline)) -> int { return v < 0 ? 0 : (v >= vmax ? N : (int)t16[v] + Thi(v)); };
   auto S = [&](int v) __attribute__((always_inline)) -> int { return v >= 65535 ? INF : v + 1 - T(v); };
-  for (int b = 0; b < 2; b++) {
-    int m = INF;
-    for (int j = 0; j < 32; j++) { int s = S(tid * 64 + b * 32 + j); m = s < m ? s : m; }
-    L1[2 * tid + b] = m;
+  unsigned long long pool = 0;   // two-pass form: the unused table values of this lane's segment that nothing inside the segment took
+  int s_end = 0;                 // pool height after the segment's last value below 65535
+  if (old_form) {
+    for (int b = 0; b < 2; b++) {
+      int m = INF;
+      for (int j = 0; j < 32; j++) { int s = S(tid * 64 + b * 32 + j); m = s < m ? s : m; }
+      L1[2 * tid + b] = m;
+    }
+  } else {
+    // Lane l owns the values 64 l .. 64 l + 63: their 64 prefix counts come out of LDS once (eight 128-bit reads) and serve both the
+    // two minima of the search tree and the LIFO pool INSIDE the segment, which is a bit mask: an absent value sets its bit (push), the
+    // k-th repeat of a present value takes the highest set bit (pop: slot tprev + k, the same slot the search x - S(u) + 1 of the
+    // one-pass form finds, since S(u) = S(x - 1) - k + 1 for the k-th pop at x).  What is still set at the end goes through the
+    // search tree below; the one-pass form searched for EVERY absent value, a wave waiting for the longest of its 64 searches in
+    // every iteration (2.2e8 wave-instructions per launch, as many as a sponge launch: profiles/r3_v10_pmc_summary.json).
+    const uint4* p = reinterpret_cast<const uint4*>(t32 + 32 * tid);
+    unsigned cw[32];
+#pragma unroll
+    for (int j = 0; j < 8; j++) { const uint4 q = p[j]; cw[4 * j] = q.x; cw[4 * j + 1] = q.y; cw[4 * j + 2] = q.z; cw[4 * j + 3] = q.w; }
+    int tprev = T(tid * 64 - 1), m0 = INF, m1 = INF;
+#pragma unroll
+    for (int j = 0; j < 64; j++) {
+      const int v = tid * 64 + j;
+      const int tv = v >= vmax ? N : (int)((cw[j >> 1] >> (16 * (j & 1))) & 0xffff) + Thi(v);
+      if (v < 65535) {
+        const int sv = v + 1 - tv;
+        if (j < 32) m0 = sv < m0 ? sv : m0; else m1 = sv < m1 ? sv : m1;
+        s_end = sv;
+        const int c = tv - tprev;
+        if (c == 0) pool |= 1ull << j;
+        else
+          for (int k = 1; k < c && pool; k++) {
+            const int u = 63 - __builtin_clzll(pool);
+            pool &= ~(1ull << u);
+            perm_out[tprev + k] = (u64)(tid * 64 + u);
+          }
+      }
+      tprev = tv;
+    }
+    L1[2 * tid] = m0; L1[2 * tid + 1] = m1;
   }
   __syncthreads();
   if (tid < 64) { int m = INF; for (int j = 0; j < 32; j++) { int s = L1[tid * 32 + j]; m = s < m ? s : m; } L2[tid] = m; }
@@ -782,6 +811,7 @@ __global__ void __launch_bounds__(RC_THREADS) range_check_kernel(u64* __restrict
   }
   __syncthreads();
 
+  RC_MARK(4);
   // first x in [from, from | 31] with S(x) < target, or -1 (8 prefix counts per LDS read)
   auto scan32 = [&](int from, int target) __attribute__((always_inline)) -> int {
     const int hi = from | 31;
@@ -808,7 +838,9 @@ __global__ void __launch_bounds__(RC_THREADS) range_check_kernel(u64* __restrict
     }
     return -1;
   };
-  // first x in [from, 65534] with S(x) < target, or -1
+  // first x in [from, 65534] with S(x) < target, or -1.  (Measured and dropped, round 4: issuing every level's LDS reads together
+  // and scanning registers -- 0.48 -> 0.65 ms per launch in tools/microbench/range_check_phases.hip: with 16 waves per CU the walk
+  // is bound by the instructions of its longest searches, not by LDS latency.)
   auto firstbelow = [&](int from, int target) __attribute__((always_inline)) -> int {
     if (from > 65534) return -1;
     const int x = scan32(from, target);
@@ -829,24 +861,72 @@ __global__ void __launch_bounds__(RC_THREADS) range_check_kernel(u64* __restrict
     perm_out[slot] = (u64)val;
   };
 
-  int tprev = T(tid * 64 - 1);
-  for (int j = 0; j < 64; j++) {
-    const int v = tid * 64 + j;
-    if (v == 65535) break;                           // handled by the whole block below
-    const int tv = T(v), c = tv - tprev;
-    if (c > 0) {
-      perm_out[tprev] = (u64)v;  // first occurrence takes its own table entry
-      if (c <= HEAVY) { for (int d = 0; d < c; d++) sorted_out[tprev + d] = (u64)v; }
-      else { const unsigned h = atomicAdd(&misc[34], 1u); heavy[h] = make_uint2((unsigned)v, (unsigned)tprev); }
-    } else {
-      const int s = v + 1 - tv;
-      const int x = firstbelow(v + 1, s);
-      if (x >= 0) perm_out[x - s + 1] = (u64)v;
-      else assign_deferred(s - mfin - 1, v);
+  if (old_form) {   // round 3 (SBN_RANGE_CHECK=1, A/B): one pass, lane l owns the values 64 l .. 64 l + 63, every unused table value searches its slot
+    int tprev = T(tid * 64 - 1);
+    for (int j = 0; j < 64; j++) {
+      const int v = tid * 64 + j;
+      if (v == 65535) break;                           // handled by the whole block below
+      const int tv = T(v), c = tv - tprev;
+      if (c > 0) {
+        perm_out[tprev] = (u64)v;  // first occurrence takes its own table entry
+        if (c <= HEAVY) { for (int d = 0; d < c; d++) sorted_out[tprev + d] = (u64)v; }
+        else { const unsigned h = atomicAdd(&misc[34], 1u); heavy[h] = make_uint2((unsigned)v, (unsigned)tprev); }
+      } else {
+        const int s = v + 1 - tv;
+        const int x = firstbelow(v + 1, s);
+        if (x >= 0) perm_out[x - s + 1] = (u64)v;
+        else assign_deferred(s - mfin - 1, v);
+      }
+      tprev = tv;
     }
-    tprev = tv;
+  } else {
+    // The pushes left in the segment's pool, top first: their levels are s_end, s_end - 1, ... (nothing after a left-over push
+    // drops below it inside the segment), so ONE forward walk serves them all -- the search for level s - 1 continues at the
+    // value that popped level s -- and it starts at the next segment.  Once a level is never undercut, neither are the lower ones:
+    // those pushes stay in the pool to the end and fill the deferred slots.
+    {
+      int from = tid * 64 + 64, s = s_end;
+      while (pool) {
+        const int u = 63 - __builtin_clzll(pool);
+        const int x = firstbelow(from, s);
+        if (x < 0) break;
+        pool &= ~(1ull << u);
+        perm_out[x - s + 1] = (u64)(tid * 64 + u);
+        from = x; s--;
+      }
+      // never popped: BOTTOM first -- ranks ascend, so the value at which the pool first runs `rank + 1` short (the deferred slot of
+      // that rank sits right behind it) moves forward too, and this walk also continues where the last one ended
+      if (pool) {
+        int lvl = s - __builtin_popcountll(pool) + 1, dfrom = 0;
+        while (pool) {
+          const int u = __builtin_ctzll(pool);
+          pool &= pool - 1;
+          const int rank = lvl - mfin - 1;
+          int slot;
+          if (rank < -mfin) { const int vv = firstbelow(dfrom, -rank); slot = vv + rank + 1; dfrom = vv; }
+          else slot = t_last + KT + (rank + mfin);
+          perm_out[slot] = (u64)(tid * 64 + u);
+          lvl++;
+        }
+      }
+    }
+    RC_MARK(5);
+    // Lane l <-> values l, l + 1024, ...: neighbouring lanes write neighbouring slots (the one-pass form stored with a stride of
+    // ~512 bytes between lanes: 3.2 x the algorithmic write traffic).  The sorted copy and the table entry of every first occurrence.
+    for (int j = 0; j < 64; j++) {
+      const int v = j * RC_THREADS + tid;
+      if (v == 65535) break;                           // handled by the whole block below
+      const int tp = T(v - 1), c = T(v) - tp;
+      if (c > 0) {
+        perm_out[tp] = (u64)v;
+        if (c <= HEAVY) { for (int d = 0; d < c; d++) sorted_out[tp + d] = (u64)v; }
+        else { const unsigned h = atomicAdd(&misc[34], 1u); heavy[h] = make_uint2((unsigned)v, (unsigned)tp); }
+      }
+    }
+    RC_MARK(6);
   }
   __syncthreads();
+  RC_MARK(7);
   const unsigned nheavy = misc[34];
   for (unsigned h = 0; h < nheavy; h++) {
     const int v = (int)heavy[h].x, st = (int)heavy[h].y, c = T(v) - st;
@@ -860,6 +940,7 @@ __global__ void __launch_bounds__(RC_THREADS) range_check_kernel(u64* __restrict
     const int pooled = S(65534) - mfin;              // pool height after the values below 65535 = rank of the first left-over 65535
     for (int r = tid; r < KT - c65; r += RC_THREADS) assign_deferred(pooled + r, 65535);
   }
+  RC_MARK(8);
 }
 
 }  // namespace tg

@@ -3,6 +3,7 @@
 // owns only the Fiat-Shamir transcript and proof assembly; every polynomial / hashing / constraint
 // stage runs in the kernels of kernels.cuh on one HIP stream.
 #include "host_common.hpp"
+#include "settings.hpp"
 #include "kernels.cuh"
 #include "kernels_tracegen.cuh"
 #include <algorithm>
@@ -23,11 +24,14 @@ namespace sbn { thread_local std::string g_last_error; }
   } while (0)
 
 // sbn_set_device: the device of the provers created afterwards by the calling thread, and the default of threads that never
-// call it (the ranks of a local split group are threads with one device each)
+// chose one; sbn_set_thread_device: the calling thread only (the ranks of a local split group are threads with one device each:
+// they must not move the process default under the main thread).  Both also make it HIP's current device of the calling thread,
+// so that a plain-C caller's next HIP-level step (sbn_rccl_comm_create allocates its staging buffers) lands on the same GPU.
 static std::atomic<int> g_default_device{0};
 static thread_local int t_device = -1;
 static inline int cur_device() { return t_device >= 0 ? t_device : g_default_device.load(); }
 #define g_device (cur_device())
+namespace sbn { int current_device() { return cur_device(); } }   // transport.hip
 
 // Stage k spans [ev[k], ev[k+1]) on the prover's main stream.  The commit stages overlap NTT (main
 // stream) with sponge absorption (hash stream); the absorption kernels are additionally timed one by
@@ -130,6 +134,8 @@ struct sbn_prover {
   hipStream_t nstream = nullptr;             // second transform stream (2^19 LDE rows and up): the LDE of chunk k beside the inverse transform of chunk k+1
   hipEvent_t intt_done[MAX_CHUNKS];          // main -> second transform stream: the coefficients of chunk k are complete
   bool ntt_two_streams = false;
+  Settings set;                              // the SBN_* switches this prover was created under (settings.hpp)
+  int chain_mode = 0;                        // curve witness: 0 host pool, 1 one lane per instance, 2 one wave per instance
   hipEvent_t chunk_ready[MAX_CHUNKS];        // main -> hash: LDE chunk k is complete
   hipEvent_t abs_ev[2 * MAX_CHUNKS];         // hash stream: before/after each absorb launch
   hipEvent_t hash_done;                      // hash -> main
@@ -293,7 +299,7 @@ static int tree_build_inner(sbn_prover* P, DevTree& t, hipStream_t st) {
   // Round 3: the narrow levels (<= 8192 parents) run FIVE levels per launch -- a workgroup owns 32 consecutive nodes and hashes its
   // own 16 -> 8 -> 4 -> 2 -> 1 parents through LDS (merkle_subtree_kernel, 16 lanes per permutation), so a 2^17-leaf tree takes
   // 3 + 2 launches instead of 3 + 10 and the dependent chain loses eight launch gaps (SBN_MERKLE_FUSE=0: one launch per level, A/B).
-  static const bool fuse = [] { const char* e = getenv("SBN_MERKLE_FUSE"); return !(e && e[0] == '0'); }();
+  const bool fuse = P->set.merkle_fuse;
   u32 l0 = 0;
   while (l0 < t.nlevels) {
     const size_t parents = t.nleaf >> (l0 + 1);
@@ -380,24 +386,31 @@ static int commit_pipeline(sbn_prover* P, const u64* vals, u64* coef, u64* lde, 
 // receive that never completes, and hipStreamSynchronize would hang the whole job; polling returns hipErrorNotReady after
 // SBN_COMM_TIMEOUT_S seconds (default 600), prove() fails with SBN_ERR_HIP and the caller can tear the job down.
 static thread_local double t_wait_deadline_s = 0;   // 0: plain runtime waits
+// (the ranks of a local group are threads that may outnumber the CPUs of the box: spin briefly, then sleep between polls)
+static inline void poll_backoff(unsigned spins) {
+  if (spins < 2000) std::this_thread::yield();
+  else std::this_thread::sleep_for(std::chrono::microseconds(spins < 20000 ? 20 : 200));
+}
 static inline hipError_t stream_wait(hipStream_t st) {
   if (t_wait_deadline_s <= 0) return hipStreamSynchronize(st);
   const auto t0 = std::chrono::steady_clock::now();
+  unsigned spins = 0;
   for (;;) {
     const hipError_t e = hipStreamQuery(st);
     if (e != hipErrorNotReady) return e;
     if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > t_wait_deadline_s) return hipErrorNotReady;
-    std::this_thread::yield();
+    poll_backoff(++spins);
   }
 }
 static inline hipError_t event_wait(hipEvent_t ev) {
   if (t_wait_deadline_s <= 0) return hipEventSynchronize(ev);
   const auto t0 = std::chrono::steady_clock::now();
+  unsigned spins = 0;
   for (;;) {
     const hipError_t e = hipEventQuery(ev);
     if (e != hipErrorNotReady) return e;
     if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > t_wait_deadline_s) return hipErrorNotReady;
-    std::this_thread::yield();
+    poll_backoff(++spins);
   }
 }
 // ---- oversized-trace split: exchange helpers ------------------------------------------------------------------------
@@ -596,15 +609,20 @@ static int create_ctx(const sbn_air_desc* air, const sbn_config* cfg, uint32_t d
   // sponge out of the 256 MiB Infinity Cache, and 64 columns of 2^19 rows are 268 MB (Fq12ExpStark(512): 0.708 -> 0.675 s,
   // profiles/r3_v2_fq12_chunk.txt).
   P->ntt_chunk = P->lde_log >= 19 ? 48 : 64;
-  if (const char* ce = getenv("SBN_NTT_CHUNK")) {
-    const long v = atol(ce);
-    if (v < 8 || v > 256 || (v % 8) != 0) { sbn_prover_destroy(P); return fail(SBN_ERR_BAD_ARG, "SBN_NTT_CHUNK must be a multiple of 8 between 8 and 256"); }
-    P->ntt_chunk = (size_t)v;
+  {
+    std::string serr;
+    if (!P->set.load(serr)) { sbn_prover_destroy(P); return fail(SBN_ERR_BAD_ARG, "%s", serr.c_str()); }
   }
-  { const char* fe = getenv("SBN_FAST_NTT"); P->fast_ntt = !(fe && fe[0] == '0'); }
-  { const char* xe = getenv("SBN_NTT_XCD"); P->ntt_xcd = !(xe && xe[0] == '0'); }
-  { const char* ue = getenv("SBN_NTT_FUSED"); P->ntt_fused = P->fast_ntt && (degree_bits == 16 || degree_bits == 17) && !(ue && ue[0] == '0'); }   // =0: four separate passes (A/B)
-  if (const char* se = getenv("SBN_NTT_SUB")) { const long v = atol(se); if (v >= 8 && v <= 256 && v % 8 == 0) P->ntt_sub = (size_t)v; }
+  const Settings& set = P->set;
+  if (set.ntt_chunk) P->ntt_chunk = (size_t)set.ntt_chunk;
+  P->fast_ntt = set.fast_ntt; P->ntt_xcd = set.ntt_xcd;
+  P->ntt_fused = P->fast_ntt && (degree_bits == 16 || degree_bits == 17) && set.ntt_fused;   // SBN_NTT_FUSED=0: four separate passes (A/B)
+  P->ntt_sub = (size_t)set.ntt_sub;
+  // curve chains of the device witness: the host pool when the CPU has AVX-512 IFMA (eight instances per register: 128 instances
+  // are 16 tasks of ~0.15 ms, chains_ifma.hpp) or the pool has the threads for the scalar form (2.2 ms on 16), else one wave per
+  // instance on the device (5.2 ms whatever the host share: an 8-rank node may leave a rank two CPUs, where the scalar host chains
+  // take ~18 ms)
+  P->chain_mode = set.device_chain >= 0 ? set.device_chain : ((tracegen_host_chains_vectorized() || tracegen_host_threads() >= 8) ? 0 : 2);
   acc(ntt_fast_setup());
   hipc(hipStreamCreate(&P->stream), "hipStreamCreate");
   hipc(hipStreamCreate(&P->hstream), "hipStreamCreate");
@@ -612,7 +630,7 @@ static int create_ctx(const sbn_air_desc* air, const sbn_config* cfg, uint32_t d
   // r3_v8_fq12_512_kernel_stats.csv: five passes of 410 us per chunk beside a 1.19 ms sponge launch, 1.63 ms of VALU work in a 2.05 ms
   // period): the LDE passes of chunk k then run on a second stream beside the inverse passes of chunk k+1 (SBN_NTT_STREAMS=1: one
   // stream, =2: two streams at any size -- at 2^16 rows, where the stage IS at its VALU bound, this was measured slower in round 2).
-  { const char* ne = getenv("SBN_NTT_STREAMS"); P->ntt_two_streams = ne ? ne[0] == '2' : P->lde_log >= 19; }
+  P->ntt_two_streams = set.ntt_streams ? set.ntt_streams == 2 : P->lde_log >= 19;
   if (P->ntt_two_streams) {
     hipc(hipStreamCreate(&P->nstream), "hipStreamCreate");
     for (auto& e : P->intt_done) hipc(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
@@ -632,13 +650,21 @@ static int create_ctx(const sbn_air_desc* air, const sbn_config* cfg, uint32_t d
     u32 lr = 0; while ((1u << lr) < R) lr++;
     uint64_t sb = 0, rb = 0; size_t sw = 0, slotw = 0;
     if (comm->struct_size != sizeof(sbn_comm)) { sbn_prover_destroy(P); return fail(SBN_ERR_BAD_ARG, "sbn_comm.struct_size does not match this library (ABI %d)", SBN_ABI_VERSION); }
-    if (!getenv("SBN_NTT_CHUNK")) P->ntt_chunk = SPLIT_BLOCK;   // (the size-dependent default above is the single-GPU pipeline's: a rank's rows are M / world)
+    if (!set.ntt_chunk) P->ntt_chunk = SPLIT_BLOCK;   // (the size-dependent default above is the single-GPU pipeline's: a rank's rows are M / world)
     if (P->ntt_chunk != SPLIT_BLOCK) { sbn_prover_destroy(P); return fail(SBN_ERR_UNSUPPORTED, "the split prover deals columns in blocks of %zu: unset SBN_NTT_CHUNK", SPLIT_BLOCK); }
     split_sizes(as, degree_bits, cfg->rate_bits, R, SPLIT_BLOCK, &sb, &rb, &sw, &slotw);
     if ((1u << lr) != R || lr > cfg->cap_height || comm->rank >= R || !comm->all_to_all || !comm->all_gather_host || !comm->send_buf || !comm->recv_buf ||
         comm->send_bytes < sb || comm->recv_bytes < rb) {
       sbn_prover_destroy(P);
       return fail(SBN_ERR_BAD_ARG, "bad sbn_comm (world must be a power of two <= 2^cap_height; staging buffers of sbn_split_exchange_bytes)");
+    }
+    for (const void* buf : {(const void*)comm->send_buf, (const void*)comm->recv_buf}) {   // (a transport created on another GPU: ADVICE r3)
+      hipPointerAttribute_t pa{};
+      if (hipPointerGetAttributes(&pa, buf) != hipSuccess || pa.device != P->device) {
+        (void)hipGetLastError();
+        sbn_prover_destroy(P);
+        return fail(SBN_ERR_BAD_ARG, "sbn_comm staging buffers do not live on this prover's device %d (call sbn_set_device before creating the transport)", g_device);
+      }
     }
     SplitCtx* S = P->sp = new SplitCtx();
     for (auto& e : S->xchg_done) e = nullptr;
@@ -674,7 +700,7 @@ static int create_ctx(const sbn_air_desc* air, const sbn_config* cfg, uint32_t d
   acc(dmalloc(&P->d_q, 2 * m)); acc(dmalloc(&P->d_qlde, 4 * m));
   acc(tree_alloc(P->tree_q, m, cfg->cap_height));
   acc(dmalloc(&P->d_tw_f, m)); acc(dmalloc(&P->d_tw_i, m)); acc(dmalloc(&P->d_shift, m)); acc(dmalloc(&P->d_shift_inv, m));
-  { const char* se = getenv("SBN_NTT_SPLIT1024"); if (P->lde_log == 19 && !(se && se[0] == '0')) acc(dmalloc(&P->d_shift_odd, n)); }   // =0: generic first pass (A/B)
+  if (P->lde_log == 19 && set.ntt_split1024) acc(dmalloc(&P->d_shift_odd, n));   // SBN_NTT_SPLIT1024=0: generic first pass (A/B)
   acc(dmalloc(&P->d_xs, m)); acc(dmalloc(&P->d_lag_first, m)); acc(dmalloc(&P->d_lag_last, m));
   P->apow_n = apow_len(as.nconstraints, as.nzs);
   acc(dmalloc(&P->d_apow, (size_t)SBN_NCH * P->apow_n));
@@ -935,7 +961,6 @@ static int generate_trace_device(sbn_prover* P, const uint32_t* ios, size_t K, u
   auto take = [&](size_t words) { u64* r = w; w += (words + 7) & ~(size_t)7; return r; };
   const size_t cw = 257 * 12 * E * K;  // one Jacobian chain of every instance
   u64* ja = take(cw); u64* jb = take(cw);
-  u64* aa = take(257 * 8 * E * K);  u64* ab = take(257 * 8 * E * K);
   u64* sv = take(28 * E * n);       u64* inv = take(n);
   u64* d_out = take(16 * E * K);
   unsigned char* row_op = (unsigned char*)take(n / 8 + 1);
@@ -946,7 +971,7 @@ static int generate_trace_device(sbn_prover* P, const uint32_t* ios, size_t K, u
   if ((size_t)(w - wbase) > P->lde_scratch_words) return fail(SBN_ERR_UNSUPPORTED, "scratch does not fit");
   if (int rc = range_check_setup(P->device)) return rc;
 
-  const bool timing = getenv("SBN_TRACE_TIMING") != nullptr;
+  const bool timing = P->set.trace_timing;
   hipEvent_t e0 = P->abs_ev[0], e1 = P->abs_ev[1];
   std::vector<hipEvent_t> kev;
   auto mark = [&]() { if (timing) { hipEvent_t e; if (hipEventCreate(&e) == hipSuccess && hipEventRecord(e, st) == hipSuccess) kev.push_back(e); } };
@@ -961,10 +986,10 @@ static int generate_trace_device(sbn_prover* P, const uint32_t* ios, size_t K, u
   hipLaunchKernelGGL(tg::io_pulse_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)(2 * K)), dim3(256), 0, st, inv, n, (size_t)sh.rpb, sh.witness_col(0), P->d_trace);
   mark();
   // the two 256-step curve chains per instance: host threads while the device writes the input-independent columns
-  // SBN_TRACEGEN_DEVICE_CHAIN: 2 = one wave per instance walking levels of independent Fq operations (tg::chain_coop_kernel),
-  // 1 = one lane per instance (tg::chain_kernel, 13 ms), unset = host threads + pinned upload
-  const char* dce = getenv("SBN_TRACEGEN_DEVICE_CHAIN");
-  if (dce && dce[0] == '2') {
+  // chain_mode (SBN_TRACEGEN_DEVICE_CHAIN; create_ctx picks by the host pool's size): 2 = one wave per instance walking levels of
+  // independent Fq operations (tg::chain_coop_kernel), 1 = one lane per instance (tg::chain_kernel, 13 ms), 0 = host threads +
+  // pinned upload
+  if (P->chain_mode == 2) {
     static const ChainProgram prog = build_chain_program(E);
     if (prog.levels[0] <= 0 || prog.levels[0] > 24 || prog.levels[1] > 24) return fail(SBN_ERR_UNSUPPORTED, "internal: chain program does not fit");
     tg::ChainProgDev cp{};
@@ -977,7 +1002,7 @@ static int generate_trace_device(sbn_prover* P, const uint32_t* ios, size_t K, u
     cp.zero_slot[0] = (unsigned char)(2 * E + 1); cp.zero_slot[1] = (unsigned char)(5 * E + 1);
     for (int i = 0; i < 6 * E; i++) cp.coord[i] = (unsigned char)i;
     hipLaunchKernelGGL(tg::chain_coop_kernel<E>, dim3((unsigned)K), dim3(tg::CP_LANES), 0, st, d_ios, K, ja, jb, d_err, cp);
-  } else if (dce) hipLaunchKernelGGL(tg::chain_kernel<E>, blocks(K, 64), dim3(64), 0, st, d_ios, K, ja, jb, d_err);
+  } else if (P->chain_mode == 1) hipLaunchKernelGGL(tg::chain_kernel<E>, blocks(K, 64), dim3(64), 0, st, d_ios, K, ja, jb, d_err);
   else {
     if (P->h_chain_words < 2 * cw) {
       if (P->h_chain) (void)hipHostFree(P->h_chain);
@@ -990,18 +1015,16 @@ static int generate_trace_device(sbn_prover* P, const uint32_t* ios, size_t K, u
     HIPC(hipMemcpyAsync(jb, P->h_chain + cw, cw * sizeof(u64), hipMemcpyHostToDevice, st));
   }
   mark();
-  hipLaunchKernelGGL(tg::affine_kernel<E>, blocks((2 * 257 * K + tg::TG_INV_BATCH - 1) / tg::TG_INV_BATCH, 64), dim3(64), 0, st, ja, jb, K, aa, ab, d_err);
-  mark();
-  hipLaunchKernelGGL(tg::lambda_kernel<E>, blocks((n + tg::TG_INV_BATCH - 1) / tg::TG_INV_BATCH, 64), dim3(64), 0, st, d_ios, K, aa, ab, n, sv, row_op, d_out, d_err);
+  hipLaunchKernelGGL(tg::affine_lambda_kernel<E>, blocks((n + tg::TG_ROWS - 1) / tg::TG_ROWS, 64), dim3(64), 0, st, d_ios, K, ja, jb, n, sv, row_op, d_out, d_err);
   mark();
   hipLaunchKernelGGL(tg::gadget_witness_kernel<E>, blocks(3 * E * n, 256), dim3(256), 0, st, sv, row_op, n, sh.gadget_col, P->d_trace, d_err);
   mark();
   if (n > 65536) {   // multiplicities beyond u16: histogram of every target column in HBM first (kernels_tracegen.cuh)
     HIPC(hipMemsetAsync(d_cnt, 0, (size_t)sh.num_rc * 65536 * sizeof(unsigned int), st));
     hipLaunchKernelGGL(tg::range_count_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)sh.num_rc), dim3(256), 0, st, P->d_trace, n, sh.rc_start, d_cnt, d_err);
-    hipLaunchKernelGGL(tg::range_check_kernel<true>, dim3((unsigned)sh.num_rc), dim3(tg::RC_THREADS), tg::RC_LDS_BYTES, st, P->d_trace, n, sh.rc_start, sh.start_lookups, d_err, d_cnt);
+    hipLaunchKernelGGL(tg::range_check_kernel<true>, dim3((unsigned)sh.num_rc), dim3(tg::RC_THREADS), tg::RC_LDS_BYTES, st, P->d_trace, n, sh.rc_start, sh.start_lookups, d_err, d_cnt, P->set.range_check);
   } else {
-    hipLaunchKernelGGL(tg::range_check_kernel<false>, dim3((unsigned)sh.num_rc), dim3(tg::RC_THREADS), tg::RC_LDS_BYTES, st, P->d_trace, n, sh.rc_start, sh.start_lookups, d_err, (const unsigned int*)nullptr);
+    hipLaunchKernelGGL(tg::range_check_kernel<false>, dim3((unsigned)sh.num_rc), dim3(tg::RC_THREADS), tg::RC_LDS_BYTES, st, P->d_trace, n, sh.rc_start, sh.start_lookups, d_err, (const unsigned int*)nullptr, P->set.range_check);
   }
   mark();
   HIPC(hipGetLastError());
@@ -1013,7 +1036,7 @@ static int generate_trace_device(sbn_prover* P, const uint32_t* ios, size_t K, u
   float ms = 0; HIPC(hipEventElapsedTime(&ms, e0, e1));
   P->stage_ms[ST_COUNT + EX_TRACEGEN_MS] = ms;
   if (timing) {
-    static const char* names[] = {"flags+pulses", "chains", "affine", "lambda", "row_witness", "range_check"};
+    static const char* names[] = {"flags+pulses", "chains", "affine+lambda", "row_witness", "range_check"};
     for (size_t i = 0; i + 1 < kev.size(); i++) { float t = 0; (void)hipEventElapsedTime(&t, kev[i], kev[i + 1]); fprintf(stderr, "[device tracegen] %-14s %8.3f ms\n", names[i], t); }
     for (auto e : kev) (void)hipEventDestroy(e);
     fprintf(stderr, "[device tracegen] %-14s %8.3f ms\n", "total", ms);
@@ -1062,7 +1085,7 @@ static int generate_trace_device_fq12(sbn_prover* P, const uint32_t* ios, size_t
   int* d_err = (int*)take(1);
   if ((size_t)(w - wbase) > P->lde_scratch_words) return fail(SBN_ERR_UNSUPPORTED, "scratch does not fit");
 
-  const bool timing = getenv("SBN_TRACE_TIMING") != nullptr;
+  const bool timing = P->set.trace_timing;
   hipEvent_t e0 = P->abs_ev[0], e1 = P->abs_ev[1];
   std::vector<hipEvent_t> kev;
   auto mark = [&]() { if (timing) { hipEvent_t e; if (hipEventCreate(&e) == hipSuccess && hipEventRecord(e, st) == hipSuccess) kev.push_back(e); } };
@@ -1079,7 +1102,7 @@ static int generate_trace_device_fq12(sbn_prover* P, const uint32_t* ios, size_t
   mark();
   // the square-and-multiply chains: one workgroup per instance on the device (kernels_tracegen.cuh fq12_chain_kernel);
   // SBN_FQ12_HOST_CHAIN=1: the library's host threads + a pinned upload, as in round 2 (A/B)
-  static const bool host_chain = [] { const char* e = getenv("SBN_FQ12_HOST_CHAIN"); return e && e[0] == '1'; }();
+  const bool host_chain = P->set.fq12_host_chain;
   if (host_chain) {
     if (P->h_chain_words < 2 * cw) {
       if (P->h_chain) (void)hipHostFree(P->h_chain);
@@ -1092,7 +1115,7 @@ static int generate_trace_device_fq12(sbn_prover* P, const uint32_t* ios, size_t
   } else hipLaunchKernelGGL(tg::fq12_chain_kernel, dim3((unsigned)K), dim3(320), 0, st, d_ios, IOW, steps, ca, cb, d_outs);
   mark();
   // one lane per (row, output coefficient) by default; SBN_FQ12_ROW_KERNEL=1: round 2's one lane per row (A/B)
-  static const bool row_kernel = [] { const char* e = getenv("SBN_FQ12_ROW_KERNEL"); return e && e[0] == '1'; }();
+  const bool row_kernel = P->set.fq12_row_kernel;
   if (row_kernel) hipLaunchKernelGGL(tg::fq12_row_kernel, blocks(n, 64), dim3(64), 0, st, d_ios, IOW, log_rpb, ca, cb, n, P->d_trace, d_err);
   else hipLaunchKernelGGL(tg::fq12_gadget_kernel, blocks(12 * n, 256), dim3(256), 0, st, d_ios, IOW, log_rpb, ca, cb, n, P->d_trace, d_err);
   mark();
@@ -1179,9 +1202,9 @@ static int generate_trace_device_fq(sbn_prover* P, const uint32_t* ios, size_t K
   if (n > 65536) {   // multiplicities beyond u16: histogram of every target column in HBM first (kernels_tracegen.cuh)
     HIPC(hipMemsetAsync(d_cnt, 0, (size_t)sh.num_rc * 65536 * sizeof(unsigned int), st));
     hipLaunchKernelGGL(tg::range_count_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)sh.num_rc), dim3(256), 0, st, P->d_trace, n, sh.rc_start, d_cnt, d_err);
-    hipLaunchKernelGGL(tg::range_check_kernel<true>, dim3((unsigned)sh.num_rc), dim3(tg::RC_THREADS), tg::RC_LDS_BYTES, st, P->d_trace, n, sh.rc_start, sh.start_lookups, d_err, d_cnt);
+    hipLaunchKernelGGL(tg::range_check_kernel<true>, dim3((unsigned)sh.num_rc), dim3(tg::RC_THREADS), tg::RC_LDS_BYTES, st, P->d_trace, n, sh.rc_start, sh.start_lookups, d_err, d_cnt, P->set.range_check);
   } else {
-    hipLaunchKernelGGL(tg::range_check_kernel<false>, dim3((unsigned)sh.num_rc), dim3(tg::RC_THREADS), tg::RC_LDS_BYTES, st, P->d_trace, n, sh.rc_start, sh.start_lookups, d_err, (const unsigned int*)nullptr);
+    hipLaunchKernelGGL(tg::range_check_kernel<false>, dim3((unsigned)sh.num_rc), dim3(tg::RC_THREADS), tg::RC_LDS_BYTES, st, P->d_trace, n, sh.rc_start, sh.start_lookups, d_err, (const unsigned int*)nullptr, P->set.range_check);
   }
   HIPC(hipGetLastError());
   int err = 0;
@@ -1241,7 +1264,7 @@ static void launch_quotient_kind(sbn_prover* P, const QuotientParams& qp, size_t
   if (qp.seg_mask & 12u) hipLaunchKernelGGL((quotient_kernel<KIND, 2>), g2, dim3(256), 0, P->hstream, qp, qp.apow[0], qp.apow[1], qp.pic);
   // SBN_QUOTIENT_TAIL (A/B): 1 = the tail segment behind the permutation checks on the second stream instead of behind the head;
   // 2 = the tail IN FRONT of the head on the main stream (it then walks the lookup columns at the same time as the permutation checks)
-  static const int tail_mode = [] { const char* e = getenv("SBN_QUOTIENT_TAIL"); return e ? atoi(e) : 0; }();
+  const int tail_mode = P->set.quotient_tail;
   if (tail_mode == 2 && (qp.seg_mask & 2u)) hipLaunchKernelGGL((quotient_kernel<KIND, 1>), g1, dim3(256), 0, P->stream, qp, qp.apow[0], qp.apow[1], qp.pic);
   if (qp.seg_mask & 1u) hipLaunchKernelGGL((quotient_kernel<KIND, 0>), g1, dim3(256), 0, P->stream, qp, qp.apow[0], qp.apow[1], qp.pic);
   if (tail_mode != 2 && (qp.seg_mask & 2u)) hipLaunchKernelGGL((quotient_kernel<KIND, 1>), g1, dim3(256), 0, tail_mode == 1 ? P->hstream : P->stream, qp, qp.apow[0], qp.apow[1], qp.pic);
@@ -1285,8 +1308,7 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
   if (S && S->comm.world > 1) {
     // every rank must have a witness before anyone walks into the first exchange (a rank whose generate_trace failed would
     // leave the others waiting for its blocks): agree on a status word first
-    const char* te = getenv("SBN_COMM_TIMEOUT_S");
-    t_wait_deadline_s = te && atof(te) > 0 ? atof(te) : 600.0;
+    t_wait_deadline_s = P->set.comm_timeout_s;
     std::vector<uint32_t> st_all(S->comm.world, 0);
     const uint32_t mine = P->loaded ? 1u : 0u;
     if ((rc = split_all_gather_host(P, &mine, st_all.data(), sizeof(uint32_t)))) return rc;
@@ -1393,7 +1415,7 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
     const size_t qblocks = (qp.m + 255) / 256;
     qp.seg_mask = 0xfu;
 #ifdef SBN_DIAG   // diagnostic builds only (make CXXFLAGS+=-DSBN_DIAG): time single segments; the proof is invalid unless the mask is 15
-    { const char* e = getenv("SBN_DIAG_QUOTIENT_SEGMASK"); if (e) qp.seg_mask = (u32)atoi(e) & 0xfu; }
+    { const char* e = std::getenv("SBN_DIAG_QUOTIENT_SEGMASK"); if (e) qp.seg_mask = (u32)atoi(e) & 0xfu; }
     if (qp.seg_mask != 0xfu) HIPC(hipMemsetAsync(qp.part, 0, (size_t)QSEG * SBN_NCH * qp.m * sizeof(u64), st));
 #endif
     // AIR head and tail on the main stream, the permutation checks beside them on the second stream (idle here)
@@ -1746,8 +1768,8 @@ extern "C" int sbn_commit_values(const uint64_t* cols, size_t ncols, size_t n, u
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(SBN_ERR_NO_DEVICE, "no HIP device available: no CPU fallback");
   HIPC(hipSetDevice(g_device));
   { int rc0 = ntt_fast_setup(); if (rc0) return rc0; }
-  { const char* fe = getenv("SBN_FAST_NTT"); P.fast_ntt = !(fe && fe[0] == '0'); }
-  { const char* xe = getenv("SBN_NTT_XCD"); P.ntt_xcd = !(xe && xe[0] == '0'); }
+  { std::string serr; if (!P.set.load(serr)) return fail(SBN_ERR_BAD_ARG, "%s", serr.c_str()); }
+  P.fast_ntt = P.set.fast_ntt; P.ntt_xcd = P.set.ntt_xcd;
   HIPC(hipStreamCreate(&P.stream));
   u64 *d_vals = nullptr, *d_coef = nullptr, *d_lde = nullptr;
   int rc = 0;
@@ -1834,7 +1856,31 @@ extern "C" int sbn_poseidon_permute_host(uint64_t* states, size_t count, int use
 extern "C" int sbn_set_device(int device) {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return fail(SBN_ERR_NO_DEVICE, "device %d not available", device);
+  HIPC(hipSetDevice(device));
   t_device = device; g_default_device.store(device);
+  return SBN_OK;
+}
+extern "C" int sbn_set_thread_device(int device) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return fail(SBN_ERR_NO_DEVICE, "device %d not available", device);
+  HIPC(hipSetDevice(device));
+  t_device = device;
+  return SBN_OK;
+}
+// The resolved switches of a prover as one line of key=value pairs (settings.hpp): what bench.py prints into `config`.
+extern "C" int sbn_prover_describe(const sbn_prover* P, char* out, size_t cap) {
+  if (!P || !out || cap == 0) return fail(SBN_ERR_BAD_ARG, "null argument");
+  const Settings& s = P->set;
+  static const char* const CH[] = {"host_pool", "device_lane", "device_wave"};
+  const char* chain = P->chain_mode == 0 && tracegen_host_chains_vectorized() ? "host_pool_ifma_x8" : CH[P->chain_mode < 0 || P->chain_mode > 2 ? 0 : P->chain_mode];
+  char buf[1024];
+  snprintf(buf, sizeof buf,
+           "abi=%d device=%d ntt_chunk=%zu fast_ntt=%d ntt_xcd=%d ntt_fused=%d ntt_sub=%zu ntt_streams=%d ntt_split1024=%d merkle_fuse=%d quotient_tail=%d "
+           "curve_chains=%s host_threads=%u fq12_host_chain=%d fq12_row_kernel=%d range_check=%d comm_timeout_s=%g experimental=%d ignored=[%s]",
+           SBN_ABI_VERSION, P->device, P->ntt_chunk, (int)P->fast_ntt, (int)P->ntt_xcd, (int)P->ntt_fused, P->ntt_sub, P->ntt_two_streams ? 2 : 1, P->d_shift_odd ? 1 : 0,
+           (int)s.merkle_fuse, s.quotient_tail, chain, tracegen_host_threads(), (int)s.fq12_host_chain,
+           (int)s.fq12_row_kernel, s.range_check, s.comm_timeout_s, (int)s.experimental, s.ignored.c_str());
+  snprintf(out, cap, "%s", buf);
   return SBN_OK;
 }
 extern "C" int sbn_device_count(void) { int n = 0; return hipGetDeviceCount(&n) == hipSuccess ? n : 0; }

@@ -14,6 +14,7 @@
 #include "host_common.hpp"
 #include <algorithm>
 #include "bn254w.cuh"
+#include "chains_ifma.hpp"
 #include <thread>
 #include <atomic>
 #include <cstring>
@@ -77,7 +78,9 @@ class WorkerPool {
   static bool& in_worker() { static thread_local bool w = false; return w; }
   WorkerPool() {
     unsigned nt = std::thread::hardware_concurrency(); if (nt == 0) nt = 4; if (nt > 64) nt = 64;
-    if (const char* e = getenv("SBN_HOST_THREADS")) { int v = atoi(e); if (v >= 1 && v <= 256) nt = (unsigned)v; }
+    const Settings set = Settings::from_env_or_default();   // SBN_HOST_THREADS (settings.hpp), read when the pool is first used
+    if (set.host_threads) nt = (unsigned)set.host_threads;
+    nthreads_ = nt;
     for (unsigned t = 1; t < nt; t++) workers_.emplace_back([this] { worker(); });
     for (auto& t : workers_) t.detach();  // they sleep until process exit; nothing to join at unload
   }
@@ -96,6 +99,10 @@ class WorkerPool {
     }
   }
   std::vector<std::thread> workers_;
+  unsigned nthreads_ = 1;
+ public:
+  unsigned threads() const { return nthreads_; }
+ private:
   std::mutex m_, run_m_;
   std::condition_variable cv_, done_;
   const std::function<void(size_t)>* job_ = nullptr;
@@ -104,6 +111,7 @@ class WorkerPool {
   unsigned active_ = 0;
 };
 void parallel_for(size_t n, const std::function<void(size_t)>& f) { WorkerPool::get().run(n, f); }
+unsigned pool_threads() { return WorkerPool::get().threads(); }   // the caller's thread included
 // contiguous index ranges of `chunk` per task: consecutive rows written by one thread stay cache-friendly
 // in the column-major trace
 void parallel_for_chunks(size_t n, size_t chunk, const std::function<void(size_t, size_t)>& f) {
@@ -207,17 +215,65 @@ static bool fill_split_range_check(uint64_t* trace, size_t n, int table_col, int
 // Both curve chains of every instance on host threads (the sequential 0.1% of witness generation; the device does the
 // rest, see sbn_prover_generate_trace).  ja / jb: [K][257][3][E][4] u64 (bn254w.cuh jac_at).
 namespace sbn {
-int tracegen_host_chains(int E, const uint32_t* ios, size_t K, u64* ja, u64* jb) {
+// form: 0 = eight instances per AVX-512 IFMA register when the CPU has it (chains_ifma.hpp), else one instance per task;
+// 1 = always one instance per task (exp_chains); 2 = IFMA or fail.  Both forms write the same words.
+int tracegen_host_chains(int E, const uint32_t* ios, size_t K, u64* ja, u64* jb, int form) {
   std::atomic<int> bad(0);
   const size_t iow = 8 * (4 * (size_t)E + 1);
+#if defined(SBN_HAVE_IFMA)
+  if (form != 1 && ifma::available()) {
+    parallel_for((K + 7) / 8, [&](size_t g) {
+      const size_t k0 = 8 * g; const int lanes = (int)std::min<size_t>(8, K - k0);
+      const int b = E == 1 ? ifma::exp_chains_x8<1>(ios, k0, lanes, ja, jb) : ifma::exp_chains_x8<2>(ios, k0, lanes, ja, jb);
+      if (b) bad |= b;
+    });
+    return bad.load();
+  }
+#endif
+  if (form == 2) return -1;
   parallel_for(K, [&](size_t k) { int b = E == 1 ? exp_chains<1>(ios + iow * k, k, ja, jb) : exp_chains<2>(ios + iow * k, k, ja, jb); if (b) bad |= b; });
   return bad.load();
 }
 }  // namespace sbn
 
+namespace sbn {
+unsigned tracegen_host_threads() { return pool_threads(); }
+bool tracegen_host_chains_vectorized() {
+#if defined(SBN_HAVE_IFMA)
+  return ifma::available();
+#else
+  return false;
+#endif
+}
+}  // namespace sbn
+// The SBN_* switches of the calling process as a prover created now would resolve them (no device needed): SBN_OK and one line
+// of key=value pairs, or SBN_ERR_BAD_ARG naming the value that is not understood.
+extern "C" int sbn_settings_check(char* out, size_t cap) {
+  if (!out || cap == 0) return fail(SBN_ERR_BAD_ARG, "null argument");
+  Settings s; std::string err;
+  if (!s.load(err)) return fail(SBN_ERR_BAD_ARG, "%s", err.c_str());
+  snprintf(out, cap, "host_threads=%u curve_chains_on_host=%s device_chain=%d comm_timeout_s=%g trace_timing=%d no_avx512=%d experimental=%d ntt_chunk=%d fast_ntt=%d ntt_xcd=%d "
+           "ntt_fused=%d ntt_sub=%d ntt_streams=%d ntt_split1024=%d merkle_fuse=%d fq12_host_chain=%d fq12_row_kernel=%d quotient_tail=%d range_check=%d ignored=[%s]",
+           tracegen_host_threads(), tracegen_host_chains_vectorized() ? "ifma_x8" : "scalar", s.device_chain, s.comm_timeout_s, (int)s.trace_timing, (int)s.no_avx512, (int)s.experimental,
+           s.ntt_chunk, (int)s.fast_ntt, (int)s.ntt_xcd, (int)s.ntt_fused, s.ntt_sub, s.ntt_streams, (int)s.ntt_split1024, (int)s.merkle_fuse, (int)s.fq12_host_chain,
+           (int)s.fq12_row_kernel, s.quotient_tail, s.range_check, s.ignored.c_str());
+  return SBN_OK;
+}
+// Parity hook (include/sbn.h): the Jacobian chains of the curve witness as the device generator consumes them.
+extern "C" int sbn_host_curve_chains(int E, const uint32_t* ios, size_t num_io, uint64_t* ja, uint64_t* jb, int form) {
+  if (!ios || !ja || !jb || (E != 1 && E != 2) || num_io == 0 || form < 0 || form > 2) return fail(SBN_ERR_BAD_ARG, "bad arguments");
+  const size_t iow = 8 * (4 * (size_t)E + 1);
+  for (size_t k = 0; k < num_io; k++)
+    for (int v = 0; v < 4 * E; v++) { u64 t[4]; u32x8_to_u64x4(ios + iow * k + 8 * v, t); if (geq_p(t)) return fail(SBN_ERR_BAD_ARG, "coordinate >= p (instance %zu)", k); }
+  const int rc = tracegen_host_chains(E, ios, num_io, ja, jb, form);
+  if (rc < 0) return fail(SBN_ERR_UNSUPPORTED, "this CPU has no AVX-512 IFMA");
+  if (rc) return fail(SBN_ERR_WITNESS, "degenerate affine operation (x1 == x2 or y == 0)");
+  return SBN_OK;
+}
+
 struct PhaseTimer {  // SBN_TRACE_TIMING=1 prints per-phase wall time to stderr
   bool on; std::chrono::steady_clock::time_point t;
-  PhaseTimer() : on(getenv("SBN_TRACE_TIMING") != nullptr), t(std::chrono::steady_clock::now()) {}
+  PhaseTimer() : on(Settings::from_env_or_default().trace_timing), t(std::chrono::steady_clock::now()) {}
   void lap(const char* name) {
     auto n = std::chrono::steady_clock::now();
     if (on) fprintf(stderr, "[tracegen] %-18s %8.3f s\n", name, std::chrono::duration<double>(n - t).count());

@@ -311,6 +311,13 @@ class SplitProver:
             if bad:
                 raise api.SbnError(-4, f"split proof abandoned: rank(s) {bad} failed before the first exchange")
 
+    def selftest(self):
+        """sbn_comm_selftest on this prover's transport (every rank calls it): a pattern exchange checked on the device; raises
+        SbnError naming the receiving rank and the block that differs."""
+        L = api.lib()
+        L.sbn_comm_selftest.argtypes = [C.POINTER(_Comm)]
+        self._checked(L.sbn_comm_selftest(C.byref(self._c)))
+
     def prove(self):
         self.agree()
         h = C.c_void_p()
@@ -349,7 +356,7 @@ def prove_local(stark, config, degree_bits, world, ios=None, trace=None, public_
     def rank_main(r):
         try:
             if devices is not None:
-                api._check(api.lib().sbn_set_device(devices[r]))
+                api._check(api.lib().sbn_set_thread_device(devices[r]))   # this rank's thread only: the process default stays the caller's
             sp = SplitProver(stark, config, degree_bits, transport=grp.comms[r])
             try:
                 if ios is not None:

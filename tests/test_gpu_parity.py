@@ -329,6 +329,37 @@ def test_other_exp_tables_second_seed_full_oracle_proof_equality(gpu, O, table, 
     gpu.verify_stark_proof(stark, got, cfg)
 
 
+def _check_every_chain_placement(gpu, stark, cfg, bits, ios, pi_want, trace_want):
+    """The curve chains of the device witness (src/curves/g1/exp.rs:255-318) in every placement the library can pick
+    (SBN_TRACEGEN_DEVICE_CHAIN, read when a prover is created): 0 = host pool (eight instances per AVX-512 IFMA register, or the
+    scalar form with SBN_NO_AVX512-less CPUs), 1 = one lane per instance (chain_kernel), 2 = one wave per instance
+    (chain_coop_kernel, what a rank with a small host share gets), and the old one-pass range-check kernel: same trace words."""
+    for env in ({"SBN_TRACEGEN_DEVICE_CHAIN": "0"}, {"SBN_TRACEGEN_DEVICE_CHAIN": "1"}, {"SBN_TRACEGEN_DEVICE_CHAIN": "2"},
+                {"SBN_EXPERIMENTAL": "1", "SBN_RANGE_CHECK": "1"}):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            pr = gpu.Prover(stark, cfg, bits)
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    del os.environ[k]
+                else:
+                    os.environ[k] = v
+        try:
+            d = pr.describe()
+            if "SBN_TRACEGEN_DEVICE_CHAIN" in env:
+                assert d["curve_chains"].startswith({"0": "host_pool", "1": "device_lane", "2": "device_wave"}[env["SBN_TRACEGEN_DEVICE_CHAIN"]]), d
+            else:
+                assert d["range_check"] == "1" and d["experimental"] == "1", d
+            assert np.array_equal(pr.generate_trace(ios), pi_want), env
+            got = pr.read_trace()
+            bad = np.nonzero((got != trace_want).any(axis=1))[0]
+            assert bad.size == 0, (env, bad[:8].tolist())
+        finally:
+            pr.close()
+
+
 def test_g1exp_device_witness_generation_matches_oracle(gpu, O, g1exp_case, g1exp_gpu_proof, golden):
     """G1ExpStark::generate_trace on the device (src/curves/g1/exp.rs:255-327): trace and public inputs equal the CPU
     oracle's word for word, and proving straight from the device-resident trace gives the same proof bytes."""
@@ -352,12 +383,7 @@ def test_g1exp_device_witness_generation_matches_oracle(gpu, O, g1exp_case, g1ex
         t_host, pi_host = stark.generate_trace_and_public_inputs(ios)
         assert np.array_equal(pi2, pi_host)
         assert np.array_equal(prover.read_trace(), t_host)
-        os.environ["SBN_TRACEGEN_DEVICE_CHAIN"] = "1"              # the host-free variant: chains walked by chain_kernel
-        try:
-            assert np.array_equal(prover.generate_trace(ios), pi_host)
-            assert np.array_equal(prover.read_trace(), t_host)
-        finally:
-            del os.environ["SBN_TRACEGEN_DEVICE_CHAIN"]
+        _check_every_chain_placement(gpu, stark, cfg, 16, ios, pi_host, t_host)
         ios[5, 16:32] = ios[5, 0:16]                               # offset == x with bit 0 set: x1 == x2 in the first add
         ios[5, 32] = 1
         with pytest.raises(gpu.SbnError) as e:
@@ -540,6 +566,7 @@ def test_g2exp_device_witness_generation_matches_oracle(gpu, O, g2exp_case, gold
         t_host, pi_host = stark.generate_trace_and_public_inputs(ios)
         assert np.array_equal(pi2, pi_host)
         assert np.array_equal(prover.read_trace(), t_host)
+        _check_every_chain_placement(gpu, stark, cfg, 16, ios, pi_host, t_host)
         ios[5, 32:64] = ios[5, 0:32]                               # offset == x with bit 0 set: x1 == x2 in the first add
         ios[5, 64] = 1
         with pytest.raises(gpu.SbnError) as e:

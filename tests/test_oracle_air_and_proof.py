@@ -136,7 +136,7 @@ def test_fri_final_poly_times_x_switch(O, S, g1op_case):
     cfgz = stark.config()
     cfgz.fri_variant = S.api.FRI_DEFAULT
     S.verify_stark_proof(stark, S.Proof(w1, 9), cfgz)
-    assert S.lib().sbn_abi_version() == 3
+    assert S.lib().sbn_abi_version() == 4
 
 
 @pytest.mark.parametrize("where", ["trace_cap", "opening", "fri_cap", "query_leaf", "final_poly", "pow", "truncate", "noncanonical"])

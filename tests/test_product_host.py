@@ -544,3 +544,74 @@ def test_unit_test_tables_shape_and_host_witness(S, O, golden):
     assert S.eval_constraints_host(lk, bad[:, r - 1], bad[:, r], [], [3, 5], 1, 0, 0) != [0, 0]
     with pytest.raises(S.SbnError):
         lk.generate_trace([1, 2, 3], [1, 2, 3])                  # not a power of two
+
+
+@pytest.mark.parametrize("E,count", [(1, 128), (1, 13), (2, 16), (2, 5)])
+def test_ifma_curve_chains_equal_the_scalar_chains(S, O, E, count):
+    """The curve chains of the device witness (bn254w.cuh exp_chains; src/curves/g1/exp.rs:165-230, src/curves/g2/exp.rs:180-246) eight
+    instances per AVX-512 IFMA register (csrc/chains_ifma.hpp: radix 2^52, R' = 2^260, every stored word converted back to the
+    2^256 Montgomery form) against one instance at a time: the same [count][257][3][E][4] words, whole and ragged groups, all-zero and
+    all-one scalars, and the degenerate instance (offset == x with bit 0 set) refused by both."""
+    import ctypes as C
+    L = S.lib()
+    ios = (O.g1exp_inputs(count, 21)[0] if E == 1 else O.g2exp_inputs(count, 22)[0]).copy()
+    ios[1, 32 * E:] = 0
+    ios[2, 32 * E:] = 0xFFFFFFFF
+    words = count * 257 * 3 * E * 4
+    out = {}
+    for form in (1, 2):
+        ja, jb = np.zeros(words, dtype=np.uint64), np.full(words, 7, dtype=np.uint64)
+        rc = L.sbn_host_curve_chains(E, ios.ctypes.data_as(C.c_void_p), count, ja.ctypes.data_as(C.c_void_p), jb.ctypes.data_as(C.c_void_p), form)
+        if form == 2 and rc == -4:
+            pytest.skip("this CPU has no AVX-512 IFMA")
+        assert rc == 0, L.sbn_last_error()
+        out[form] = (ja, jb)
+    assert np.array_equal(out[1][0], out[2][0]) and np.array_equal(out[1][1], out[2][1])
+    # the last stored point of chain b is x * s + offset (Jacobian, Montgomery form): check one instance with python integers
+    P = O.BN_P
+    if E == 1:
+        k = min(3, count - 1)
+        _, native = O.g1exp_inputs(count, 21)
+        x, off, s = native[k]
+        want = O.g1_add(O.g1_mul(x, s), off)
+        w = out[2][1][((k * 257 + 256) * 3) * 4:((k * 257 + 256) * 3 + 3) * 4]
+        X, Y, Z = (sum(int(w[4 * c + i]) << (64 * i) for i in range(4)) * pow(2, -256, P) % P for c in range(3))
+        zi = pow(Z, -1, P)
+        assert (X * zi * zi % P, Y * zi * zi * zi % P) == tuple(want)
+    bad = ios.copy()
+    bad[0, 16 * E:32 * E] = bad[0, 0:16 * E]
+    bad[0, 32 * E] = 1
+    for form in (1, 2):
+        ja, jb = np.zeros(words, dtype=np.uint64), np.zeros(words, dtype=np.uint64)
+        assert L.sbn_host_curve_chains(E, bad.ctypes.data_as(C.c_void_p), count, ja.ctypes.data_as(C.c_void_p), jb.ctypes.data_as(C.c_void_p), form) == -8
+
+
+def test_settings_are_read_once_checked_and_experiments_need_their_switch(S):
+    """csrc/settings.hpp: every SBN_* switch is parsed in one place; a value that is not understood is an
+    error; experiment switches are ignored (and reported) without SBN_EXPERIMENTAL=1; the product sources read the environment
+    nowhere else."""
+    import subprocess
+    import sys
+
+    def run(env):
+        code = ("import starky_bn254_amd as S\n"
+                "try:\n    d = S.api.settings_check(); print('OK', d['ntt_chunk'], d['range_check'], d['ignored'], d['device_chain'], d['host_threads'])\n"
+                "except S.SbnError as e:\n    print('ERR', e.code, e)\n")
+        e = {k: v for k, v in os.environ.items() if not k.startswith("SBN_")}
+        e.update(env, PYTHONPATH=ROOT)
+        return subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=120).stdout.strip()
+    assert run({}).startswith("OK 0 0 [] -1")
+    assert run({"SBN_HOST_THREADS": "3"}) == "OK 0 0 [] -1 3"
+    assert run({"SBN_NTT_CHUNK": "32", "SBN_RANGE_CHECK": "1"}) .startswith("OK 0 0 [SBN_NTT_CHUNK,SBN_RANGE_CHECK]")      # ignored, and said so
+    assert run({"SBN_EXPERIMENTAL": "1", "SBN_NTT_CHUNK": "32", "SBN_RANGE_CHECK": "1"}).startswith("OK 32 1 []")
+    assert run({"SBN_EXPERIMENTAL": "1", "SBN_NTT_CHUNK": "30"}).startswith("ERR -1")
+    assert run({"SBN_TRACEGEN_DEVICE_CHAIN": "3"}).startswith("ERR -1")
+    assert run({"SBN_TRACEGEN_DEVICE_CHAIN": "2"}).startswith("OK 0 0 [] 2")
+    assert run({"SBN_COMM_TIMEOUT_S": "soon"}).startswith("ERR -1")
+    assert run({"SBN_HOST_THREADS": "0"}).startswith("ERR -1")
+    csrc = os.path.join(ROOT, "starky_bn254_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".cuh", ".hpp")) and f != "settings.hpp":
+            src = open(os.path.join(csrc, f)).read()
+            hits = [ln for ln in src.splitlines() if "getenv(" in ln and "SBN_DIAG_QUOTIENT_SEGMASK" not in ln]
+            assert hits == [], (f, hits)

@@ -53,3 +53,39 @@ def test_two_rank_sharding_matches_single_process():
     mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
     assert dict(ret["merged"]) == expect
     assert ret["tmax"] == 2.0
+
+
+def _dry_run(*flags):
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if not k.startswith("SBN_") and k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run", *flags], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return json.loads(out.stdout)
+
+
+def test_bench_dry_run_plans_for_eight_ranks():
+    """First contact with an 8-GPU node: `bench.py --gpus 8 ... --dry-run` prints every rank's plan without a
+    GPU or a process group.  config[4]: 185 trace + 84 Z column blocks dealt round-robin, two planes per block from four ranks
+    up, staging sizes = sbn_split_exchange_bytes, ~2.2 GB per xGMI link and proof; config[2]: 256 units, 32 per rank, seeds
+    1000..1255; default mode: one seed per rank."""
+    import starky_bn254_amd as S
+    from starky_bn254_amd import split
+    p = _dry_run("--gpus", "8", "--split", "--table", "fq12")
+    assert p["mode"] == "split" and p["n_gpus"] == 8 and p["table"] == "Fq12ExpStark(512)" and p["degree_bits"] == 18
+    assert (p["num_columns"], p["permutation_zs"], p["planes_per_block"], p["merkle_cap_subtrees_per_rank"]) == (11786, 5328, 2, 2)
+    stark = S.Fq12ExpStark(512)
+    sb, rb = split.exchange_bytes(stark, stark.config(), 18, 8)
+    assert (p["staging_send_bytes_per_rank"], p["staging_recv_bytes_per_rank"]) == (sb, rb)
+    assert len(p["ranks"]) == 8 and [r["rank"] for r in p["ranks"]] == list(range(8))
+    assert sum(r["trace_column_blocks"] for r in p["ranks"]) == 185 and sum(r["trace_columns"] for r in p["ranks"]) == 11786
+    assert sum(r["z_column_blocks"] for r in p["ranks"]) == 84 and sum(r["z_columns"] for r in p["ranks"]) == 5328
+    assert max(r["trace_column_blocks"] for r in p["ranks"]) - min(r["trace_column_blocks"] for r in p["ranks"]) <= 1
+    assert all(1.8e9 < r["bytes_per_link_per_proof"] < 2.6e9 for r in p["ranks"])
+    assert p["message_bytes_per_peer_block_plane"] == 64 * 65536 * 8 and p["xgmi_links_per_gpu"] == 7
+    assert "switches" in p and p["switches"]["experimental"] == "0"
+    b = _dry_run("--gpus", "8", "--batch", "256", "--seed", "1000")
+    assert b["mode"] == "batch" and b["seeds"] == "1000..1255" and [r["units"] for r in b["ranks"]] == [32] * 8
+    assert b["ranks"][3]["first_units"] == [3, 11, 19, 27]
+    d = _dry_run("--gpus", "4")
+    assert d["mode"] == "default" and [r["seed"] for r in d["ranks"]] == [1000, 1001, 1002, 1003] and d["launch"].startswith("python -m torch.distributed.run")

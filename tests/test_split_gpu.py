@@ -107,7 +107,9 @@ def test_split_proof_local_ranks(S, O, golden, table, num_io, seed, key, world):
 def test_transport_selftests(S):
     """sbn_comm_selftest through both native transports: uneven blocks, self blocks, the all-gather form, the host all-gather.
     RCCL at world 1 (one rank per device is all a one-GPU box allows): ncclSend / ncclRecv to itself inside a group, and
-    ncclAllGather; local at world 4 on device 0."""
+    ncclAllGather; local at world 8 (the node's size; bench.py --split runs the same self-test before its first proof at
+    world > 1).  A transport that delivers a wrong block fails FAST, naming the receiving rank and the block: rank 2's exchange
+    is wrapped so that it posts the blocks for ranks 0 and 1 swapped."""
     import ctypes as C
     import threading
     from starky_bn254_amd import split
@@ -117,19 +119,39 @@ def test_transport_selftests(S):
     rc = split.RcclComm(1 << 22, 1 << 22, 0, 1)
     rc.selftest()
     rc.close()
-    world = 4
-    grp = split.LocalGroup(world, 1 << 22, 1 << 22)
-    res = [None] * world
+    world = 8
+    for corrupt in (False, True):
+        grp = split.LocalGroup(world, 1 << 23, 1 << 23)
+        comms = [grp.comms[r] for r in range(world)]
+        keep = []
+        if corrupt:
+            orig = grp.comms[2].all_to_all
 
-    def go(r):
-        res[r] = S.lib().sbn_comm_selftest(C.byref(grp.comms[r]))
-        if res[r] != 0:
-            grp.abort()
-    th = [threading.Thread(target=go, args=(r,)) for r in range(world)]
-    [t.start() for t in th]
-    [t.join() for t in th]
-    grp.close()
-    assert res == [0] * world, S.lib().sbn_last_error()
+            def swapped(ctx, stream, so, sl, ro, rl):
+                arr = (C.c_uint64 * world)(*[so[i] for i in range(world)])
+                arr[0], arr[1] = arr[1], arr[0]
+                return orig(ctx, stream, arr, sl, ro, rl)
+            cb = split._A2A(swapped)
+            keep.append(cb)
+            bad = split._Comm.from_buffer_copy(grp.comms[2])
+            bad.all_to_all = cb
+            comms[2] = bad
+        res, msg = [None] * world, [None] * world
+
+        def go(r):
+            res[r] = S.lib().sbn_comm_selftest(C.byref(comms[r]))
+            if res[r] != 0:
+                msg[r] = S.lib().sbn_last_error().decode()
+                grp.abort()
+        th = [threading.Thread(target=go, args=(r,)) for r in range(world)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        grp.close()
+        if not corrupt:
+            assert res == [0] * world, msg
+        else:
+            assert res[0] != 0 and res[1] != 0, (res, msg)
+            assert "on rank 0 the block from rank 2" in msg[0] and "on rank 1 the block from rank 2" in msg[1], msg
 
 
 def test_split_proof_over_the_native_rccl_transport_world_1(S, O, golden):
