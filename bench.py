@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0,
                     help="BASELINE config[2] literally: this many independent G1 proofs (seeds seed+unit), units dealt round-robin to the ranks, "
                          "witness generated on the device inside the timed region, per-unit digests gathered on rank 0 (strong scaling; --steps is ignored)")
+    ap.add_argument("--inflight", type=int, default=3, help="--batch: prover contexts (proofs in flight) per GPU (default 3)")
     ap.add_argument("--split", action="store_true",
                     help="BASELINE config[4]: ONE proof split over all ranks (sbn_split_prover_*, RCCL all-to-all + all-gathers); --table fq12 --num-io 512 is the config as written")
     ap.add_argument("--transport", choices=["rccl", "torch"], default="rccl",
@@ -226,6 +227,7 @@ def main():
         prover.generate_trace(ios)
         t0 = time.perf_counter()
         wall_gen = wall_prove = 0.0
+        st_after = {}
         for _ in range(5):
             ta = time.perf_counter()
             pi_dev = prover.generate_trace(ios)
@@ -234,9 +236,12 @@ def main():
             proof_dev = prover.prove()
             wall_gen += tb - ta
             wall_prove += time.perf_counter() - tb
+            for k, v in prover.stage_times().items():
+                st_after[k] = st_after.get(k, 0.0) + v / 5
         torch.cuda.synchronize()
         e2e = {"device_tracegen_ms": tg_ms, "ios_to_proof_ms_device_witness": (time.perf_counter() - t0) / 5 * 1e3,
                "generate_trace_wall_ms": wall_gen / 5 * 1e3, "prove_after_generate_wall_ms": wall_prove / 5 * 1e3,
+               "stage_ms_of_prove_after_generate": {k: round(v, 3) for k, v in st_after.items() if k in ("trace_commit", "perm_z", "z_commit", "quotient_eval", "openings", "fri_combine", "fri_layers")},
                "same_proof_as_host_witness": bool((proof_dev.words == proof.words).all() and (pi_dev == pi).all())}
 
     if rank == 0:
@@ -331,7 +336,7 @@ def bench_batch(args, S, np, torch, dist, rank, world, barrier, max_over_ranks):
     t0 = time.time()
     ios_units = np.stack([synthetic_ios(NUM_IO, sharding.unit_seed(args.seed, u), "g1") for u in units]) if units else np.zeros((0, NUM_IO, 40), np.uint32)
     t_inputs = time.time() - t0
-    inflight = 3
+    inflight = max(1, min(args.inflight, 16))
     bp = S.BatchProver(stark, cfg, DEGREE_BITS, inflight)
     if len(units):
         bp.prove_ios(ios_units[:min(inflight, len(units))])            # warm-up (untimed)
@@ -459,7 +464,7 @@ def dry_run_plan(args):
                           "z_columns": zc, "bytes_sent_per_proof": sent, "bytes_per_link_per_proof": sent // max(world - 1, 1)})
         plan["ranks"] = ranks
     elif args.batch:
-        plan.update({"table": f"G1ExpStark({NUM_IO})", "units": args.batch, "seeds": f"{args.seed}..{args.seed + args.batch - 1}", "proofs_in_flight_per_gpu": 3,
+        plan.update({"table": f"G1ExpStark({NUM_IO})", "units": args.batch, "seeds": f"{args.seed}..{args.seed + args.batch - 1}", "proofs_in_flight_per_gpu": max(1, min(args.inflight, 16)),
                      "collectives": "none on the data path (barrier, MAX of the timed region, all-gather of digests)",
                      "ranks": [{"rank": r, "units": len(sharding.shard_units(args.batch, r, world)), "first_units": sharding.shard_units(args.batch, r, world)[:4]} for r in range(world)]})
     else:

@@ -135,6 +135,7 @@ struct sbn_prover {
   hipEvent_t intt_done[MAX_CHUNKS];          // main -> second transform stream: the coefficients of chunk k are complete
   bool ntt_two_streams = false;
   Settings set;                              // the SBN_* switches this prover was created under (settings.hpp)
+  unsigned gen_calls = 0;                    // generate_trace calls so far (SBN_TRACEGEN_SKIP spares the first)
   int chain_mode = 0;                        // curve witness: 0 host pool, 1 one lane per instance, 2 one wave per instance
   hipEvent_t chunk_ready[MAX_CHUNKS];        // main -> hash: LDE chunk k is complete
   hipEvent_t abs_ev[2 * MAX_CHUNKS];         // hash stream: before/after each absorb launch
@@ -980,16 +981,20 @@ static int generate_trace_device(sbn_prover* P, const uint32_t* ios, size_t K, u
   HIPC(hipMemsetAsync(d_err, 0, sizeof(int), st));
   auto blocks = [](size_t k, unsigned b) { return dim3((unsigned)((k + b - 1) / b)); };
   mark();
+  const int skip = P->gen_calls++ ? P->set.tracegen_skip : 0;   // measurement only (settings.hpp): the first call of a prover always writes the whole trace
+  if (!(skip & 1)) {
   hipLaunchKernelGGL(tg::flags_kernel, blocks(n, 256), dim3(256), 0, st, d_ios, IOW, n, sh.start_flags, P->d_trace);
   hipLaunchKernelGGL(tg::small_inverse_kernel, blocks(n, 256), dim3(256), 0, st, inv, n);
   hipLaunchKernelGGL(tg::periodic_kernel, blocks(n, 256), dim3(256), 0, st, inv, n, sh.start_periodic, sh.start_io_pulses, sh.start_lookups, (u64)65535, P->d_trace);
   hipLaunchKernelGGL(tg::io_pulse_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)(2 * K)), dim3(256), 0, st, inv, n, (size_t)sh.rpb, sh.witness_col(0), P->d_trace);
+  }
   mark();
   // the two 256-step curve chains per instance: host threads while the device writes the input-independent columns
   // chain_mode (SBN_TRACEGEN_DEVICE_CHAIN; create_ctx picks by the host pool's size): 2 = one wave per instance walking levels of
   // independent Fq operations (tg::chain_coop_kernel), 1 = one lane per instance (tg::chain_kernel, 13 ms), 0 = host threads +
   // pinned upload
-  if (P->chain_mode == 2) {
+  if (skip & 2) {
+  } else if (P->chain_mode == 2) {
     static const ChainProgram prog = build_chain_program(E);
     if (prog.levels[0] <= 0 || prog.levels[0] > 24 || prog.levels[1] > 24) return fail(SBN_ERR_UNSUPPORTED, "internal: chain program does not fit");
     tg::ChainProgDev cp{};
@@ -1015,11 +1020,14 @@ static int generate_trace_device(sbn_prover* P, const uint32_t* ios, size_t K, u
     HIPC(hipMemcpyAsync(jb, P->h_chain + cw, cw * sizeof(u64), hipMemcpyHostToDevice, st));
   }
   mark();
+  if (!(skip & 2))
   hipLaunchKernelGGL(tg::affine_lambda_kernel<E>, blocks((n + tg::TG_ROWS - 1) / tg::TG_ROWS, 64), dim3(64), 0, st, d_ios, K, ja, jb, n, sv, row_op, d_out, d_err);
   mark();
+  if (!(skip & 4))
   hipLaunchKernelGGL(tg::gadget_witness_kernel<E>, blocks(3 * E * n, 256), dim3(256), 0, st, sv, row_op, n, sh.gadget_col, P->d_trace, d_err);
   mark();
-  if (n > 65536) {   // multiplicities beyond u16: histogram of every target column in HBM first (kernels_tracegen.cuh)
+  if (skip & 8) {
+  } else if (n > 65536) {   // multiplicities beyond u16: histogram of every target column in HBM first (kernels_tracegen.cuh)
     HIPC(hipMemsetAsync(d_cnt, 0, (size_t)sh.num_rc * 65536 * sizeof(unsigned int), st));
     hipLaunchKernelGGL(tg::range_count_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)sh.num_rc), dim3(256), 0, st, P->d_trace, n, sh.rc_start, d_cnt, d_err);
     hipLaunchKernelGGL(tg::range_check_kernel<true>, dim3((unsigned)sh.num_rc), dim3(tg::RC_THREADS), tg::RC_LDS_BYTES, st, P->d_trace, n, sh.rc_start, sh.start_lookups, d_err, d_cnt, P->set.range_check);

@@ -33,6 +33,9 @@ interleaved streams provide them (a single stream pads with s_nop).
 import os
 
 CSRC = os.environ.get("SBN_GEN_OUT") or os.path.join(os.path.dirname(__file__), "..", "starky_bn254_amd", "csrc")
+# MEASUREMENT variants of the two zero-extension moves of a multiply (tools/ab_sponge_moves.sh; never used for the library):
+#   nomov = the moves left out (wrong results: what would the stream cost without them?), lshr = v_lshrrev_b64 {hi, 0} instead
+VARIANT = os.environ.get("SBN_GEN_VARIANT", "")
 
 
 class Stream:
@@ -63,11 +66,18 @@ def mul(s, a, b, dst):
     Register reuse inside the window: P2 accumulates in place over P1, X and R in place over P0 (its high half is dead
     after the first move), T and the carry mask share the low half of the one zero-extended pair ZY."""
     ca, cb = s.ca, s.cb
+    def zext(src_pair, src_hi):
+        if VARIANT == "nomov":
+            return
+        if VARIANT == "lshr":
+            s.emit(f"v_lshrrev_b64 {s.pair(ZY)}, 32, {src_pair}")
+        else:
+            s.emit(f"v_mov_b32 {s.lo(ZY)}, {src_hi}")
     s.emit(f"v_mad_u64_u32 {s.pair(P0)}, {ca}, {a[0]}, {b[0]}, 0", wr=[ca])
-    s.emit(f"v_mov_b32 {s.lo(ZY)}, {s.hi(P0)}")
+    zext(s.pair(P0), s.hi(P0))
     s.emit(f"v_mad_u64_u32 {s.pair(P1)}, {ca}, {a[0]}, {b[1]}, {s.pair(ZY)}", wr=[ca])
     s.emit(f"v_mad_u64_u32 {s.pair(P1)}, {cb}, {a[1]}, {b[0]}, {s.pair(P1)}", wr=[cb])            # P2 (in place); cb = cM
-    s.emit(f"v_mov_b32 {s.lo(ZY)}, {s.hi(P1)}")
+    zext(s.pair(P1), s.hi(P1))
     s.emit(f"v_mad_u64_u32 {s.pair(P3)}, {ca}, {a[1]}, {b[1]}, {s.pair(ZY)}", wr=[ca])
     s.emit(f"v_subb_co_u32_e64 {s.lo(P0)}, {cb}, {s.lo(P0)}, {s.hi(P3)}, {cb}", rd=[cb], wr=[cb])   # X.lo
     s.emit(f"v_subbrev_co_u32_e64 {s.hi(P0)}, {cb}, 0, {s.lo(P1)}, {cb}", rd=[cb], wr=[cb])        # X.hi; cb = b
