@@ -143,6 +143,8 @@ struct sbn_prover {
   u64* d_sponge = nullptr;                   // [12][m] sponge state carried between column chunks
   u64* h_chain = nullptr;                    // pinned staging for the host-computed curve chains (device tracegen)
   size_t h_chain_words = 0;
+  u64* h_io = nullptr;                       // pinned staging of the device witness: the instance list in, the outputs + error word back
+  size_t h_io_words = 0;
   u64* h_open = nullptr;                     // pinned landing buffer of the opened values [(ncols + nzs + 4)][4]
   u64* h_open2 = nullptr;                    // second landing buffer: the values at g*zeta of the trace and Z columns (the host is still reading the first)
 };
@@ -801,6 +803,7 @@ extern "C" void sbn_prover_destroy(sbn_prover* P) {
   if (P->hash_done) (void)hipEventDestroy(P->hash_done);
   if (P->d_sponge) (void)hipFree(P->d_sponge);
   if (P->h_chain) (void)hipHostFree(P->h_chain);
+  if (P->h_io) (void)hipHostFree(P->h_io);
   if (P->h_open) (void)hipHostFree(P->h_open);
   if (P->h_open2) (void)hipHostFree(P->h_open2);
   if (P->hstream) (void)hipStreamDestroy(P->hstream);
@@ -976,8 +979,18 @@ static int generate_trace_device(sbn_prover* P, const uint32_t* ios, size_t K, u
   hipEvent_t e0 = P->abs_ev[0], e1 = P->abs_ev[1];
   std::vector<hipEvent_t> kev;
   auto mark = [&]() { if (timing) { hipEvent_t e; if (hipEventCreate(&e) == hipSuccess && hipEventRecord(e, st) == hipSuccess) kev.push_back(e); } };
+  // pinned staging (a copy from / to pageable memory blocks the calling thread inside the runtime, once per copy)
+  const size_t io_words = (IOW * K + 1) / 2, out_words = 16 * E * K + 1;
+  if (P->h_io_words < io_words + out_words) {
+    if (P->h_io) (void)hipHostFree(P->h_io);
+    P->h_io = nullptr; P->h_io_words = 0;
+    HIPC(hipHostMalloc((void**)&P->h_io, (io_words + out_words) * sizeof(u64), hipHostMallocDefault));
+    P->h_io_words = io_words + out_words;
+  }
+  memcpy(P->h_io, ios, IOW * K * sizeof(uint32_t));
+  u64* const h_out = P->h_io + io_words;
   HIPC(hipEventRecord(e0, st));
-  HIPC(hipMemcpyAsync(d_ios, ios, IOW * K * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+  HIPC(hipMemcpyAsync(d_ios, P->h_io, IOW * K * sizeof(uint32_t), hipMemcpyHostToDevice, st));
   HIPC(hipMemsetAsync(d_err, 0, sizeof(int), st));
   auto blocks = [](size_t k, unsigned b) { return dim3((unsigned)((k + b - 1) / b)); };
   mark();
@@ -1036,11 +1049,12 @@ static int generate_trace_device(sbn_prover* P, const uint32_t* ios, size_t K, u
   }
   mark();
   HIPC(hipGetLastError());
-  std::vector<u64> out(16 * E * K); int err = 0;
-  HIPC(hipMemcpyAsync(out.data(), d_out, out.size() * sizeof(u64), hipMemcpyDeviceToHost, st));
-  HIPC(hipMemcpyAsync(&err, d_err, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPC(hipMemcpyAsync(h_out, d_out, 16 * E * K * sizeof(u64), hipMemcpyDeviceToHost, st));
+  HIPC(hipMemcpyAsync(h_out + 16 * E * K, d_err, sizeof(int), hipMemcpyDeviceToHost, st));
   HIPC(hipEventRecord(e1, st));
   HIPC(hipStreamSynchronize(st));
+  const u64* out = h_out;
+  const int err = (int)(h_out[16 * E * K] & 0xffffffffu);
   float ms = 0; HIPC(hipEventElapsedTime(&ms, e0, e1));
   P->stage_ms[ST_COUNT + EX_TRACEGEN_MS] = ms;
   if (timing) {
