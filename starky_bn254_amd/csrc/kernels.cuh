@@ -680,6 +680,10 @@ __device__ __forceinline__ F wave_scan_mul(F x, int lane) {  // inclusive prefix
 
 // Every lane takes PZ_E consecutive rows per sweep step (a serial product inside the lane, then one wave scan over the
 // lanes' totals), which amortises the scan and the two barriers over PZ_E rows.  n must be a multiple of 256 * PZ_E.
+// The kernel moves 7 words per row (lhs, rhs twice, Z written, read and written) = 2.8 GB for G1ExpStark(128) in 0.53 ms: it runs
+// at HBM speed, not at the latency of its chain of scan steps.  Measured and dropped in round 4 (profiles/r4_perm_z_experiments.txt):
+// loading the rows of step k + 1 in front of the barriers of step k (0.53 -> 0.66 ms: sixteen more live 64-bit values per lane),
+// and four workgroups per column in two passes with a fix-up by the segment products (0.54 -> 0.58 ms: the same traffic).
 template <int PZ_E>
 __global__ __launch_bounds__(256) void permutation_z_kernel(const u64* __restrict__ trace, size_t n, const PairCols* __restrict__ pairs,
                                                             u64 gamma0, u64 gamma1, u64* __restrict__ zout) {
