@@ -663,7 +663,7 @@ __global__ void range_count_kernel(const u64* __restrict__ trace, size_t n, int 
 // gives the first min(c, K) occurrences of 65535 their own table entry (Ordering::Equal), further occurrences run off
 // the table and are deferred, and table copies left over when the inputs end are appended to the pool (lookup.rs:100-101).
 template <bool BIG>
-__global__ void __launch_bounds__(RC_THREADS) range_check_kernel(u64* __restrict__ trace, size_t n, int first_col, int start_lookups, int* __restrict__ err,
+__global__ void __launch_bounds__(RC_THREADS) __attribute__((amdgpu_waves_per_eu(5, 5))) range_check_kernel(u64* __restrict__ trace, size_t n, int first_col, int start_lookups, int* __restrict__ err,
                                                                  const unsigned int* __restrict__ cnt, int old_form) {
   extern __shared__ unsigned int lds[];
   unsigned int* t32 = lds;                                                  // 32768 words = 65536 u16 counters, then T (mod 2^16)
