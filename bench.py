@@ -78,9 +78,12 @@ def main():
     os.environ.setdefault("SBN_HOST_THREADS", str(max(1, min(64, effective_cpus() // max(world, 1)))))
     # HIP maps a process's streams onto 4 hardware queues by default; three provers in flight hold nine streams, and the small
     # copies of witness generation then wait behind another prover's sponge launch on the same queue.  Eight queues: batches from
-    # instance lists +1.6 .. 4.7 %, one proof in flight unchanged (profiles/r4_hwq_and_inflight_sweeps.txt).  Read by the HIP runtime
-    # when it starts, so it is set before torch is imported.
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    # instance lists +1.6 .. 4.7 %, one proof in flight unchanged -- but ONE SPLIT proof at world 1 is 12 - 16 % slower with them (its
+    # transform / exchange / sponge streams then land on queues of their own: 24.0 -> 27.9 ms for G1, 0.664 -> 0.743 s for the 2^18-row
+    # table), so only --batch asks for them (profiles/r4_hwq_and_inflight_sweeps.txt).  Read by the HIP runtime when it starts, so it
+    # is set before torch is imported.
+    if args.batch:
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
     # The contract is ONE JSON line on stdout.  RCCL prints a version banner on file descriptor 1 when its first communicator
     # comes up, so the descriptor is kept aside for the result and everything else that writes to "stdout" goes to stderr.
@@ -266,7 +269,7 @@ def main():
                        "permutation_zs": stark.num_permutation_zs(cfg), "fri": "rate_bits=1 cap=4 arity=16 queries=84 pow_bits=16",
                        "proofs_per_rank": args.steps * max(args.concurrency, 1), "proofs_in_flight_per_gpu": max(args.concurrency, 1),
                        "parallelism": f"independent proofs x{world}, no collective", "host_threads_per_rank": int(os.environ["SBN_HOST_THREADS"]),
-                       "hip_hw_queues": int(os.environ["GPU_MAX_HW_QUEUES"]), "switches": prover.describe()},
+                       "hip_hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "switches": prover.describe()},
             "stage_ms": stage_ms,
             "host": {"tracegen_s": t_tracegen, "h2d_s": t_h2d, "trace_bytes": int(trace.nbytes)},
         }
@@ -364,7 +367,7 @@ def bench_batch(args, S, np, torch, dist, rank, world, barrier, max_over_ranks):
                 "config": {"workload": f"batch of {args.batch} independent G1ExpStark(128) proofs (2^16 rows x 1676 columns each), instance list -> device witness -> proof, "
                                        f"{inflight} proofs in flight per GPU (BASELINE config[2])",
                            "units_per_rank": len(units), "seeds": f"{args.seed}..{args.seed + args.batch - 1}", "parallelism": f"units round-robin over {world} ranks, no collective",
-                           "host_threads_per_rank": int(os.environ["SBN_HOST_THREADS"]), "hip_hw_queues": int(os.environ["GPU_MAX_HW_QUEUES"])},
+                           "host_threads_per_rank": int(os.environ["SBN_HOST_THREADS"]), "hip_hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))},
                 "batch_check": {"digests_gathered": len(merged), "all_units_present_and_distinct": bool(ok)},
                 "host": {"synthetic_inputs_s": t_inputs}}
         emit(line)

@@ -808,11 +808,15 @@ static inline void exp_pi_consts(const ExpShape& sh, const P* const apow[SBN_NCH
     }
 }
 
-// `part`: 0 = all constraints, 1 = sections [1]-[8] only, 2 = sections [9]-[10] only (sh.num_tail_constraints() of them).
+// `part`: 0 = all constraints, 1 = sections [1]-[8] only, 2 = sections [9]-[10] only (sh.num_tail_constraints() of them);
+// 3 = part 2 WITHOUT the 2 num_rc lookup constraints of the u16 range check (their exponents are skipped: lookups_beside_permutation
+// below emits them from the workgroups of the permutation checks, which load the same sorted / permuted columns anyway).
 // The stream is a Horner sum in alpha, so the quotient kernel evaluates the parts in different workgroups and joins
 // them as head * alpha^(tail count) + tail.
 template <int E, class P, class Row>
 GL_HD void exp_eval(Cons<P>& cs, const Row& row, const ExpShape& sh, const ExpPiConsts<P>* pic, int part = 0) {
+  const bool lookups_elsewhere = part == 3;
+  if (part == 3) part = 2;
   const P one = lift<P>(1), base = lift<P>(65536);
   const int sf = sh.start_flags, S = sh.pi_per_io;
   constexpr bool F12 = E == 12 || E == 13;  // Fq12 operands (u16 public-input limbs, split range check)
@@ -943,9 +947,33 @@ GL_HD void exp_eval(Cons<P>& cs, const Row& row, const ExpShape& sh, const ExpPi
     for (int i = mc + 1; i < mc + 1 + 6 * sh.num_rc; i += 6) { lookup_pair(cs, row, i + 1, i + 2); lookup_pair(cs, row, i + 4, i + 5); }
     range_table_block(cs, row, mc, 255);
   } else {
+    if (lookups_elsewhere) cs.rem -= 2 * sh.num_rc;
+    else {
 #pragma unroll 4
-    for (int k = 0; k < sh.num_rc; k++) lookup_pair(cs, row, sh.start_lookups + 1 + 2 * k, sh.start_lookups + 2 + 2 * k);
+      for (int k = 0; k < sh.num_rc; k++) lookup_pair(cs, row, sh.start_lookups + 1 + 2 * k, sh.start_lookups + 2 + 2 * k);
+    }
     range_table_block(cs, row, sh.start_lookups, 65535);
+  }
+}
+// The lookup constraints of the u16 range check (eval_lookups, src/utils/lookup.rs:13-34) for the range-checked columns [k0, k1),
+// emitted OUTSIDE the AIR's own segment with their absolute exponents: lookup k is followed by the 2 (num_rc - 1 - k) constraints of
+// the later lookups, the 3 of the table block and the 2 num_zs permutation checks.  The permutation check of Z columns 2k, 2k + 1
+// reads the sorted copy (start_lookups + 1 + 2k) and the permuted table (+ 2 + 2k) of column k: evaluated in the same workgroup,
+// the lookups find both in cache and the tail segment no longer walks 2 num_rc columns of its own (0.8 GB of the G1 quotient
+// stage's 4.4 GB).  The accumulators of a permutation segment are joined with weight alpha^0, so absolute exponents are right there.
+// MEASURED SLOWER (round 4, G1: quotient stage 1.18 -> 1.25 ms, proofs identical): kept behind SBN_QUOTIENT_LOOKUPS=1 only.
+template <class P, class Row>
+GL_HD void lookups_beside_permutation(Cons<P>& cs, const Row& row, const ExpShape& sh, int num_zs, int k0, int k1) {
+  const int after = 3 + 2 * num_zs;
+#pragma unroll 2
+  for (int k = k0; k < k1; k++) {
+    const int col_in = sh.start_lookups + 1 + 2 * k, col_tab = col_in + 1;
+    const P nin = row.n(col_in);
+    const P d_table = nin - row.n(col_tab);
+    const P c0 = (nin - row.l(col_in)) * d_table, c1 = d_table * cs.l_last;
+    const int e = after + 2 * (sh.num_rc - 1 - k);
+#pragma unroll
+    for (int j = 0; j < SBN_NCH; j++) { cs.a[j].mac(c0, cs.apow[j][e + 1]); cs.a[j].mac(c1, cs.apow[j][e]); }
   }
 }
 

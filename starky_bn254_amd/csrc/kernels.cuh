@@ -801,6 +801,7 @@ struct QuotientParams {
   u64 seg_shift[4][SBN_NCH];  // alpha_j^(number of constraints that follow the segment)
   int seg_count[4];           // constraints of each segment (its first one is weighted alpha^(count-1) inside the segment)
   int zsplit;       // both permutation constraints of the Z columns [0, zsplit) go with segment 2, those of [zsplit, num_zs) with segment 3
+  int lookups_in_perm;   // u16-range-check tables: the lookup constraints go with the permutation segments (their columns are loaded there anyway)
 };
 
 // The constraint stream is one Horner sum in alpha, so it splits exactly into four segments: 0 = AIR sections [1]-[8]
@@ -865,9 +866,16 @@ __global__ __launch_bounds__(256, 2) void quotient_kernel(QuotientParams p, cons
   } else {
     constexpr int E = KIND == 4 ? 12 : (KIND == 6 ? 13 : (KIND == 3 ? 2 : (KIND == 5 ? 0 : 1)));
     ExpShape sh(E, p.num_io);
-    if (PART < 2) exp_eval<E>(cs, row, sh, (const ExpPiConsts<F>*)pic_arg, 1 + PART);
-    else if (seg == 2) permutation_checks(cs, row, zrow, sh, p.num_zs, F(p.gamma0), F(p.gamma1), 0, p.zsplit);
-    else permutation_checks(cs, row, zrow, sh, p.num_zs, F(p.gamma0), F(p.gamma1), p.zsplit, p.num_zs);
+    // u16 range check (G1 / G2 / Fq tables), SBN_QUOTIENT_LOOKUPS=1 (experiment switch): the lookup constraints beside the permutation
+    // checks, which load the same columns (air.cuh lookups_beside_permutation).  Measured in round 4: the tail segment loses 0.8 GB of
+    // reads, but the permutation segments -- the longest of the three concurrent kernels -- get the work: 1.18 -> 1.25 ms for the stage.
+    const bool moved = (E == 0 || E == 1 || E == 2) && p.lookups_in_perm;
+    if (PART < 2) exp_eval<E>(cs, row, sh, (const ExpPiConsts<F>*)pic_arg, (PART == 1 && moved) ? 3 : 1 + PART);
+    else {
+      const int z0 = seg == 2 ? 0 : p.zsplit, z1 = seg == 2 ? p.zsplit : p.num_zs;
+      permutation_checks(cs, row, zrow, sh, p.num_zs, F(p.gamma0), F(p.gamma1), z0, z1);
+      if (moved) lookups_beside_permutation(cs, row, sh, p.num_zs, (z0 + 1) / 2, (z1 + 1) / 2);
+    }
   }
 #pragma unroll
   for (int j = 0; j < SBN_NCH; j++) p.part[((size_t)seg * SBN_NCH + j) * p.m + i] = cs.result(j).v;
@@ -899,6 +907,112 @@ __global__ void domain_tables_kernel(u64* xs, u64* lag_first, u64* lag_last, siz
   xs[i] = x.v;
   lag_first[i] = (zx * f_inv(nn * (x - F(1)))).v;
   lag_last[i] = (zx * f_inv(nn * (g * x - F(1)))).v;
+}
+
+// ---- permutation Z without reading Z back (round 4) ---------------------------------------------------------------------------------
+// permutation_z_kernel moves 7 words per row (the rhs column twice, Z written, read and written again) and runs at HBM speed.  Cut into
+// CHUNKS of 256 * PZ_E rows, a column needs no second sweep: pass A multiplies up num and den of every chunk (2 words per row), pass M
+// turns the chunk products of a column into  P[c] = prod of num of the chunks before c  and  Q[c] = (prod of den of the chunks after c)
+// / (prod of every den)  (one inversion per column), and pass B reads a chunk's two columns again and writes
+//   Z[i] = P[c] * prod_{k < i, k in chunk} num_k  *  Q[c] * prod_{k >= i, k in chunk} den_k        (5 words per row, every pass parallel
+// over columns x chunks).  Exact field arithmetic: the same Z.  tot / pq: [column][chunk][2].
+__device__ __forceinline__ F wave_scan_mul_rev(F x, int lane) {  // inclusive SUFFIX product within a wave
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    u64 o = __shfl_down((unsigned long long)x.v, d, 64);
+    if (lane + d < 64) x = x * F(o);
+  }
+  return x;
+}
+template <int PZ_E>
+__global__ __launch_bounds__(256) void permz_chunk_products_kernel(const u64* __restrict__ trace, size_t n, const PairCols* __restrict__ pairs, u64 gamma0, u64 gamma1,
+                                                                   u64* __restrict__ tot) {
+  __shared__ u64 wn[4], wd[4];
+  const int z = blockIdx.y;
+  const size_t c = blockIdx.x, chunks = gridDim.x;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const size_t i0 = c * 256 * PZ_E + (size_t)tid * PZ_E;
+  const u64* lhs = trace + (size_t)pairs[z].lhs * n + i0;
+  const u64* rhs = trace + (size_t)pairs[z].rhs * n + i0;
+  const F g0(gamma0), g1(gamma1);
+  u64 lv[PZ_E], rv[PZ_E];
+#pragma unroll
+  for (int e = 0; e < PZ_E; e++) { lv[e] = lhs[e]; rv[e] = rhs[e]; }
+  F pn(1), pd(1);
+#pragma unroll
+  for (int e = 0; e < PZ_E; e++) { const F l(lv[e]), r(rv[e]); pn = pn * ((l + g0) * (l + g1)); pd = pd * ((r + g0) * (r + g1)); }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { pn = pn * F(__shfl_xor((unsigned long long)pn.v, d, 64)); pd = pd * F(__shfl_xor((unsigned long long)pd.v, d, 64)); }
+  if (lane == 0) { wn[wv] = pn.v; wd[wv] = pd.v; }
+  __syncthreads();
+  if (tid == 0) {
+    tot[((size_t)z * chunks + c) * 2] = (F(wn[0]) * F(wn[1]) * F(wn[2]) * F(wn[3])).v;
+    tot[((size_t)z * chunks + c) * 2 + 1] = (F(wd[0]) * F(wd[1]) * F(wd[2]) * F(wd[3])).v;
+  }
+}
+// one wave per column: P[c], Q[c] from the chunk products, 64 chunks per step
+__global__ __launch_bounds__(64) void permz_chunk_scan_kernel(const u64* __restrict__ tot, u32 chunks, u64* __restrict__ pq) {
+  const int z = blockIdx.x, lane = threadIdx.x;
+  const u64* t = tot + (size_t)z * chunks * 2;
+  u64* o = pq + (size_t)z * chunks * 2;
+  F carry(1), all(1);
+  for (u32 b = 0; b < chunks; b += 64) {
+    const u32 idx = b + lane;
+    const bool on = idx < chunks;
+    const F inc = wave_scan_mul(on ? F(t[2 * idx]) : F(1), lane);
+    const u64 pv = __shfl_up((unsigned long long)inc.v, 1, 64);
+    if (on) o[2 * idx] = (lane == 0 ? carry : carry * F(pv)).v;
+    carry = carry * F(__shfl((unsigned long long)inc.v, 63, 64));
+    F d = on ? F(t[2 * idx + 1]) : F(1);
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) d = d * F(__shfl_xor((unsigned long long)d.v, k, 64));
+    all = all * d;
+  }
+  F carry_s = f_inv(all);
+  for (u32 b = ((chunks - 1) / 64) * 64;; b -= 64) {
+    const u32 idx = b + lane;
+    const bool on = idx < chunks;
+    const F inc = wave_scan_mul_rev(on ? F(t[2 * idx + 1]) : F(1), lane);
+    const u64 sv = __shfl_down((unsigned long long)inc.v, 1, 64);
+    if (on) o[2 * idx + 1] = (lane == 63 ? carry_s : carry_s * F(sv)).v;
+    carry_s = carry_s * F(__shfl((unsigned long long)inc.v, 0, 64));
+    if (b == 0) break;
+  }
+}
+template <int PZ_E>
+__global__ __launch_bounds__(256) void permz_chunk_write_kernel(const u64* __restrict__ trace, size_t n, const PairCols* __restrict__ pairs, u64 gamma0, u64 gamma1,
+                                                                const u64* __restrict__ pq, u64* __restrict__ zout) {
+  __shared__ u64 wn[4], wd[4];
+  const int z = blockIdx.y;
+  const size_t c = blockIdx.x, chunks = gridDim.x;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const size_t i0 = c * 256 * PZ_E + (size_t)tid * PZ_E;
+  const u64* lhs = trace + (size_t)pairs[z].lhs * n + i0;
+  const u64* rhs = trace + (size_t)pairs[z].rhs * n + i0;
+  u64* zc = zout + (size_t)z * n + i0;
+  const F g0(gamma0), g1(gamma1);
+  u64 lv[PZ_E], rv[PZ_E];
+#pragma unroll
+  for (int e = 0; e < PZ_E; e++) { lv[e] = lhs[e]; rv[e] = rhs[e]; }
+  F pn[PZ_E], sd[PZ_E];   // inclusive prefix of num / inclusive suffix of den inside the lane
+#pragma unroll
+  for (int e = 0; e < PZ_E; e++) { const F l(lv[e]); const F num = (l + g0) * (l + g1); pn[e] = e ? pn[e - 1] * num : num; }
+#pragma unroll
+  for (int e = PZ_E - 1; e >= 0; e--) { const F r(rv[e]); const F den = (r + g0) * (r + g1); sd[e] = e < PZ_E - 1 ? sd[e + 1] * den : den; }
+  const F incn = wave_scan_mul(pn[PZ_E - 1], lane), incd = wave_scan_mul_rev(sd[0], lane);
+  if (lane == 63) wn[wv] = incn.v;
+  if (lane == 0) wd[wv] = incd.v;
+  __syncthreads();
+  F pre(pq[((size_t)z * chunks + c) * 2]), suf(pq[((size_t)z * chunks + c) * 2 + 1]);
+  for (int w = 0; w < wv; w++) pre = pre * F(wn[w]);
+  for (int w = 3; w > wv; w--) suf = suf * F(wd[w]);
+  const u64 pv = __shfl_up((unsigned long long)incn.v, 1, 64), sv = __shfl_down((unsigned long long)incd.v, 1, 64);
+  const F exn = lane == 0 ? pre : pre * F(pv);     // prod of num of every row before this lane's first
+  const F exd = lane == 63 ? suf : suf * F(sv);    // Q[c] * prod of den of every row after this lane's last
+  const F both = exn * exd;
+  zc[0] = (both * sd[0]).v;
+#pragma unroll
+  for (int e = 1; e < PZ_E; e++) zc[e] = (both * pn[e - 1] * sd[e]).v;
 }
 
 // =================================================================================================

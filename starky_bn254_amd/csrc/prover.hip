@@ -1358,6 +1358,17 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
     auto launch_z = [&](size_t z0, size_t cnt, hipStream_t s) {
       if (cnt == 0) return;
       const PairCols* pp = pairs + z0; u64* out = P->d_zval + z0 * n;
+      // from 2^13 rows up: chunk products, one wave per column for their prefix / suffix, then Z written once -- 5 words per row
+      // instead of 7 (kernels.cuh permz_chunk_*; the chunk products wait in the idle quotient scratch).  SBN_PERM_Z=1 (experiment
+      // switch): the one-workgroup-per-column kernel of rounds 1-3.
+      const size_t chunks = n / 2048;
+      if (n >= 8192 && n % 2048 == 0 && P->set.perm_z != 1 && cnt <= 65535 && cnt * chunks * 4 <= 2 * 32 * n) {
+        u64* tot = P->d_part; u64* pq = P->d_part + cnt * chunks * 2;
+        hipLaunchKernelGGL(permz_chunk_products_kernel<8>, dim3((unsigned)chunks, (unsigned)cnt), dim3(256), 0, s, P->d_trace, n, pp, gamma0.v, gamma1.v, tot);
+        hipLaunchKernelGGL(permz_chunk_scan_kernel, dim3((unsigned)cnt), dim3(64), 0, s, tot, (u32)chunks, pq);
+        hipLaunchKernelGGL(permz_chunk_write_kernel<8>, dim3((unsigned)chunks, (unsigned)cnt), dim3(256), 0, s, P->d_trace, n, pp, gamma0.v, gamma1.v, pq, out);
+        return;
+      }
       if (n % 2048 == 0) hipLaunchKernelGGL(permutation_z_kernel<8>, dim3((unsigned)cnt), dim3(256), 0, s, P->d_trace, n, pp, gamma0.v, gamma1.v, out);
       else if (n % 1024 == 0) hipLaunchKernelGGL(permutation_z_kernel<4>, dim3((unsigned)cnt), dim3(256), 0, s, P->d_trace, n, pp, gamma0.v, gamma1.v, out);
       else hipLaunchKernelGGL(permutation_z_kernel<2>, dim3((unsigned)cnt), dim3(256), 0, s, P->d_trace, n, pp, gamma0.v, gamma1.v, out);   // n = 512
@@ -1428,6 +1439,7 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
       // columns below / from zsplit with exponents counted from the end of the stream (nothing follows either of them).
       // (Measured and dropped: the AIR tail on a third stream beside the other two -- 1.22 -> 1.32 ms for the stage, G2 2.0 -> 2.3.)
       qp.zsplit = (int)(Z / 2);
+      qp.lookups_in_perm = P->set.quotient_lookups == 1;   // measured slower (quotient stage 1.18 -> 1.25 ms for G1): an experiment switch only
       const u64 n_tail = is_exp_air(P->air.kind) ? (u64)ExpShape(exp_e(P->air.kind), (int)P->air.num_io).num_tail_constraints() : 0;
       const u64 after[4] = {n_tail + 2 * (u64)Z, 2 * (u64)Z, 0, 0};
       qp.seg_count[0] = (int)(P->air.nconstraints - n_tail); qp.seg_count[1] = (int)n_tail;
@@ -1898,10 +1910,10 @@ extern "C" int sbn_prover_describe(const sbn_prover* P, char* out, size_t cap) {
   char buf[1024];
   snprintf(buf, sizeof buf,
            "abi=%d device=%d ntt_chunk=%zu fast_ntt=%d ntt_xcd=%d ntt_fused=%d ntt_sub=%zu ntt_streams=%d ntt_split1024=%d merkle_fuse=%d quotient_tail=%d "
-           "curve_chains=%s host_threads=%u fq12_host_chain=%d fq12_row_kernel=%d range_check=%d comm_timeout_s=%g experimental=%d ignored=[%s]",
+           "curve_chains=%s host_threads=%u fq12_host_chain=%d fq12_row_kernel=%d range_check=%d perm_z=%d quotient_lookups=%d comm_timeout_s=%g experimental=%d ignored=[%s]",
            SBN_ABI_VERSION, P->device, P->ntt_chunk, (int)P->fast_ntt, (int)P->ntt_xcd, (int)P->ntt_fused, P->ntt_sub, P->ntt_two_streams ? 2 : 1, P->d_shift_odd ? 1 : 0,
            (int)s.merkle_fuse, s.quotient_tail, chain, tracegen_host_threads(), (int)s.fq12_host_chain,
-           (int)s.fq12_row_kernel, s.range_check, s.comm_timeout_s, (int)s.experimental, s.ignored.c_str());
+           (int)s.fq12_row_kernel, s.range_check, s.perm_z, s.quotient_lookups, s.comm_timeout_s, (int)s.experimental, s.ignored.c_str());
   snprintf(out, cap, "%s", buf);
   return SBN_OK;
 }

@@ -253,10 +253,10 @@ extern "C" int sbn_settings_check(char* out, size_t cap) {
   Settings s; std::string err;
   if (!s.load(err)) return fail(SBN_ERR_BAD_ARG, "%s", err.c_str());
   snprintf(out, cap, "host_threads=%u curve_chains_on_host=%s device_chain=%d comm_timeout_s=%g trace_timing=%d no_avx512=%d experimental=%d ntt_chunk=%d fast_ntt=%d ntt_xcd=%d "
-           "ntt_fused=%d ntt_sub=%d ntt_streams=%d ntt_split1024=%d merkle_fuse=%d fq12_host_chain=%d fq12_row_kernel=%d quotient_tail=%d range_check=%d ignored=[%s]",
+           "ntt_fused=%d ntt_sub=%d ntt_streams=%d ntt_split1024=%d merkle_fuse=%d fq12_host_chain=%d fq12_row_kernel=%d quotient_tail=%d range_check=%d perm_z=%d quotient_lookups=%d ignored=[%s]",
            tracegen_host_threads(), tracegen_host_chains_vectorized() ? "ifma_x8" : "scalar", s.device_chain, s.comm_timeout_s, (int)s.trace_timing, (int)s.no_avx512, (int)s.experimental,
            s.ntt_chunk, (int)s.fast_ntt, (int)s.ntt_xcd, (int)s.ntt_fused, s.ntt_sub, s.ntt_streams, (int)s.ntt_split1024, (int)s.merkle_fuse, (int)s.fq12_host_chain,
-           (int)s.fq12_row_kernel, s.quotient_tail, s.range_check, s.ignored.c_str());
+           (int)s.fq12_row_kernel, s.quotient_tail, s.range_check, s.perm_z, s.quotient_lookups, s.ignored.c_str());
   return SBN_OK;
 }
 // Parity hook (include/sbn.h): the Jacobian chains of the curve witness as the device generator consumes them.
