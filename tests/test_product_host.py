@@ -491,6 +491,27 @@ def test_committed_profiles_json_parse():
             json.loads(line)
 
 
+def test_design_numbers_point_at_committed_files():
+    """DESIGN.md holds the current state with the profiles/ file behind every number -- every file it, README.md or
+    INTEGRATION.md names must exist (a `*` stands for a family of files), and DESIGN.md stays wrapped outside its tables."""
+    import glob
+    import re
+    for doc in ("DESIGN.md", "README.md", "INTEGRATION.md"):
+        text = open(os.path.join(ROOT, doc)).read()
+        names = set(re.findall(r"`(?:profiles/)?(r[1-9]_[A-Za-z0-9_*{},.]+\.(?:json|jsonl|txt|csv|log))`", text))
+        assert doc != "DESIGN.md" or len(names) >= 20
+        for n in names:
+            pats = [n]
+            m = re.search(r"\{([^}]*)\}", n)
+            if m:
+                pats = [n[:m.start()] + alt + n[m.end():] for alt in m.group(1).split(",")]
+            for pat in pats:
+                assert glob.glob(os.path.join(ROOT, "profiles", pat)), (doc, n, pat)
+    long_lines = [ln for ln in open(os.path.join(ROOT, "DESIGN.md")).read().splitlines() if len(ln) > 130 and not ln.startswith("|")]
+    assert long_lines == [], long_lines[:3]
+    assert os.path.exists(os.path.join(ROOT, "profiles", "HISTORY.md"))
+
+
 def test_production_library_ignores_the_quotient_diagnostic_switch():
     """SBN_DIAG_QUOTIENT_SEGMASK (skip constraint segments, invalid proof) is compiled in only with -DSBN_DIAG."""
     src = open(os.path.join(ROOT, "starky_bn254_amd", "csrc", "prover.hip")).read()
