@@ -81,9 +81,40 @@ static int unit_tables() {
   return 0;
 }
 
+// the curve chains of the device witness (csrc/bn254w.cuh exp_chains) one instance at a time and eight per AVX-512 IFMA register
+// (csrc/chains_ifma.hpp): the same words, for whole and ragged groups -- with every store and shift of the vector form under ASan / UBSan
+static int curve_chains() {
+  // G1 points with small coordinates: (1, 2) is on y^2 = x^3 + 3; offsets and more points by repeated doubling are not needed -- the
+  // chains accept any pair of affine points that is not degenerate for the given exponent
+  const uint64_t P[4] = {0x3c208c16d87cfd47ULL, 0x97816a916871ca8dULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
+  for (int count : {8, 11}) {
+    std::vector<uint32_t> ios((size_t)count * 40, 0);
+    for (int k = 0; k < count; k++) {
+      uint32_t* io = ios.data() + 40 * k;
+      io[0] = 1; io[8] = 2;                                  // x = (1, 2)
+      io[16] = 1;                                            // offset = (1, -2)
+      uint64_t ny[4]; unsigned __int128 br = 0;
+      for (int i = 0; i < 4; i++) { unsigned __int128 t = (unsigned __int128)P[i] - (i == 0 ? 2 : 0) - (uint64_t)br; ny[i] = (uint64_t)t; br = (t >> 64) & 1; }
+      for (int i = 0; i < 4; i++) { io[24 + 2 * i] = (uint32_t)ny[i]; io[24 + 2 * i + 1] = (uint32_t)(ny[i] >> 32); }
+      for (int i = 0; i < 8; i++) io[32 + i] = 0x9e3779b9u * (uint32_t)(k * 8 + i + 1) | 2u;   // exponent: bit 0 clear (x + (-x) would be degenerate), bit 1 set
+      io[32] &= ~1u;
+    }
+    const size_t words = (size_t)count * 257 * 3 * 4;
+    std::vector<uint64_t> ja1(words), jb1(words), ja2(words, 7), jb2(words, 9);
+    if (sbn_host_curve_chains(1, ios.data(), (size_t)count, ja1.data(), jb1.data(), 1)) { fprintf(stderr, "scalar chains failed: %s\n", sbn::g_last_error.c_str()); return 1; }
+    const int rc = sbn_host_curve_chains(1, ios.data(), (size_t)count, ja2.data(), jb2.data(), 2);
+    if (rc == SBN_ERR_UNSUPPORTED) { printf("curve chains: this CPU has no AVX-512 IFMA, scalar form only\n"); return 0; }
+    if (rc) { fprintf(stderr, "IFMA chains failed: %s\n", sbn::g_last_error.c_str()); return 1; }
+    if (ja1 != ja2 || jb1 != jb2) { fprintf(stderr, "IFMA chains differ from the scalar chains (%d instances)\n", count); return 1; }
+  }
+  printf("curve chains: eight instances per IFMA register == one at a time\n");
+  return 0;
+}
+
 int main(int argc, char** argv) {
   if (argc < 2) { fprintf(stderr, "usage: san_host <dir>\n"); return 2; }
   if (unit_tables()) return 1;
+  if (curve_chains()) return 1;
   int rc = run(argv[1], "modular", SBN_AIR_MODULAR, 16, sbn_generate_trace_modular);
   rc |= run(argv[1], "g1op", SBN_AIR_G1_OP, 32, sbn_generate_trace_g1_op);
   return rc;
