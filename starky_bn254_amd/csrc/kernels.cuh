@@ -133,7 +133,10 @@ namespace nw {
 // C++ forms (A/B measurements).
 #if !defined(SBN_NTT_CXX_ARITH)
 using namespace gp;   // single-instruction primitives (gl.cuh)
-// x + carry * (2^32 - 1), twice (the first repayment can wrap again only from the top 2^32 values)
+// x + carry * (2^32 - 1), twice (the first repayment can wrap again only from the top 2^32 values).  Round 4 measured what the
+// second repayment costs and whether an exact form can avoid it (profiles/r4_ntt_repay_ab.txt): leaving it out (wrong once in ~2^33
+// operations) makes a G1 proof 0.59 ms shorter; a wave-uniform branch on its carry mask gives nothing back; ORing the mask into a flag
+// and re-running a flagged tile exactly is 5.8 ms SLOWER (64 scalar ORs per DFT-16 on the CU's one scalar unit, which the sponge needs).
 __device__ __forceinline__ u64 repay_carry(u64 s, u64 k) { u64 k2, k3; u64 t = madm1(sel01(k), s, k2); return madm1(sel01(k2), t, k3); }
 __device__ __forceinline__ u64 add(u64 a, u64 b) {
   u64 k1, k2; u32 lo = addco(lo32(a), lo32(b), k1); u32 hi = addc(hi32(a), hi32(b), k1, k2);
