@@ -323,6 +323,7 @@ struct NttFusedParams {
   const u64* tw_i; const u64* tw_f; u32 tw_log;   // inverse / forward root tables of the LDE size
   const u64* pre;                           // coset scale 7^i
   u64 scale;                                // 1 / n
+  const u64* pre2;                          // 2^18-row form only: 7^i w_1024^(row of i), NttPassParams::pre2
 };
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void ntt_fused_inv_b_lde_a_kernel(NttFusedParams p) {   // 128 VGPRs: two of its waves fit beside the sponge's two on a SIMD
   extern __shared__ u64 lds[];
@@ -395,6 +396,122 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void n
       const u64 v = nw::mul(x[b][pidx], tw_full(p.tw_f, p.tw_log, (u32)(k * tg2), p.log_n + 1));
       out[(size_t)k * p.n1 + tg2] = nw::canon(v);
     }
+  }
+}
+
+// -------------------------------------------------------------------------------------------------------------
+// K1-512: the same fusion for 2^18-row tables (n = 512 x 512; the LDE is 2^19 = 1,024 x 512 points, its first pass two
+// 512-point transforms, NttPassParams::split).  The inverse transform's pass B is a 512-point DIF pass: a leading radix-2 stage,
+// then two 256-point blocks, so a lane ends with the coefficients k = 2 (g + 16 k2) + b (k2 = 0..15, b = 0, 1) of its tile
+// column.  The LDE's pass wants the rows r = k of the same tile column; it is therefore run decimation in TIME over the
+// parity of r: E = DFT_256(rows 2 r'), O = DFT_256(rows 2 r' + 1) with r' = g + 16 q -- exactly what the lane holds at
+// (b, q = k2) -- and X[j] = E[j] + w_512^j O[j], X[j + 256] = E[j] - w_512^j O[j] at the end, in the lane that owns j in
+// both blocks.  Output half h (rows 2 X + h of the 1,024-point pass) scales the rows by pre (h = 0) or pre2 (h = 1) first.
+// Half 0 takes the coefficients from registers; half 1 reads the lane's own 32 coefficients back (written a moment ago: L2)
+// rather than holding them, which would cost 64 more VGPRs and the place beside the sponge waves.  Saves two launches per
+// chunk and one read of the coefficients; same arithmetic as the separate passes.
+// -------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void ntt_fused512_inv_b_lde_a_kernel(NttFusedParams p) {
+  extern __shared__ u64 lds[];
+  const size_t col = blockIdx.x;
+  const size_t t0 = (size_t)blockIdx.y << 4;
+  const u64* in = p.in + col * p.in_col_stride;
+  u64* coef = p.coef + col * p.coef_col_stride;
+  u64* out = p.out + col * p.out_col_stride;
+  const u32 g = threadIdx.x & 15, t = threadIdx.x >> 4;   // part 1: lanes over g first (the input rows are contiguous)
+  const size_t tg = t0 + t;
+  u64 x[2][16];
+  // ---- part 1: pass B of the inverse transform (512-point DIF, omega^-1: index permutation 11)
+#pragma unroll
+  for (u32 q0 = 0; q0 < 16; q0 += 8) {
+#pragma unroll
+    for (u32 q = q0; q < q0 + 8; q++) {
+      const u64 lo = in[(size_t)(g + 16 * q) + tg * 512], hi = in[(size_t)(g + 16 * q + 256) + tg * 512];
+      x[0][q] = nw::add(lo, hi);
+      x[1][q] = nw::mul(nw::sub(lo, hi), tw_full(p.tw_i, p.tw_log, g + 16 * q, 9));
+    }
+    asm volatile("" ::: "memory");
+  }
+#pragma unroll
+  for (u32 b = 0; b < 2; b++) {
+    nw::dft16_rho(x[b]);
+#pragma unroll
+    for (u32 pidx = 0; pidx < 16; pidx++) {
+      const u32 m = __brev(pidx) >> 28, k1 = (11u * m) & 15;
+      u64 v = x[b][pidx];
+      if (g && k1) v = nw::mul(v, tw_full(p.tw_i, p.tw_log, (u32)(g * k1), 8));
+      lds[(b * 16 + k1) * 257 + t * 16 + g] = v;
+    }
+  }
+  __syncthreads();
+  // coefficient k = 2 (g + 16 k2) + b: stored, and kept (weak form) as row k of the LDE pass
+#pragma unroll
+  for (u32 b = 0; b < 2; b++) {
+    u64 z[16];
+#pragma unroll
+    for (u32 gp = 0; gp < 16; gp++) z[gp] = lds[(b * 16 + g) * 257 + t * 16 + gp];
+    nw::dft16_rho(z);
+#pragma unroll
+    for (u32 pidx = 0; pidx < 16; pidx++) {
+      const u32 m = __brev(pidx) >> 28, k2 = (11u * m) & 15;
+      const u64 v = nw::mul(z[pidx], p.scale);
+      coef[(size_t)((g + 16 * k2) * 2 + b) * 512 + tg] = nw::canon(v);
+      x[b][k2] = v;
+    }
+    asm volatile("" ::: "memory");                     // (block 1's exchange reads stay behind block 0's stores: registers)
+  }
+  __syncthreads();
+  // ---- part 2: the 1,024-point first pass of the coset LDE, output half h = 0, 1 (omega: index permutation 5)
+#pragma unroll 1
+  for (u32 h = 0; h < 2; h++) {
+    u32 t2 = threadIdx.x & 15, k1o = threadIdx.x >> 4;   // lanes of the last round: t fastest (128-byte stores)
+    u32 gl = g, tl = t;
+    asm volatile("" : "+v"(t2), "+v"(k1o), "+v"(gl), "+v"(tl));   // opaque: ~100 table / output addresses are not hoisted out of the loop (and spilled)
+    const size_t tg2 = t0 + t2, tgl = t0 + tl;
+    // rows scaled by the coset table of this half, eight at a time (compiler fences: 32 hoisted table loads and their
+    // addresses would cost the occupancy); half 1 reads the lane's own coefficients back (L2) instead of holding 32 values
+    const u64* __restrict__ pre = h ? p.pre2 : p.pre;
+#pragma unroll
+    for (u32 b = 0; b < 2; b++)
+#pragma unroll
+      for (u32 q0 = 0; q0 < 16; q0 += 8) {
+#pragma unroll
+        for (u32 q = q0; q < q0 + 8; q++) {
+          const size_t ci = (size_t)(2 * (gl + 16 * q) + b) * 512 + tgl;
+          u64 c = x[b][q];
+          if (h) c = coef[ci];
+          x[b][q] = nw::mul(c, pre[ci]);
+        }
+        asm volatile("" ::: "memory");
+      }
+#pragma unroll
+    for (u32 b = 0; b < 2; b++) {
+      nw::dft16_rho(x[b]);
+#pragma unroll
+      for (u32 pidx = 0; pidx < 16; pidx++) {
+        const u32 m = __brev(pidx) >> 28, k1 = (5u * m) & 15;
+        u64 v = x[b][pidx];
+        if (gl && k1) v = nw::mul(v, tw_full(p.tw_f, p.tw_log, (u32)(gl * k1), 8));
+        lds[(b * 16 + k1) * 272 + gl * 17 + tl] = v;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (u32 b = 0; b < 2; b++) {
+#pragma unroll
+      for (u32 gp = 0; gp < 16; gp++) x[b][gp] = lds[(b * 16 + k1o) * 272 + gp * 17 + t2];
+      nw::dft16_rho(x[b]);
+    }
+#pragma unroll
+    for (u32 pidx = 0; pidx < 16; pidx++) {
+      const u32 m = __brev(pidx) >> 28, k2 = (5u * m) & 15;
+      const u32 j = k1o + 16 * k2;                       // frequency inside the 256-point blocks
+      const u64 e = x[0][pidx], o = nw::mul(x[1][pidx], tw_full(p.tw_f, p.tw_log, j, 9));
+      const u32 ka = 2 * j + h, kb = 2 * (j + 256) + h;  // rows of the 1,024-point pass
+      out[(size_t)ka * 512 + tg2] = nw::canon(nw::mul(nw::add(e, o), tw_full(p.tw_f, p.tw_log, (u32)(ka * tg2), 19)));
+      out[(size_t)kb * 512 + tg2] = nw::canon(nw::mul(nw::sub(e, o), tw_full(p.tw_f, p.tw_log, (u32)(kb * tg2), 19)));
+    }
+    __syncthreads();                                    // the exchange buffer is rewritten by the next half
   }
 }
 

@@ -130,6 +130,8 @@ struct sbn_prover {
   bool fast_ntt = true;                      // SBN_FAST_NTT=0 selects the generic radix-2 pass everywhere
   bool ntt_fused = false;                    // the inverse transform's pass B and the LDE's pass A as ONE kernel (2^16 / 2^17 rows)
   u64* d_tmp2 = nullptr;                     // its output: the fused kernel cannot work in place
+  u64* d_tmp3 = nullptr;                     // 2^18 rows, two transform streams: the fused kernel's second output buffer (chunks alternate)
+  bool ntt_fused512 = false;                 // 2^18-row tables: kernels.cuh ntt_fused512_inv_b_lde_a_kernel (SBN_NTT_FUSED=0: separate passes)
   hipStream_t hstream = nullptr;             // sponge absorption / Merkle stream
   hipStream_t nstream = nullptr;             // second transform stream (2^19 LDE rows and up): the LDE of chunk k beside the inverse transform of chunk k+1
   hipEvent_t intt_done[MAX_CHUNKS];          // main -> second transform stream: the coefficients of chunk k are complete
@@ -219,6 +221,7 @@ static int ntt_fast_setup() {  // idempotent, so a race between prover threads i
   if (!done[d].load()) {
     HIPC(hipFuncSetAttribute((const void*)ntt_fast_pass_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 32 * 272 * 8));
     HIPC(hipFuncSetAttribute((const void*)ntt_fused_inv_b_lde_a_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 32 * 272 * 8));
+    HIPC(hipFuncSetAttribute((const void*)ntt_fused512_inv_b_lde_a_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 32 * 272 * 8));
     done[d].store(true);
   }
   return 0;
@@ -256,8 +259,26 @@ static int intt_then_lde(sbn_prover* P, const u64* vals, u64* coef, u64* lde, si
   return 0;
 }
 
+// 2^18-row tables: inverse pass A -> d_tmp, [inverse pass B + both halves of the LDE's 1,024-point pass A] -> coefficients and `tmp2`
+// (kernels.cuh ntt_fused512_inv_b_lde_a_kernel) on the main stream; the LDE's pass B follows on `lde_stream` (the main stream, or the
+// second transform stream behind `handoff`).
+static int intt_lde_cols_fused512(sbn_prover* P, const u64* v, u64* cf, u64* lde_out, size_t nc, u64* tmp2, hipStream_t lde_stream, hipEvent_t handoff) {
+  int rc = ntt_columns(P, v, P->n, cf, P->n, P->d_tmp, P->m, nc, P->degree_bits, true, P->n, nullptr, nullptr, host_inv_pow2(P->degree_bits), nullptr, 1);
+  if (rc) return rc;
+  NttFusedParams f{};
+  f.in = P->d_tmp; f.in_col_stride = P->m; f.coef = cf; f.coef_col_stride = P->n; f.out = tmp2; f.out_col_stride = P->m;
+  f.n1 = 512; f.log_n = P->degree_bits; f.tw_i = P->d_tw_i; f.tw_f = P->d_tw_f; f.tw_log = P->lde_log; f.pre = P->d_shift; f.pre2 = P->d_shift_odd;
+  f.scale = host_inv_pow2(P->degree_bits);
+  hipLaunchKernelGGL(ntt_fused512_inv_b_lde_a_kernel, dim3((unsigned)nc, 32u), dim3(256), 32 * 272 * 8, P->stream, f);
+  if (lde_stream != P->stream) {
+    HIPC(hipEventRecord(handoff, P->stream));
+    HIPC(hipStreamWaitEvent(lde_stream, handoff, 0));
+  }
+  return ntt_columns(P, cf, P->n, lde_out, P->m, tmp2, P->m, nc, P->lde_log, false, P->n, P->d_shift, nullptr, 1, lde_stream, 2);
+}
 // values -> coefficients -> coset LDE of nc columns (column strides n, n, m): the unit of the commit pipelines
 static int intt_lde_cols(sbn_prover* P, const u64* v, u64* cf, u64* lde_out, size_t nc) {
+  if (P->ntt_fused512 && P->d_tmp2) return intt_lde_cols_fused512(P, v, cf, lde_out, nc, P->d_tmp2, P->stream, nullptr);
   if (P->ntt_fused && P->d_tmp2) {
     // three launches instead of four: inverse pass A -> d_tmp, [inverse pass B + LDE pass A] -> coefficients and d_tmp2
     // (kernels.cuh ntt_fused_inv_b_lde_a_kernel), LDE pass B -> lde
@@ -356,7 +377,13 @@ static int commit_pipeline(sbn_prover* P, const u64* vals, u64* coef, u64* lde, 
   for (size_t k = 0; k < nchunks; k++) {
     size_t c0 = k * ch, nc = std::min(ch, ncols - c0);
     int rc;
-    if (P->ntt_two_streams && !P->ntt_sub && !P->ntt_fused) {
+    if (P->ntt_two_streams && !P->ntt_sub && P->ntt_fused512 && P->d_tmp3) {
+      // the fused kernel of chunk k writes buffer k & 1, which the LDE pass B of chunk k - 2 (second stream) must have left
+      if (k >= 2) HIPC(hipStreamWaitEvent(P->stream, P->chunk_ready[k - 2], 0));
+      rc = intt_lde_cols_fused512(P, vals + c0 * P->n, coef + c0 * P->n, lde + c0 * P->m, nc, (k & 1) ? P->d_tmp3 : P->d_tmp2, P->nstream, P->intt_done[k]);
+      if (rc) return rc;
+      HIPC(hipEventRecord(P->chunk_ready[k], P->nstream));
+    } else if (P->ntt_two_streams && !P->ntt_sub && !P->ntt_fused && !P->ntt_fused512) {
       rc = ntt_columns(P, vals + c0 * P->n, P->n, coef + c0 * P->n, P->n, P->d_tmp, P->m, nc, P->degree_bits, true, P->n, nullptr, nullptr, host_inv_pow2(P->degree_bits));
       if (rc) return rc;
       HIPC(hipEventRecord(P->intt_done[k], P->stream));
@@ -480,7 +507,10 @@ static int commit_split(sbn_prover* P, const ColShare& sh, const u64* vals, bool
       const bool two = P->ntt_two_streams && !P->ntt_fused && P->d_tmp2;
       tstream = two ? P->nstream : P->stream;
       int rc;
-      if (two) {
+      if (two && P->ntt_fused512 && P->d_tmp3) {   // (as in commit_pipeline: the fused kernel's output buffers alternate)
+        if (k >= 2) HIPC(hipStreamWaitEvent(P->stream, P->chunk_ready[k - 2], 0));
+        rc = intt_lde_cols_fused512(P, v, cf, lde_out, nc, (k & 1) ? P->d_tmp3 : P->d_tmp2, P->nstream, P->intt_done[k]);
+      } else if (two) {
         rc = ntt_columns(P, v, n, cf, n, P->d_tmp, m, nc, P->degree_bits, true, n, nullptr, nullptr, host_inv_pow2(P->degree_bits));
         if (rc) return rc;
         HIPC(hipEventRecord(P->intt_done[k], P->stream));
@@ -620,6 +650,9 @@ static int create_ctx(const sbn_air_desc* air, const sbn_config* cfg, uint32_t d
   if (set.ntt_chunk) P->ntt_chunk = (size_t)set.ntt_chunk;
   P->fast_ntt = set.fast_ntt; P->ntt_xcd = set.ntt_xcd;
   P->ntt_fused = P->fast_ntt && (degree_bits == 16 || degree_bits == 17) && set.ntt_fused;   // SBN_NTT_FUSED=0: four separate passes (A/B)
+  P->ntt_fused512 = P->fast_ntt && degree_bits == 18 && P->lde_log == 19 && set.ntt_split1024 && set.ntt_fused;
+  // with the fused middle pass the chunk also crosses the transform's second buffer: 40 columns (0.605 -> 0.589 s, profiles/r4_fused512.txt)
+  if (P->ntt_fused512 && !set.ntt_chunk) P->ntt_chunk = 40;
   P->ntt_sub = (size_t)set.ntt_sub;
   // curve chains of the device witness: the host pool when the CPU has AVX-512 IFMA (eight instances per register: 128 instances
   // are 16 tasks of ~0.15 ms, chains_ifma.hpp) or the pool has the threads for the scalar form (2.2 ms on 16), else one wave per
@@ -699,7 +732,8 @@ static int create_ctx(const sbn_air_desc* air, const sbn_config* cfg, uint32_t d
     acc(tree_alloc(P->tree_t, m, cfg->cap_height)); acc(tree_alloc(P->tree_z, m, cfg->cap_height));
   }
   acc(dmalloc(&P->d_tmp, std::max(P->ntt_chunk, (size_t)4) * m));
-  if (P->ntt_fused || P->ntt_two_streams) acc(dmalloc(&P->d_tmp2, std::max(P->ntt_chunk, (size_t)4) * m));
+  if (P->ntt_fused || P->ntt_fused512 || P->ntt_two_streams) acc(dmalloc(&P->d_tmp2, std::max(P->ntt_chunk, (size_t)4) * m));
+  if (P->ntt_fused512 && P->ntt_two_streams) acc(dmalloc(&P->d_tmp3, std::max(P->ntt_chunk, (size_t)4) * m));
   acc(dmalloc(&P->d_q, 2 * m)); acc(dmalloc(&P->d_qlde, 4 * m));
   acc(tree_alloc(P->tree_q, m, cfg->cap_height));
   acc(dmalloc(&P->d_tw_f, m)); acc(dmalloc(&P->d_tw_i, m)); acc(dmalloc(&P->d_shift, m)); acc(dmalloc(&P->d_shift_inv, m));
@@ -779,7 +813,7 @@ static int create_ctx(const sbn_air_desc* air, const sbn_config* cfg, uint32_t d
 extern "C" void sbn_prover_destroy(sbn_prover* P) {
   if (!P) return;
   (void)hipSetDevice(P->device);
-  u64* bufs[] = {P->d_trace, P->d_coef, P->d_lde, P->d_tmp, P->d_tmp2, P->d_zval, P->d_zcoef, P->d_zlde, P->d_q, P->d_qlde, P->tree_t.d, P->tree_z.d,
+  u64* bufs[] = {P->d_trace, P->d_coef, P->d_lde, P->d_tmp, P->d_tmp2, P->d_tmp3, P->d_zval, P->d_zcoef, P->d_zlde, P->d_q, P->d_qlde, P->tree_t.d, P->tree_z.d,
                  P->tree_q.d, P->d_tw_f, P->d_tw_i, P->d_shift, P->d_shift_inv, P->d_xs, P->d_lag_first, P->d_lag_last, P->d_apow, P->d_zpow,
                  P->d_open, P->d_part, P->d_w, P->d_fa, P->d_fcoef, P->d_fcoef2, P->d_pow, P->d_qbuf, P->d_shift_odd};
   for (u64* b : bufs) if (b) (void)hipFree(b);
@@ -1804,10 +1838,16 @@ extern "C" int sbn_commit_values(const uint64_t* cols, size_t ncols, size_t n, u
   { int rc0 = ntt_fast_setup(); if (rc0) return rc0; }
   { std::string serr; if (!P.set.load(serr)) return fail(SBN_ERR_BAD_ARG, "%s", serr.c_str()); }
   P.fast_ntt = P.set.fast_ntt; P.ntt_xcd = P.set.ntt_xcd;
+  // the transform kernels the prover itself picks at this size (the fused middle passes), so that the parity test of this
+  // entry point covers them
+  P.ntt_fused = P.fast_ntt && (lg == 16 || lg == 17) && P.set.ntt_fused;
+  P.ntt_fused512 = P.fast_ntt && lg == 18 && P.set.ntt_split1024 && P.set.ntt_fused;
   HIPC(hipStreamCreate(&P.stream));
   u64 *d_vals = nullptr, *d_coef = nullptr, *d_lde = nullptr;
   int rc = 0;
   rc |= dmalloc(&d_vals, ncols * n); rc |= dmalloc(&d_coef, ncols * n); rc |= dmalloc(&d_lde, ncols * P.m); rc |= dmalloc(&P.d_tmp, 64 * P.m);
+  if (P.ntt_fused || P.ntt_fused512) rc |= dmalloc(&P.d_tmp2, 64 * P.m);
+  if (lg == 18 && P.set.ntt_split1024) rc |= dmalloc(&P.d_shift_odd, n);
   rc |= dmalloc(&P.d_tw_f, P.m); rc |= dmalloc(&P.d_tw_i, P.m); rc |= dmalloc(&P.d_shift, P.m);
   rc |= tree_alloc(P.tree_t, P.m, cap_height);
   if (!rc) {
@@ -1816,9 +1856,10 @@ extern "C" int sbn_commit_values(const uint64_t* cols, size_t ncols, size_t n, u
     hipLaunchKernelGGL(pow_table_kernel, blocks(P.m), dim3(256), 0, P.stream, P.d_tw_f, P.m, w.v);
     hipLaunchKernelGGL(pow_table_kernel, blocks(P.m), dim3(256), 0, P.stream, P.d_tw_i, P.m, f_inv(w).v);
     hipLaunchKernelGGL(pow_table_kernel, blocks(P.m), dim3(256), 0, P.stream, P.d_shift, P.m, (u64)GL_GEN);
+    if (P.d_shift_odd) hipLaunchKernelGGL(shift_odd_table_kernel, blocks(n), dim3(256), 0, P.stream, P.d_shift_odd, n, P.d_shift, P.d_tw_f, 9u);
     if (hipMemcpy(d_vals, cols, ncols * n * sizeof(u64), hipMemcpyHostToDevice) != hipSuccess) rc = fail(SBN_ERR_HIP, "H2D failed");
   }
-  if (!rc) rc = intt_then_lde(&P, d_vals, d_coef, d_lde, ncols);
+  for (size_t c0 = 0; !rc && c0 < ncols; c0 += P.ntt_chunk) rc = intt_then_lde_chunk(&P, d_vals, d_coef, d_lde, c0, std::min(P.ntt_chunk, ncols - c0));
   if (!rc && ncols <= 4) rc = tree_from_matrix(&P, P.tree_t, d_lde, ncols);
   if (!rc && ncols > 4) {  // same chunked sponge as the prover (chunks of 64 columns), on one stream
     rc = dmalloc(&P.d_sponge, 12 * P.m);
@@ -1834,7 +1875,7 @@ extern "C" int sbn_commit_values(const uint64_t* cols, size_t ncols, size_t n, u
   if (!rc) memcpy(cap_out, cap.data(), cap.size() * sizeof(u64));
   if (!rc && coeffs_out && hipMemcpy(coeffs_out, d_coef, ncols * n * sizeof(u64), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(SBN_ERR_HIP, "D2H failed");
   if (!rc && lde_out && hipMemcpy(lde_out, d_lde, ncols * P.m * sizeof(u64), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(SBN_ERR_HIP, "D2H failed");
-  for (u64* b : {d_vals, d_coef, d_lde, P.d_tmp, P.d_tw_f, P.d_tw_i, P.d_shift, P.tree_t.d, P.d_sponge}) if (b) (void)hipFree(b);
+  for (u64* b : {d_vals, d_coef, d_lde, P.d_tmp, P.d_tmp2, P.d_shift_odd, P.d_tw_f, P.d_tw_i, P.d_shift, P.tree_t.d, P.d_sponge}) if (b) (void)hipFree(b);
   (void)hipStreamDestroy(P.stream);
   return rc;
 }
@@ -1911,7 +1952,7 @@ extern "C" int sbn_prover_describe(const sbn_prover* P, char* out, size_t cap) {
   snprintf(buf, sizeof buf,
            "abi=%d device=%d ntt_chunk=%zu fast_ntt=%d ntt_xcd=%d ntt_fused=%d ntt_sub=%zu ntt_streams=%d ntt_split1024=%d merkle_fuse=%d quotient_tail=%d "
            "curve_chains=%s host_threads=%u fq12_host_chain=%d fq12_row_kernel=%d range_check=%d perm_z=%d quotient_lookups=%d comm_timeout_s=%g experimental=%d ignored=[%s]",
-           SBN_ABI_VERSION, P->device, P->ntt_chunk, (int)P->fast_ntt, (int)P->ntt_xcd, (int)P->ntt_fused, P->ntt_sub, P->ntt_two_streams ? 2 : 1, P->d_shift_odd ? 1 : 0,
+           SBN_ABI_VERSION, P->device, P->ntt_chunk, (int)P->fast_ntt, (int)P->ntt_xcd, (int)(P->ntt_fused || P->ntt_fused512), P->ntt_sub, P->ntt_two_streams ? 2 : 1, P->d_shift_odd ? 1 : 0,
            (int)s.merkle_fuse, s.quotient_tail, chain, tracegen_host_threads(), (int)s.fq12_host_chain,
            (int)s.fq12_row_kernel, s.range_check, s.perm_z, s.quotient_lookups, s.comm_timeout_s, (int)s.experimental, s.ignored.c_str());
   snprintf(out, cap, "%s", buf);
