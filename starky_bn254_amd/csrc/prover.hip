@@ -259,17 +259,20 @@ static int intt_then_lde(sbn_prover* P, const u64* vals, u64* coef, u64* lde, si
   return 0;
 }
 
-// 2^18-row tables: inverse pass A -> d_tmp, [inverse pass B + both halves of the LDE's 1,024-point pass A] -> coefficients and `tmp2`
-// (kernels.cuh ntt_fused512_inv_b_lde_a_kernel) on the main stream; the LDE's pass B follows on `lde_stream` (the main stream, or the
-// second transform stream behind `handoff`).
-static int intt_lde_cols_fused512(sbn_prover* P, const u64* v, u64* cf, u64* lde_out, size_t nc, u64* tmp2, hipStream_t lde_stream, hipEvent_t handoff) {
+// The fused middle pass: inverse pass A -> d_tmp, [inverse pass B + LDE pass A] -> coefficients and `tmp2` on the main stream
+// (kernels.cuh ntt_fused_inv_b_lde_a_kernel at 2^16 / 2^17 rows; ntt_fused512_inv_b_lde_a_kernel at 2^18 rows, where the LDE's
+// pass A is the 1,024-point one in two halves); the LDE's pass B follows on `lde_stream` (the main stream, or the second transform
+// stream behind `handoff`).  Three launches per chunk instead of four / five.
+static int intt_lde_cols_fused(sbn_prover* P, const u64* v, u64* cf, u64* lde_out, size_t nc, u64* tmp2, hipStream_t lde_stream, hipEvent_t handoff) {
   int rc = ntt_columns(P, v, P->n, cf, P->n, P->d_tmp, P->m, nc, P->degree_bits, true, P->n, nullptr, nullptr, host_inv_pow2(P->degree_bits), nullptr, 1);
   if (rc) return rc;
   NttFusedParams f{};
+  const u32 log_n1 = (P->degree_bits + 1) / 2;
   f.in = P->d_tmp; f.in_col_stride = P->m; f.coef = cf; f.coef_col_stride = P->n; f.out = tmp2; f.out_col_stride = P->m;
-  f.n1 = 512; f.log_n = P->degree_bits; f.tw_i = P->d_tw_i; f.tw_f = P->d_tw_f; f.tw_log = P->lde_log; f.pre = P->d_shift; f.pre2 = P->d_shift_odd;
+  f.n1 = (size_t)1 << log_n1; f.log_n = P->degree_bits; f.tw_i = P->d_tw_i; f.tw_f = P->d_tw_f; f.tw_log = P->lde_log; f.pre = P->d_shift; f.pre2 = P->d_shift_odd;
   f.scale = host_inv_pow2(P->degree_bits);
-  hipLaunchKernelGGL(ntt_fused512_inv_b_lde_a_kernel, dim3((unsigned)nc, 32u), dim3(256), 32 * 272 * 8, P->stream, f);
+  if (P->ntt_fused512) hipLaunchKernelGGL(ntt_fused512_inv_b_lde_a_kernel, dim3((unsigned)nc, 32u), dim3(256), 32 * 272 * 8, P->stream, f);
+  else hipLaunchKernelGGL(ntt_fused_inv_b_lde_a_kernel, dim3((unsigned)nc, (unsigned)(f.n1 >> 4)), dim3(256), 32 * 272 * 8, P->stream, f);
   if (lde_stream != P->stream) {
     HIPC(hipEventRecord(handoff, P->stream));
     HIPC(hipStreamWaitEvent(lde_stream, handoff, 0));
@@ -278,20 +281,7 @@ static int intt_lde_cols_fused512(sbn_prover* P, const u64* v, u64* cf, u64* lde
 }
 // values -> coefficients -> coset LDE of nc columns (column strides n, n, m): the unit of the commit pipelines
 static int intt_lde_cols(sbn_prover* P, const u64* v, u64* cf, u64* lde_out, size_t nc) {
-  if (P->ntt_fused512 && P->d_tmp2) return intt_lde_cols_fused512(P, v, cf, lde_out, nc, P->d_tmp2, P->stream, nullptr);
-  if (P->ntt_fused && P->d_tmp2) {
-    // three launches instead of four: inverse pass A -> d_tmp, [inverse pass B + LDE pass A] -> coefficients and d_tmp2
-    // (kernels.cuh ntt_fused_inv_b_lde_a_kernel), LDE pass B -> lde
-    int rc = ntt_columns(P, v, P->n, cf, P->n, P->d_tmp, P->m, nc, P->degree_bits, true, P->n, nullptr, nullptr, host_inv_pow2(P->degree_bits), nullptr, 1);
-    if (rc) return rc;
-    NttFusedParams f{};
-    const u32 log_n1 = (P->degree_bits + 1) / 2;
-    f.in = P->d_tmp; f.in_col_stride = P->m; f.coef = cf; f.coef_col_stride = P->n; f.out = P->d_tmp2; f.out_col_stride = P->m;
-    f.n1 = (size_t)1 << log_n1; f.log_n = P->degree_bits; f.tw_i = P->d_tw_i; f.tw_f = P->d_tw_f; f.tw_log = P->lde_log; f.pre = P->d_shift;
-    f.scale = host_inv_pow2(P->degree_bits);
-    hipLaunchKernelGGL(ntt_fused_inv_b_lde_a_kernel, dim3((unsigned)nc, (unsigned)(f.n1 >> 4)), dim3(256), 32 * 272 * 8, P->stream, f);
-    return ntt_columns(P, cf, P->n, lde_out, P->m, P->d_tmp2, P->m, nc, P->lde_log, false, P->n, P->d_shift, nullptr, 1, nullptr, 2);
-  }
+  if ((P->ntt_fused || P->ntt_fused512) && P->d_tmp2) return intt_lde_cols_fused(P, v, cf, lde_out, nc, P->d_tmp2, P->stream, nullptr);
   int rc = ntt_columns(P, v, P->n, cf, P->n, P->d_tmp, P->m, nc, P->degree_bits, true, P->n, nullptr, nullptr, host_inv_pow2(P->degree_bits));
   if (rc) return rc;
   return ntt_columns(P, cf, P->n, lde_out, P->m, P->d_tmp, P->m, nc, P->lde_log, false, P->n, P->d_shift, nullptr, 1);
@@ -377,10 +367,10 @@ static int commit_pipeline(sbn_prover* P, const u64* vals, u64* coef, u64* lde, 
   for (size_t k = 0; k < nchunks; k++) {
     size_t c0 = k * ch, nc = std::min(ch, ncols - c0);
     int rc;
-    if (P->ntt_two_streams && !P->ntt_sub && P->ntt_fused512 && P->d_tmp3) {
+    if (P->ntt_two_streams && !P->ntt_sub && (P->ntt_fused || P->ntt_fused512) && P->d_tmp3) {
       // the fused kernel of chunk k writes buffer k & 1, which the LDE pass B of chunk k - 2 (second stream) must have left
       if (k >= 2) HIPC(hipStreamWaitEvent(P->stream, P->chunk_ready[k - 2], 0));
-      rc = intt_lde_cols_fused512(P, vals + c0 * P->n, coef + c0 * P->n, lde + c0 * P->m, nc, (k & 1) ? P->d_tmp3 : P->d_tmp2, P->nstream, P->intt_done[k]);
+      rc = intt_lde_cols_fused(P, vals + c0 * P->n, coef + c0 * P->n, lde + c0 * P->m, nc, (k & 1) ? P->d_tmp3 : P->d_tmp2, P->nstream, P->intt_done[k]);
       if (rc) return rc;
       HIPC(hipEventRecord(P->chunk_ready[k], P->nstream));
     } else if (P->ntt_two_streams && !P->ntt_sub && !P->ntt_fused && !P->ntt_fused512) {
@@ -504,12 +494,13 @@ static int commit_split(sbn_prover* P, const ColShare& sh, const u64* vals, bool
       u64* lde_out = R == 1 ? plane_l + b * ob * m : S->d_ldechunk;
       // two transform streams from 2^19 LDE rows up (as in commit_pipeline): the LDE (and the pack) of block k beside the inverse
       // transform of block k + 1
-      const bool two = P->ntt_two_streams && !P->ntt_fused && P->d_tmp2;
+      const bool fused = P->ntt_fused || P->ntt_fused512;
+      const bool two = P->ntt_two_streams && P->d_tmp2 && (!fused || P->d_tmp3);
       tstream = two ? P->nstream : P->stream;
       int rc;
-      if (two && P->ntt_fused512 && P->d_tmp3) {   // (as in commit_pipeline: the fused kernel's output buffers alternate)
+      if (two && fused) {   // (as in commit_pipeline: the fused kernel's output buffers alternate)
         if (k >= 2) HIPC(hipStreamWaitEvent(P->stream, P->chunk_ready[k - 2], 0));
-        rc = intt_lde_cols_fused512(P, v, cf, lde_out, nc, (k & 1) ? P->d_tmp3 : P->d_tmp2, P->nstream, P->intt_done[k]);
+        rc = intt_lde_cols_fused(P, v, cf, lde_out, nc, (k & 1) ? P->d_tmp3 : P->d_tmp2, P->nstream, P->intt_done[k]);
       } else if (two) {
         rc = ntt_columns(P, v, n, cf, n, P->d_tmp, m, nc, P->degree_bits, true, n, nullptr, nullptr, host_inv_pow2(P->degree_bits));
         if (rc) return rc;
@@ -733,7 +724,7 @@ static int create_ctx(const sbn_air_desc* air, const sbn_config* cfg, uint32_t d
   }
   acc(dmalloc(&P->d_tmp, std::max(P->ntt_chunk, (size_t)4) * m));
   if (P->ntt_fused || P->ntt_fused512 || P->ntt_two_streams) acc(dmalloc(&P->d_tmp2, std::max(P->ntt_chunk, (size_t)4) * m));
-  if (P->ntt_fused512 && P->ntt_two_streams) acc(dmalloc(&P->d_tmp3, std::max(P->ntt_chunk, (size_t)4) * m));
+  if ((P->ntt_fused || P->ntt_fused512) && P->ntt_two_streams) acc(dmalloc(&P->d_tmp3, std::max(P->ntt_chunk, (size_t)4) * m));
   acc(dmalloc(&P->d_q, 2 * m)); acc(dmalloc(&P->d_qlde, 4 * m));
   acc(tree_alloc(P->tree_q, m, cfg->cap_height));
   acc(dmalloc(&P->d_tw_f, m)); acc(dmalloc(&P->d_tw_i, m)); acc(dmalloc(&P->d_shift, m)); acc(dmalloc(&P->d_shift_inv, m));
