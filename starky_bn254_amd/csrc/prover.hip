@@ -632,7 +632,9 @@ static int create_ctx(const sbn_air_desc* air, const sbn_config* cfg, uint32_t d
   // Default 64; 48 from 2^19 LDE rows up: a chunk's LDE (chunk * M * 8 bytes) is written by the transform stream and read by the
   // sponge out of the 256 MiB Infinity Cache, and 64 columns of 2^19 rows are 268 MB (Fq12ExpStark(512): 0.708 -> 0.675 s,
   // profiles/r3_v2_fq12_chunk.txt).
-  P->ntt_chunk = P->lde_log >= 19 ? 48 : 64;
+  // 2^18 LDE rows: 64 columns are 134 MB and the sponge launches themselves run 17 % slower (35.7 against 30.4 ms per trace commitment of
+  // G1ExpStark(256)); 48 columns: prove() 61.1 -> 56.1 ms (profiles/r4_chunk_2pow17.txt).
+  P->ntt_chunk = P->lde_log >= 18 ? 48 : 64;
   {
     std::string serr;
     if (!P->set.load(serr)) { sbn_prover_destroy(P); return fail(SBN_ERR_BAD_ARG, "%s", serr.c_str()); }
