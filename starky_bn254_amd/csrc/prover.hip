@@ -130,6 +130,16 @@ struct sbn_prover {
   bool fast_ntt = true;                      // SBN_FAST_NTT=0 selects the generic radix-2 pass everywhere
   bool ntt_fused = false;                    // the inverse transform's pass B and the LDE's pass A as ONE kernel (2^16 / 2^17 rows)
   u64* d_tmp2 = nullptr;                     // its output: the fused kernel cannot work in place
+  // EXPERIMENT (SBN_RANGE_ASYNC=1; measured, no gain: profiles/r4_range_async_ab.txt)
+  // u16 range check of the curve witness BEHIND the call that generated it (n <= 2^16 rows): it writes the last columns of the trace
+  // (start_lookups ..), which the trace commitment reaches after ~14 of its 27 chunks; it runs on its own stream, the commitment
+  // joins it before the first chunk that holds such a column, every other reader of the trace joins it first (rc_finish), and its
+  // error word (own allocation: the witness scratch lives in the LDE buffer the commitment overwrites) is checked by prove()
+  hipStream_t rstream = nullptr;
+  hipEvent_t rows_done = nullptr, rc_done = nullptr;
+  int* d_rc_err = nullptr;
+  bool rc_pending = false;
+  size_t rc_first_col = 0;
   u64* d_tmp3 = nullptr;                     // 2^18 rows, two transform streams: the fused kernel's second output buffer (chunks alternate)
   bool ntt_fused512 = false;                 // 2^18-row tables: kernels.cuh ntt_fused512_inv_b_lde_a_kernel (SBN_NTT_FUSED=0: separate passes)
   hipStream_t hstream = nullptr;             // sponge absorption / Merkle stream
@@ -354,6 +364,7 @@ static int commit_pipeline(sbn_prover* P, const u64* vals, u64* coef, u64* lde, 
   size_t nchunks = (ncols + ch - 1) / ch;
   if (nchunks > (size_t)MAX_CHUNKS) return fail(SBN_ERR_UNSUPPORTED, "too many column chunks");
   if (ncols <= 4) {   // hash_or_noop: a leaf of at most 4 elements is its own digest (MyStark's 4 columns and its 2 Z columns)
+    if (P->rc_pending && vals == P->d_trace) HIPC(hipStreamWaitEvent(P->stream, P->rc_done, 0));
     int rc = intt_then_lde(P, vals, coef, lde, ncols);
     if (rc) return rc;
     P->stage_ms[ST_COUNT + ex_launches] = 0;
@@ -364,9 +375,14 @@ static int commit_pipeline(sbn_prover* P, const u64* vals, u64* coef, u64* lde, 
   // behind the LDE of chunk k -- 28.3 -> 29.6 ms per proof: the stage is bound by the VALU work of sponge + transforms
   // together, not by the latency of the transform stream, and more transform waves in flight only slow the sponge launches
   // (12.3 -> 14.8 ms of sponge kernel time).
+  bool rc_joined = !(P->rc_pending && vals == P->d_trace);
   for (size_t k = 0; k < nchunks; k++) {
     size_t c0 = k * ch, nc = std::min(ch, ncols - c0);
     int rc;
+    if (!rc_joined && c0 + nc > P->rc_first_col) {   // the first chunk with a column the asynchronous range check writes
+      HIPC(hipStreamWaitEvent(P->stream, P->rc_done, 0));
+      rc_joined = true;
+    }
     if (P->ntt_two_streams && !P->ntt_sub && (P->ntt_fused || P->ntt_fused512) && P->d_tmp3) {
       // the fused kernel of chunk k writes buffer k & 1, which the LDE pass B of chunk k - 2 (second stream) must have left
       if (k >= 2) HIPC(hipStreamWaitEvent(P->stream, P->chunk_ready[k - 2], 0));
@@ -655,6 +671,12 @@ static int create_ctx(const sbn_air_desc* air, const sbn_config* cfg, uint32_t d
   acc(ntt_fast_setup());
   hipc(hipStreamCreate(&P->stream), "hipStreamCreate");
   hipc(hipStreamCreate(&P->hstream), "hipStreamCreate");
+  if (is_exp_air(as.kind)) {   // the asynchronous range check of the curve witness (sbn_prover::rstream)
+    hipc(hipStreamCreate(&P->rstream), "hipStreamCreate");
+    hipc(hipEventCreateWithFlags(&P->rows_done, hipEventDisableTiming), "hipEventCreate");
+    hipc(hipEventCreateWithFlags(&P->rc_done, hipEventDisableTiming), "hipEventCreate");
+    hipc(hipMalloc((void**)&P->d_rc_err, 256), "hipMalloc");
+  }
   // From 2^19 LDE rows up the transform stream, not the sum of the instruction streams, bounds the commitments (profiles/
   // r3_v8_fq12_512_kernel_stats.csv: five passes of 410 us per chunk beside a 1.19 ms sponge launch, 1.63 ms of VALU work in a 2.05 ms
   // period): the LDE passes of chunk k then run on a second stream beside the inverse passes of chunk k+1 (SBN_NTT_STREAMS=1: one
@@ -806,6 +828,7 @@ static int create_ctx(const sbn_air_desc* air, const sbn_config* cfg, uint32_t d
 extern "C" void sbn_prover_destroy(sbn_prover* P) {
   if (!P) return;
   (void)hipSetDevice(P->device);
+  if (P->rc_pending) (void)hipEventSynchronize(P->rc_done);
   u64* bufs[] = {P->d_trace, P->d_coef, P->d_lde, P->d_tmp, P->d_tmp2, P->d_tmp3, P->d_zval, P->d_zcoef, P->d_zlde, P->d_q, P->d_qlde, P->tree_t.d, P->tree_z.d,
                  P->tree_q.d, P->d_tw_f, P->d_tw_i, P->d_shift, P->d_shift_inv, P->d_xs, P->d_lag_first, P->d_lag_last, P->d_apow, P->d_zpow,
                  P->d_open, P->d_part, P->d_w, P->d_fa, P->d_fcoef, P->d_fcoef2, P->d_pow, P->d_qbuf, P->d_shift_odd};
@@ -834,6 +857,10 @@ extern "C" void sbn_prover_destroy(sbn_prover* P) {
   if (P->h_open) (void)hipHostFree(P->h_open);
   if (P->h_open2) (void)hipHostFree(P->h_open2);
   if (P->hstream) (void)hipStreamDestroy(P->hstream);
+  if (P->rstream) (void)hipStreamDestroy(P->rstream);
+  if (P->rows_done) (void)hipEventDestroy(P->rows_done);
+  if (P->rc_done) (void)hipEventDestroy(P->rc_done);
+  if (P->d_rc_err) (void)hipFree(P->d_rc_err);
   if (P->nstream) { (void)hipStreamDestroy(P->nstream); for (auto& e : P->intt_done) if (e) (void)hipEventDestroy(e); }
   if (P->stream) (void)hipStreamDestroy(P->stream);
   delete P;
@@ -846,9 +873,21 @@ static int check_pi(sbn_prover* P, const uint64_t* pi, size_t n_pi) {
   P->pi.assign(pi, pi + n_pi);
   return 0;
 }
+// The asynchronous range check (sbn_prover::rstream): every reader or writer of the trace other than the trace commitment waits
+// for it here and learns its verdict; prove() calls this after the commitment, which joined it on the stream.
+static int rc_finish(sbn_prover* P) {
+  if (!P->rc_pending) return SBN_OK;
+  P->rc_pending = false;
+  int err = 0;
+  HIPC(hipEventSynchronize(P->rc_done));
+  HIPC(hipMemcpy(&err, P->d_rc_err, sizeof(int), hipMemcpyDeviceToHost));
+  if (err) { P->loaded = false; return fail(SBN_ERR_WITNESS, "range-checked column holds a value >= 2^16"); }
+  return SBN_OK;
+}
 extern "C" int sbn_prover_load_trace(sbn_prover* P, const uint64_t* trace, const uint64_t* pi, size_t n_pi) {
   if (!P || !trace) return fail(SBN_ERR_BAD_ARG, "null argument");
   int rc = check_pi(P, pi, n_pi); if (rc) return rc;
+  (void)rc_finish(P);   // (a range check still writing the columns this call overwrites)
   size_t words = P->air.ncols * P->n;
   {  // canonical-form check on several host threads (the copy below is the PCIe-bound part)
     unsigned nt = std::thread::hardware_concurrency(); if (nt == 0) nt = 4; if (nt > 16) nt = 16;
@@ -872,6 +911,7 @@ extern "C" int sbn_prover_load_trace_device(sbn_prover* P, const uint64_t* d_tra
   if (!P || !d_trace) return fail(SBN_ERR_BAD_ARG, "null argument");
   int rc = check_pi(P, pi, n_pi); if (rc) return rc;
   HIPC(hipSetDevice(P->device));
+  (void)rc_finish(P);
   if (d_trace != P->d_trace) HIPC(hipMemcpy(P->d_trace, d_trace, P->air.ncols * P->n * sizeof(u64), hipMemcpyDeviceToDevice));
   P->loaded = true;
   return SBN_OK;
@@ -1071,6 +1111,14 @@ static int generate_trace_device(sbn_prover* P, const uint32_t* ios, size_t K, u
     HIPC(hipMemsetAsync(d_cnt, 0, (size_t)sh.num_rc * 65536 * sizeof(unsigned int), st));
     hipLaunchKernelGGL(tg::range_count_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)sh.num_rc), dim3(256), 0, st, P->d_trace, n, sh.rc_start, d_cnt, d_err);
     hipLaunchKernelGGL(tg::range_check_kernel<true>, dim3((unsigned)sh.num_rc), dim3(tg::RC_THREADS), tg::RC_LDS_BYTES, st, P->d_trace, n, sh.rc_start, sh.start_lookups, d_err, d_cnt, P->set.range_check);
+  } else if (P->set.range_async && !timing && P->rstream) {
+    // behind this call: on its own stream after the rows are written; the trace commitment joins it (commit_pipeline), prove() reads its verdict
+    HIPC(hipEventRecord(P->rows_done, st));
+    HIPC(hipStreamWaitEvent(P->rstream, P->rows_done, 0));
+    HIPC(hipMemsetAsync(P->d_rc_err, 0, sizeof(int), P->rstream));
+    hipLaunchKernelGGL(tg::range_check_kernel<false>, dim3((unsigned)sh.num_rc), dim3(tg::RC_THREADS), tg::RC_LDS_BYTES, P->rstream, P->d_trace, n, sh.rc_start, sh.start_lookups, P->d_rc_err, (const unsigned int*)nullptr, P->set.range_check);
+    HIPC(hipEventRecord(P->rc_done, P->rstream));
+    P->rc_pending = true; P->rc_first_col = sh.start_lookups;
   } else {
     hipLaunchKernelGGL(tg::range_check_kernel<false>, dim3((unsigned)sh.num_rc), dim3(tg::RC_THREADS), tg::RC_LDS_BYTES, st, P->d_trace, n, sh.rc_start, sh.start_lookups, d_err, (const unsigned int*)nullptr, P->set.range_check);
   }
@@ -1282,6 +1330,7 @@ extern "C" int sbn_prover_generate_trace(sbn_prover* P, const uint32_t* ios, siz
   if (!is_exp_air(P->air.kind)) return fail(SBN_ERR_UNSUPPORTED, "device witness generation covers the Exp tables (use sbn_generate_trace_g1_op + sbn_prover_load_trace)");
   if (num_io != P->air.num_io) return fail(SBN_ERR_BAD_ARG, "prover was created for %u instances, got %zu", P->air.num_io, num_io);
   if (P->n != exp_rows_per_instance(P->air.kind) * num_io) return fail(SBN_ERR_BAD_ARG, "degree_bits does not match the rows per instance");
+  (void)rc_finish(P);   // (the range check of an earlier call that no proof consumed)
   if (P->air.kind == SBN_AIR_FQ12_EXP || P->air.kind == SBN_AIR_FQ12_EXP_U64) return generate_trace_device_fq12(P, ios, num_io, pi_out);
   if (P->n < 65536 || P->n > 262144) return fail(SBN_ERR_UNSUPPORTED, "device witness generation of the u16-range-check tables covers 2^16 .. 2^18 rows");
   if (P->air.kind == SBN_AIR_FQ_EXP) return generate_trace_device_fq(P, ios, num_io, pi_out);
@@ -1292,10 +1341,16 @@ extern "C" int sbn_prover_read_trace(sbn_prover* P, uint64_t* out) {
   if (!P || !out) return fail(SBN_ERR_BAD_ARG, "null argument");
   if (!P->loaded) return fail(SBN_ERR_BAD_ARG, "no trace loaded");
   HIPC(hipSetDevice(P->device));
+  { const int rc = rc_finish(P); if (rc) return rc; }
   HIPC(hipMemcpy(out, P->d_trace, P->air.ncols * P->n * sizeof(u64), hipMemcpyDeviceToHost));
   return SBN_OK;
 }
-extern "C" uint64_t* sbn_prover_trace_device_ptr(sbn_prover* P) { return P ? P->d_trace : nullptr; }
+extern "C" uint64_t* sbn_prover_trace_device_ptr(sbn_prover* P) {
+  if (!P) return nullptr;
+  (void)hipSetDevice(P->device);
+  (void)rc_finish(P);   // the caller reads or writes the buffer next
+  return P->d_trace;
+}
 
 extern "C" int sbn_prover_stage_times(const sbn_prover* P, float* ms, int cap) {
   if (!P || !ms) return 0;
@@ -1366,10 +1421,12 @@ extern "C" int sbn_prover_prove(sbn_prover* P, sbn_proof** out) {
   if (!P->loaded) return fail(SBN_ERR_BAD_ARG, "no trace loaded");
   if (S) {
     S->tev_used = 0;
+    if (P->rc_pending) HIPC(hipStreamWaitEvent(st, P->rc_done, 0));
     if ((rc = commit_split(P, S->cs, P->d_trace, true, P->d_coef, S->lde_l, S->lde_n, P->tree_t))) return rc;
   } else if ((rc = commit_pipeline(P, P->d_trace, P->d_coef, P->d_lde, C, P->tree_t, EX_TRACE_ABSORB_MS, EX_TRACE_ABSORB_LAUNCHES))) return rc;
   HIPC(hipEventRecord(P->ev[ST_PERM_Z], st));
   if ((rc = S ? split_cap_to_host(P, P->tree_t, trace_cap) : tree_cap_to_host(P, P->tree_t, trace_cap))) return rc;
+  if ((rc = rc_finish(P))) return rc;   // (the commitment joined the asynchronous range check; its verdict)
   ch.observe_words(trace_cap.data(), capw);
 
   // P2 permutation argument -------------------------------------------------------------------------
@@ -1944,10 +2001,10 @@ extern "C" int sbn_prover_describe(const sbn_prover* P, char* out, size_t cap) {
   char buf[1024];
   snprintf(buf, sizeof buf,
            "abi=%d device=%d ntt_chunk=%zu fast_ntt=%d ntt_xcd=%d ntt_fused=%d ntt_sub=%zu ntt_streams=%d ntt_split1024=%d merkle_fuse=%d quotient_tail=%d "
-           "curve_chains=%s host_threads=%u fq12_host_chain=%d fq12_row_kernel=%d range_check=%d perm_z=%d quotient_lookups=%d comm_timeout_s=%g experimental=%d ignored=[%s]",
+           "curve_chains=%s host_threads=%u fq12_host_chain=%d fq12_row_kernel=%d range_check=%d range_async=%d perm_z=%d quotient_lookups=%d comm_timeout_s=%g experimental=%d ignored=[%s]",
            SBN_ABI_VERSION, P->device, P->ntt_chunk, (int)P->fast_ntt, (int)P->ntt_xcd, (int)(P->ntt_fused || P->ntt_fused512), P->ntt_sub, P->ntt_two_streams ? 2 : 1, P->d_shift_odd ? 1 : 0,
            (int)s.merkle_fuse, s.quotient_tail, chain, tracegen_host_threads(), (int)s.fq12_host_chain,
-           (int)s.fq12_row_kernel, s.range_check, s.perm_z, s.quotient_lookups, s.comm_timeout_s, (int)s.experimental, s.ignored.c_str());
+           (int)s.fq12_row_kernel, s.range_check, (int)s.range_async, s.perm_z, s.quotient_lookups, s.comm_timeout_s, (int)s.experimental, s.ignored.c_str());
   snprintf(out, cap, "%s", buf);
   return SBN_OK;
 }

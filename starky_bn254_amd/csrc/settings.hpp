@@ -41,6 +41,7 @@ struct Settings {
   int range_check = 0;           // SBN_RANGE_CHECK: 0 default, 1 = the round-3 kernel (one lane per 64 consecutive values)
   int perm_z = 0;                // SBN_PERM_Z=1: one workgroup per Z column, two sweeps (rounds 1-3) instead of the three chunk passes
   int quotient_lookups = 0;      // SBN_QUOTIENT_LOOKUPS=1: the lookup constraints of the u16 range check beside the permutation checks instead of in the AIR tail segment (measured slower)
+  bool range_async = false;      // SBN_RANGE_ASYNC=1: the u16 range check of the curve witness behind generate_trace, beside the first half of the trace commitment (measured: no gain)
   int tracegen_skip = 0;         // SBN_TRACEGEN_SKIP: MEASUREMENT ONLY -- bit mask of curve-witness kernels NOT launched (1 flags / pulses,
                                  //   2 chains + affine_lambda, 4 gadget witness, 8 range check): the trace keeps what an earlier call wrote
   std::string ignored;           // experiment switches that were set without SBN_EXPERIMENTAL=1
@@ -71,7 +72,7 @@ struct Settings {
     x = -1; if (!integer("SBN_TRACEGEN_DEVICE_CHAIN", 0, 2, &x)) return false; device_chain = (int)x;
     x = 0; if (!integer("SBN_EXPERIMENTAL", 0, 1, &x)) return false; experimental = x == 1;
     static const char* const EXP[] = {"SBN_NTT_CHUNK", "SBN_FAST_NTT", "SBN_NTT_XCD", "SBN_NTT_FUSED", "SBN_NTT_SUB", "SBN_NTT_STREAMS", "SBN_NTT_SPLIT1024",
-                                      "SBN_MERKLE_FUSE", "SBN_FQ12_HOST_CHAIN", "SBN_FQ12_ROW_KERNEL", "SBN_QUOTIENT_TAIL", "SBN_RANGE_CHECK", "SBN_TRACEGEN_SKIP", "SBN_PERM_Z", "SBN_QUOTIENT_LOOKUPS"};
+                                      "SBN_MERKLE_FUSE", "SBN_FQ12_HOST_CHAIN", "SBN_FQ12_ROW_KERNEL", "SBN_QUOTIENT_TAIL", "SBN_RANGE_CHECK", "SBN_TRACEGEN_SKIP", "SBN_PERM_Z", "SBN_QUOTIENT_LOOKUPS", "SBN_RANGE_ASYNC"};
     if (!experimental) {
       for (const char* n : EXP) if (get(n)) { if (!ignored.empty()) ignored += ","; ignored += n; }
       return true;
@@ -95,6 +96,7 @@ struct Settings {
     x = 0; if (!integer("SBN_TRACEGEN_SKIP", 0, 15, &x)) return false; tracegen_skip = (int)x;
     x = 0; if (!integer("SBN_PERM_Z", 0, 1, &x)) return false; perm_z = (int)x;
     x = 0; if (!integer("SBN_QUOTIENT_LOOKUPS", 0, 1, &x)) return false; quotient_lookups = (int)x;
+    x = 0; if (!integer("SBN_RANGE_ASYNC", 0, 1, &x)) return false; range_async = x != 0;
     return true;
   }
   // The environment of a caller that has no prover (library-level entry points): invalid values fall back to the defaults.

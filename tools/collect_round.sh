@@ -21,7 +21,7 @@ SBN_TRACE_TIMING=1 python bench.py --steps 3 --warmup 1 --skip-cpu-baseline --no
 (cd tools/microbench && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../starky_bn254_amd/csrc range_check_phases.hip -o /tmp/range_check_phases 2> /dev/null && /tmp/range_check_phases > ../../gpurun_out/${TAG}_range_check_phases.txt)
 (cd tools/microbench && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../starky_bn254_amd/csrc sponge_rate.hip -o /tmp/sponge_rate && /tmp/sponge_rate 12400 > ../../gpurun_out/${TAG}_sponge_rate.txt)
 # every experiment switch (honoured only with SBN_EXPERIMENTAL=1, csrc/settings.hpp) must give the same proof bytes
-for sw in SBN_NTT_FUSED=0 SBN_NTT_STREAMS=2 SBN_NTT_XCD=0 SBN_FAST_NTT=0 SBN_NTT_SUB=16 SBN_MERKLE_FUSE=0 SBN_QUOTIENT_TAIL=2 SBN_RANGE_CHECK=1 SBN_PERM_Z=1 SBN_QUOTIENT_LOOKUPS=1; do echo -n "$sw: " >> gpurun_out/${TAG}_switch_parity.txt; env SBN_EXPERIMENTAL=1 $sw python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "commit_matches or g1exp_proof or proof_bit_exact or g1stark or g1exp_device_witness" 2>&1 | tail -1 >> gpurun_out/${TAG}_switch_parity.txt; done
+for sw in SBN_NTT_FUSED=0 SBN_NTT_STREAMS=2 SBN_NTT_XCD=0 SBN_FAST_NTT=0 SBN_NTT_SUB=16 SBN_MERKLE_FUSE=0 SBN_QUOTIENT_TAIL=2 SBN_RANGE_CHECK=1 SBN_RANGE_ASYNC=1 SBN_PERM_Z=1 SBN_QUOTIENT_LOOKUPS=1; do echo -n "$sw: " >> gpurun_out/${TAG}_switch_parity.txt; env SBN_EXPERIMENTAL=1 $sw python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "commit_matches or g1exp_proof or proof_bit_exact or g1stark or g1exp_device_witness" 2>&1 | tail -1 >> gpurun_out/${TAG}_switch_parity.txt; done
 # the pipeline variants of the 2^18-row tables (fused middle pass, transform streams, split 1,024-point pass) against the committed oracle digest of config[4]
 for sw in SBN_NTT_FUSED=0 SBN_NTT_STREAMS=1 SBN_NTT_SPLIT1024=0 SBN_NTT_CHUNK=48; do echo -n "2^18 rows, $sw: " >> gpurun_out/${TAG}_switch_parity.txt; env SBN_EXPERIMENTAL=1 $sw python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "fq12exp_2pow18" 2>&1 | tail -1 >> gpurun_out/${TAG}_switch_parity.txt; done
 cat gpurun_out/${TAG}_switch_parity.txt
