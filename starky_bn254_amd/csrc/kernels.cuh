@@ -409,7 +409,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void n
 // both blocks.  Output half h (rows 2 X + h of the 1,024-point pass) scales the rows by pre (h = 0) or pre2 (h = 1) first.
 // Half 0 takes the coefficients from registers; half 1 reads the lane's own 32 coefficients back (written a moment ago: L2)
 // rather than holding them, which would cost 64 more VGPRs and the place beside the sponge waves.  Saves two launches per
-// chunk and one read of the coefficients; same arithmetic as the separate passes.
+// chunk and one read of the coefficients; same arithmetic as the separate passes.  Capped at 128 VGPRs (two waves beside the
+// sponge's two; the compiler spills 14 dwords of lane indices at the start): measured against 143 VGPRs without spills,
+// Fq12ExpStark(512) 0.605 against 0.608 s and the sponge launches beside it 8 % faster (profiles/r4_fused512.txt).  The compiler
+// fences and the opaque lane indices below keep it from hoisting ~100 table / output addresses out of the phases they belong to
+// (without them: 256 VGPRs + 10 AGPRs, or ~190 spilled dwords at 128).
 // -------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void ntt_fused512_inv_b_lde_a_kernel(NttFusedParams p) {
   extern __shared__ u64 lds[];
