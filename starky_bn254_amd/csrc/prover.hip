@@ -141,7 +141,7 @@ struct sbn_prover {
   bool rc_pending = false;
   size_t rc_first_col = 0;
   u64* d_tmp3 = nullptr;                     // 2^18 rows, two transform streams: the fused kernel's second output buffer (chunks alternate)
-  bool ntt_fused512 = false;                 // 2^18-row tables: kernels.cuh ntt_fused512_inv_b_lde_a_kernel (SBN_NTT_FUSED=0: separate passes)
+  bool ntt_fused512 = false;                 // 2^18-row tables: kernels_ntt.cuh ntt_fused512_inv_b_lde_a_kernel (SBN_NTT_FUSED=0: separate passes)
   hipStream_t hstream = nullptr;             // sponge absorption / Merkle stream
   hipStream_t nstream = nullptr;             // second transform stream (2^19 LDE rows and up): the LDE of chunk k beside the inverse transform of chunk k+1
   hipEvent_t intt_done[MAX_CHUNKS];          // main -> second transform stream: the coefficients of chunk k are complete
@@ -209,7 +209,7 @@ static int ntt_columns(sbn_prover* P, const u64* in, size_t in_cs, u64* out, siz
     if (P->fast_ntt && pa.log_r == 9 && log_n2 >= 4) pa.log_t = 4;  // the fast kernel always uses 16-wide tiles
     if (P->fast_ntt && pb.log_r == 9 && log_n1 >= 4) pb.log_t = 4;
     // 1,024-point first pass over an input whose rows 512.. are zero (the 2^19-point coset LDE): two 512-point fast passes
-    // on grid.z (kernels.cuh NttPassParams::split) instead of the generic radix-2 pass
+    // on grid.z (kernels_ntt.cuh NttPassParams::split) instead of the generic radix-2 pass
     const bool split_a = P->fast_ntt && !inverse && pa.log_r == 10 && log_n2 >= 4 && pa.in_st == 1 && n_in <= (size_t)512 * pa.in_sr && pre == P->d_shift && P->d_shift_odd;
     if (split_a) { pa.log_r = 9; pa.log_t = 4; pa.split = 1; pa.pre2 = P->d_shift_odd; }
     ga = dim3((unsigned)(n2 >> pa.log_t), (unsigned)nc, split_a ? 2u : 1u); gb = dim3((unsigned)(n1 >> pb.log_t), (unsigned)nc);
@@ -270,7 +270,7 @@ static int intt_then_lde(sbn_prover* P, const u64* vals, u64* coef, u64* lde, si
 }
 
 // The fused middle pass: inverse pass A -> d_tmp, [inverse pass B + LDE pass A] -> coefficients and `tmp2` on the main stream
-// (kernels.cuh ntt_fused_inv_b_lde_a_kernel at 2^16 / 2^17 rows; ntt_fused512_inv_b_lde_a_kernel at 2^18 rows, where the LDE's
+// (kernels_ntt.cuh ntt_fused_inv_b_lde_a_kernel at 2^16 / 2^17 rows; ntt_fused512_inv_b_lde_a_kernel at 2^18 rows, where the LDE's
 // pass A is the 1,024-point one in two halves); the LDE's pass B follows on `lde_stream` (the main stream, or the second transform
 // stream behind `handoff`).  Three launches per chunk instead of four / five.
 static int intt_lde_cols_fused(sbn_prover* P, const u64* v, u64* cf, u64* lde_out, size_t nc, u64* tmp2, hipStream_t lde_stream, hipEvent_t handoff) {
@@ -790,7 +790,7 @@ static int create_ctx(const sbn_air_desc* air, const sbn_config* cfg, uint32_t d
   auto blocks = [](size_t k) { return dim3((unsigned)((k + 255) / 256)); };
   F w = f_root_of_unity(P->lde_log);
   // FULL root tables (w^i for every i < m: the second half is the negated first): the register passes index them without the
-  // compare / negate of a half table (tw_full, kernels.cuh); everything else reads the first half only
+  // compare / negate of a half table (tw_full, kernels_ntt.cuh); everything else reads the first half only
   hipLaunchKernelGGL(pow_table_kernel, blocks(m), dim3(256), 0, P->stream, P->d_tw_f, m, w.v);
   hipLaunchKernelGGL(pow_table_kernel, blocks(m), dim3(256), 0, P->stream, P->d_tw_i, m, f_inv(w).v);
   hipLaunchKernelGGL(pow_table_kernel, blocks(m), dim3(256), 0, P->stream, P->d_shift, m, (u64)GL_GEN);
