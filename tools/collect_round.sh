@@ -1,7 +1,7 @@
 # Collects a round's evidence on a GPU box in one gpurun call:  bash tools/collect_round.sh <tag>   (files gpurun_out/<tag>_*)
 # GPU tests, tools/collect_profiles.sh (bench line, kernel trace, PMC passes), G2 / Fq12 / split / batch bench lines, the sponge
 # microbenchmark, parity under every A/B switch, 2-rank gloo rehearsals of the three bench modes.
-TAG=${1:-r4_v4}
+TAG=${1:-r4_v5}
 set -x
 cd $GRAFT_REPO_ROOT
 python -m pytest tests -x -q -m gpu > gpurun_out/${TAG}_gpu_tests.log 2>&1; echo rc=$? >> gpurun_out/${TAG}_gpu_tests.log; tail -3 gpurun_out/${TAG}_gpu_tests.log
