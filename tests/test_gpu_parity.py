@@ -85,7 +85,7 @@ def test_poseidon_reduction_edge_cases(gpu, O):
     assert np.array_equal(dev, gpu.poseidon_permute_host(big, use_definition=True))
 
 
-@pytest.mark.parametrize("ncols,n", [(1, 512), (3, 512), (4, 1024), (5, 512), (8, 2048), (9, 4096), (20, 1024), (17, 65536), (130, 16384), (3, 262144), (66, 262144)])
+@pytest.mark.parametrize("ncols,n", [(1, 512), (3, 512), (4, 1024), (5, 512), (8, 2048), (9, 4096), (20, 1024), (17, 65536), (130, 16384), (9, 131072), (3, 262144), (66, 262144)])
 def test_commit_matches_oracle(gpu, O, ncols, n):
     """PolynomialBatch::from_values: iNTT, coset LDE (shift 7, blow-up 2), Poseidon leaves, Merkle cap.
     Covers <=4 columns (hash_or_noop copies the row), a ragged last sponge block, and NTT sizes that
@@ -93,6 +93,34 @@ def test_commit_matches_oracle(gpu, O, ncols, n):
     rng = np.random.default_rng(ncols * 1000 + n)
     cols = rng.integers(0, P, size=(ncols, n), dtype=np.uint64)
     cols[0, :4] = [0, P - 1, 1, 0xFFFFFFFF00000000]
+    cap, co, lde = gpu.commit_values(cols, want_coeffs=True, want_lde=True)
+    rcap, rco, rlde = O.commit_values(cols, want_coeffs=True, want_lde=True)
+    assert np.array_equal(co, rco)
+    assert np.array_equal(lde, rlde)
+    assert np.array_equal(cap, rcap)
+
+
+@pytest.mark.parametrize("n", [65536, 131072, 262144])
+def test_commit_edge_values_in_the_register_passes(gpu, O, n):
+    """The register transform passes work on WEAK values (any u64 congruent mod p) whose carries are repaid twice; a uniformly random
+    column reaches the second repayment once in ~2^32 operations.  Columns built from the values around 0, 2^32 and p (constant,
+    alternating, in runs of 16 / 256 / 4096 rows, and mixed at random) push sums and differences to the wrap-around points all the time:
+    coefficients, LDE and cap must still equal the oracle's (canonical arithmetic).  One size per fused middle pass (2^16, 2^17, 2^18 rows)."""
+    edge = np.array([0, 1, 2, 0xFFFFFFFF, 0x100000000, 0x100000001, P - 1, P - 2, P - 0xFFFFFFFF, P - 0x100000000, P - 0x100000001,
+                     0xFFFFFFFE00000001, 0x7FFFFFFF80000000, 0xFFFFFFFF00000000 - 1, 0x8000000000000000, 0xFFFFFFFE00000000], dtype=np.uint64)
+    assert (edge < P).all()
+    rng = np.random.default_rng(n)
+    cols = np.zeros((16, n), dtype=np.uint64)
+    cols[0, :] = P - 1
+    cols[1, :] = np.where(np.arange(n) % 2 == 0, 0, P - 1)
+    cols[2, :] = 0xFFFFFFFF
+    cols[3, :] = np.where(np.arange(n) % 2 == 0, P - 1, 1)
+    for c, run in ((4, 16), (5, 256), (6, 4096)):
+        cols[c, :] = edge[(np.arange(n) // run) % len(edge)]
+    cols[7, :] = edge[np.arange(n) % len(edge)]
+    for c in range(8, 16):
+        cols[c, :] = edge[rng.integers(0, len(edge), size=n)]
+    cols[15, ::3] = rng.integers(0, P, size=len(cols[15, ::3]), dtype=np.uint64)
     cap, co, lde = gpu.commit_values(cols, want_coeffs=True, want_lde=True)
     rcap, rco, rlde = O.commit_values(cols, want_coeffs=True, want_lde=True)
     assert np.array_equal(co, rco)
